@@ -1,0 +1,244 @@
+"""Synthetic (random-init) weights and inputs at the reference's shapes.
+
+There is no network on the build or GPU boxes, so the released checkpoint and the
+BEAT-X data cannot be fetched; bench.py, smoke(), the tests and the golden-vector
+generator all use the deterministic tensors made here.  Every tensor is drawn
+from its own numpy Philox stream keyed by (seed, crc32(name)), so values do not
+depend on generation order, on torch, or on the platform.
+
+State-dict key names follow the reference module tree (SURVEY.md Appendix A;
+reference: mogen/models/transformers/diffusion_transformer.py:335-420,
+gesture_vae.py:25-98, utils/detr_utils.py:101-210,335-480), so the same dict
+loads into the reference classes with strict=True (done by
+tests/golden/make_goldens.py) and into this package's weight packer.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+NFEATS = {"upper": 78, "hands": 180, "face": 106, "lowertrans": 61}
+PARTS = ("upper", "hands", "face", "lowertrans")  # reference RNG/encode order
+
+
+def default_model_cfg(num_layers=8):
+    """Shapes of configs/raggesture_beatx/basegesture_len150_beat.py:32-160."""
+    return dict(
+        latent_dim=512, time_embed_dim=2048, num_heads=16, ff_size=1024,
+        num_layers=num_layers, max_seq_len=150, frame_chunk_size=15,
+        text_latent_dim=768, num_speakers=25,
+        scale_func_cfg=dict(coarse_scale=6.5, both_coef=0.52351, text_coef=-0.28419,
+                            retr_coef=2.39872),
+        per_joint_scale=dict(upper=1.0, hands=1.0, face=1.0, lowertransl=1.0),
+    )
+
+
+def default_vae_cfg(part, decoder_arch="all_encoder", latent_dim=512, num_layers=8,
+                    num_heads=4, ff_size=1024, position_embedding="learned",
+                    normalize_before=False, activation="gelu"):
+    """The VAE YAMLs ship with the weights, not with the repo; these are
+    the survey's probe hyper-parameters."""
+    return dict(
+        latent_dim=latent_dim, num_heads=num_heads, ff_size=ff_size, num_layers=num_layers,
+        decoder_arch=decoder_arch, position_embedding=position_embedding,
+        nfeats=NFEATS[part], vae_dist="normal", num_frames=150, frame_chunk_size=15,
+        transformer_activation=activation, transformer_normalize_before=normalize_before,
+        dropout=0.0, test_ckpt="synthetic.bin",
+    )
+
+
+def _rng(seed, name):
+    return np.random.Generator(np.random.Philox(key=[seed & 0xFFFFFFFF, zlib.crc32(name.encode())]))
+
+
+def _uniform(seed, name, shape, bound):
+    a = _rng(seed, name).uniform(-bound, bound, size=shape).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+def _normal(seed, name, shape, std=1.0, mean=0.0):
+    a = (_rng(seed, name).standard_normal(size=shape) * std + mean).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+def _linear(sd, seed, name, out_f, in_f):
+    b = 1.0 / math.sqrt(in_f)
+    sd[name + ".weight"] = _uniform(seed, name + ".weight", (out_f, in_f), b)
+    sd[name + ".bias"] = _uniform(seed, name + ".bias", (out_f,), b)
+
+
+def _layernorm(sd, seed, name, d):
+    sd[name + ".weight"] = _normal(seed, name + ".weight", (d,), 0.1, 1.0)
+    sd[name + ".bias"] = _normal(seed, name + ".bias", (d,), 0.1)
+
+
+def sine_pe(max_len, d_model):
+    """PositionEmbeddingSine1D table (reference utils/detr_utils.py:33-41), [max_len,1,d]."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0).transpose(0, 1).contiguous()
+
+
+def _stylization(sd, seed, name, d, te):
+    _linear(sd, seed, name + ".emb_layers.1", 2 * d, te)
+    _layernorm(sd, seed, name + ".norm", d)
+    _linear(sd, seed, name + ".out_layers.2", d, d)  # zero_module in the reference; re-randomised
+
+
+def synth_denoiser_state(seed=0, cfg=None, prefix=""):
+    """ReGestureTransformer state dict (without the VAEs)."""
+    cfg = cfg or default_model_cfg()
+    d, te, ff = cfg["latent_dim"], cfg["time_embed_dim"], cfg["ff_size"]
+    n_lat = cfg["max_seq_len"] // cfg["frame_chunk_size"]
+    t_tok = 4 * n_lat + 3
+    sd = {}
+    bound = math.sqrt(6.0 / (t_tok + d))
+    sd["global_positional_embedding.pe"] = _uniform(seed, "global_positional_embedding.pe",
+                                                    (t_tok, 1, d), bound)
+    sd["sequence_embedding.pe"] = sine_pe(n_lat, d)
+    _linear(sd, seed, "text_pre_proj", d, cfg["text_latent_dim"])
+    _linear(sd, seed, "audio_pre_proj", d, cfg["text_latent_dim"])
+    sd["speaker_embedding.weight"] = _normal(seed, "speaker_embedding.weight",
+                                             (cfg["num_speakers"], d), 1.0 / d)
+    _linear(sd, seed, "joint_embed", d, d)
+    _linear(sd, seed, "time_embed.0", te, d)
+    _linear(sd, seed, "time_embed.2", te, te)
+    _linear(sd, seed, "out", d, d)
+    for l in range(cfg["num_layers"]):
+        p = "temporal_decoder_blocks.%d." % l
+        _layernorm(sd, seed, p + "sa_block.norm", d)
+        for n in ("query", "key", "value"):
+            _linear(sd, seed, p + "sa_block." + n, d, d)
+        _stylization(sd, seed, p + "sa_block.proj_out", d, te)
+        for c in ("xf_text", "xf_audio", "xf_spk"):
+            q = p + "ca_blocks.%s." % c
+            _layernorm(sd, seed, q + "norm", d)
+            _layernorm(sd, seed, q + "text_norm", d)
+            for n in ("query", "key", "value"):
+                _linear(sd, seed, q + n, d, d)
+            _stylization(sd, seed, q + "proj_out", d, te)
+        _linear(sd, seed, p + "ca_mix", d, 3 * d)
+        _linear(sd, seed, p + "ffn.linear1", ff, d)
+        _linear(sd, seed, p + "ffn.linear2", d, ff)
+        _stylization(sd, seed, p + "ffn.proj_out", d, te)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def _mha_block(sd, seed, name, d, ff, cross=False):
+    xb = math.sqrt(6.0 / (4 * d))
+    sd[name + ".self_attn.in_proj_weight"] = _uniform(seed, name + ".self_attn.in_proj_weight", (3 * d, d), xb)
+    sd[name + ".self_attn.in_proj_bias"] = _normal(seed, name + ".self_attn.in_proj_bias", (3 * d,), 0.02)
+    _linear(sd, seed, name + ".self_attn.out_proj", d, d)
+    if cross:
+        sd[name + ".multihead_attn.in_proj_weight"] = _uniform(seed, name + ".multihead_attn.in_proj_weight", (3 * d, d), xb)
+        sd[name + ".multihead_attn.in_proj_bias"] = _normal(seed, name + ".multihead_attn.in_proj_bias", (3 * d,), 0.02)
+        _linear(sd, seed, name + ".multihead_attn.out_proj", d, d)
+    _linear(sd, seed, name + ".linear1", ff, d)
+    _linear(sd, seed, name + ".linear2", d, ff)
+    _layernorm(sd, seed, name + ".norm1", d)
+    _layernorm(sd, seed, name + ".norm2", d)
+    if cross:
+        _layernorm(sd, seed, name + ".norm3", d)
+
+
+def _skip_stack(sd, seed, name, d, ff, num_layers, cross=False):
+    if num_layers % 2 == 0:
+        num_layers += 1
+    nb = (num_layers - 1) // 2
+    for i in range(nb):
+        _mha_block(sd, seed, "%s.input_blocks.%d" % (name, i), d, ff, cross)
+    _mha_block(sd, seed, name + ".middle_block", d, ff, cross)
+    for i in range(nb):
+        _mha_block(sd, seed, "%s.output_blocks.%d" % (name, i), d, ff, cross)
+        _linear(sd, seed, "%s.linear_blocks.%d" % (name, i), d, 2 * d)
+    _layernorm(sd, seed, name + ".norm", d)
+
+
+def synth_vae_state(seed, vcfg, prefix=""):
+    """TransformerVAE state dict for one body part (reference gesture_vae.py:25-98)."""
+    d, ff = vcfg["latent_dim"], vcfg["ff_size"]
+    sd = {}
+    sd["global_motion_token"] = _normal(seed, "global_motion_token", (2, d), 1.0)
+    for n in ("query_pos_encoder", "query_pos_decoder", "mem_pos_decoder"):
+        if vcfg["position_embedding"] == "learned":
+            sd[n + ".pe"] = _uniform(seed, n + ".pe", (1024, 1, d), math.sqrt(6.0 / (1024 + d)))
+        else:
+            sd[n + ".pe"] = sine_pe(1024, d)
+    _skip_stack(sd, seed, "encoder", d, ff, vcfg["num_layers"], cross=False)
+    if vcfg["decoder_arch"] == "all_encoder":
+        _skip_stack(sd, seed, "decoder", d, ff, vcfg["num_layers"], cross=False)
+    else:
+        _skip_stack(sd, seed, "decoder", d, ff, (vcfg["num_layers"] - 1) * 4 + 1, cross=True)
+    _linear(sd, seed, "skel_embedding", d, vcfg["nfeats"])
+    _linear(sd, seed, "final_layer", vcfg["nfeats"], d)
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def synth_vae_cfgs(decoder_arch="all_encoder", **kw):
+    return {p: default_vae_cfg(p, decoder_arch=decoder_arch, **kw) for p in PARTS}
+
+
+def synth_full_state(seed=0, cfg=None, vae_cfgs=None):
+    """Denoiser + 4 VAEs under the reference's sub-module names (no `model.` prefix)."""
+    cfg = cfg or default_model_cfg()
+    vae_cfgs = vae_cfgs or synth_vae_cfgs()
+    sd = synth_denoiser_state(seed, cfg)
+    for i, part in enumerate(PARTS):
+        sd.update(synth_vae_state(seed + 101 + i, vae_cfgs[part],
+                                  prefix="gesture_rep_encoder.%s_vae." % part))
+    return sd
+
+
+class NoiseTape:
+    """Explicit noise source shared by the reference (patched), the oracle and the HIP path.
+
+    The reference draws from torch's global generator in the order of SURVEY.md
+    Appendix D; "same seed" therefore means "same noise tensors".  draw(shape) returns
+    the next standard-normal fp32 tensor of a numpy PCG64 stream.
+    """
+
+    def __init__(self, seed):
+        self._g = np.random.Generator(np.random.PCG64(seed))
+        self.count = 0
+
+    def draw(self, shape, device=None):
+        self.count += 1
+        t = torch.from_numpy(self._g.standard_normal(size=tuple(shape), dtype=np.float32))
+        return t.to(device) if device is not None else t
+
+
+def synth_batch(batch, seed=1234, device="cpu"):
+    """Synthetic collated batch with the schema of mogen/datasets/builder.py:55-92 and the
+    value distributions of SURVEY.md section 8(d)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+
+    def u(shape, a):
+        return torch.from_numpy(g.uniform(-a, a, size=shape).astype(np.float32))
+
+    def n(shape, s):
+        return torch.from_numpy((g.standard_normal(size=shape) * s).astype(np.float32))
+
+    B = batch
+    d = dict(
+        motion_upper=u((B, 150, 39), 0.3), motion_lower=u((B, 150, 27), 0.3),
+        motion_face=u((B, 150, 3), 0.3), motion_hands=u((B, 150, 90), 0.3),
+        facial=n((B, 150, 100), 0.3), trans=n((B, 150, 3), 0.1),
+        contact=torch.from_numpy((g.uniform(size=(B, 150, 4)) < 0.5).astype(np.float32)),
+        motion_mask=torch.ones(B, 150),
+        audio=n((B, 499, 768), 1.0), word=n((B, 150, 768), 1.0),
+        speaker_ids=torch.zeros(B, 150, dtype=torch.int64),
+    )
+    d["motion"] = torch.zeros(B, 150, 165)
+    d = {k: v.to(device) for k, v in d.items()}
+    d.update(
+        motion_length=[150] * B, raw_word=[[""] * 150 for _ in range(B)], raw_audio=None,
+        text_features=[n((int(g.integers(12, 49)), 768), 1.0) for _ in range(B)],
+        text_segments=[[] for _ in range(B)], gesture_labels=[[] for _ in range(B)],
+        discourse=[[] for _ in range(B)], prominence=[[] for _ in range(B)],
+        sample_idx=list(range(B)), sample_name=["synthetic_%04d" % i for i in range(B)],
+    )
+    return d

@@ -1,0 +1,264 @@
+"""Generate golden vectors by running the REAL reference (/root/reference) in this container.
+
+    python tests/golden/make_goldens.py            # writes tests/golden/*.npz
+
+The reference has no tests or fixtures of its own, so its outputs on seeded
+synthetic weights/inputs are the only pin for the oracle.  Weights and inputs are NOT
+stored: they are regenerated from seeds by rag-gesture_amd/synth.py (numpy Philox/PCG64,
+platform independent); only expected outputs (and a few intermediate tensors) are stored.
+
+All randomness of the reference is routed through synth.NoiseTape by patching
+torch.randn / torch.randn_like / torch.distributions' _standard_normal for the duration
+of each run, so the oracle and the HIP path can replay the identical noise
+(SURVEY Appendix D gives the consumption order).
+
+Runs only where /root/reference exists; nothing on the GPU box imports this file.
+"""
+import contextlib
+import importlib
+import os
+import sys
+import tempfile
+import copy
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+
+import _ref_import  # noqa: E402
+
+rg = importlib.import_module("rag-gesture_amd")
+synth = rg.synth
+
+
+@contextlib.contextmanager
+def taped_noise(tape):
+    """Route every normal draw of the reference through `tape` (SURVEY Appendix D order)."""
+    import torch.distributions.normal as tdn
+    import torch.distributions.utils as tdu
+
+    o_randn, o_like, o_sn1, o_sn2 = torch.randn, torch.randn_like, tdn._standard_normal, tdu._standard_normal
+
+    def randn(*shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        return tape.draw(shape)
+
+    def randn_like(t, **kw):
+        return tape.draw(tuple(t.shape))
+
+    def std_normal(shape, dtype, device):
+        return tape.draw(tuple(shape))
+
+    torch.randn, torch.randn_like = randn, randn_like
+    tdn._standard_normal = tdu._standard_normal = std_normal
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = o_randn, o_like
+        tdn._standard_normal, tdu._standard_normal = o_sn1, o_sn2
+
+
+def build_reference_model(ns, cfg, vae_cfgs, seed, tmpdir, inference_type="ddim"):
+    """Instantiate the reference MotionDiffusion at `cfg` shapes with synthetic weights."""
+    paths = {}
+    for i, part in enumerate(synth.PARTS):
+        d = os.path.join(tmpdir, part)
+        os.makedirs(d, exist_ok=True)
+        ypath = os.path.join(d, part + ".yaml")
+        with open(ypath, "w") as f:
+            yaml.safe_dump(vae_cfgs[part], f)
+        sd = synth.synth_vae_state(seed + 101 + i, vae_cfgs[part])
+        torch.save({"model_state": sd}, os.path.join(d, vae_cfgs[part]["test_ckpt"]))
+        paths[part] = ypath
+    d, te, H = cfg["latent_dim"], cfg["time_embed_dim"], cfg["num_heads"]
+    model_cfg = dict(
+        type="MotionDiffusion",
+        model=dict(
+            type="ReGestureTransformer", input_feats=189, max_seq_len=cfg["max_seq_len"],
+            frame_chunk_size=cfg["frame_chunk_size"], latent_dim=d, time_embed_dim=te,
+            num_layers=cfg["num_layers"], body_part_cat_axis="time",
+            sa_block_cfg=dict(type="EfficientSelfAttention", latent_dim=d, num_heads=H, dropout=0, time_embed_dim=te),
+            ca_block_cfg=dict(type="EfficientCrossAttention", latent_dim=d, text_latent_dim=d, num_heads=H,
+                              dropout=0, time_embed_dim=te),
+            ffn_cfg=dict(latent_dim=d, ffn_dim=cfg["ff_size"], dropout=0, time_embed_dim=te),
+            vae_cfg=dict(upper_cfg=paths["upper"], lowertrans_cfg=paths["lowertrans"], face_cfg=paths["face"],
+                         hands_cfg=paths["hands"], latent_dim=d, frame_chunk_size=cfg["frame_chunk_size"]),
+            text_encoder=dict(pretrained_model=None, latent_dim=cfg["text_latent_dim"], num_layers=0,
+                              ff_size=2048, dropout=0, use_text_proj=False),
+            audio_encoder=dict(pretrained_model=None, latent_dim=cfg["text_latent_dim"], num_layers=0, dropout=0.1),
+            speaker_embedding=dict(num_speakers=cfg["num_speakers"]),
+            retrieval_train=False, retrieval_cfg=None,
+            scale_func_cfg=dict(cfg["scale_func_cfg"]), per_joint_scale=dict(cfg["per_joint_scale"]),
+        ),
+        loss_recon=dict(type="MSELoss", loss_weight=1, reduction="none"),
+        body_part_lossweights=dict(upper=1.0, hands=1.0, face=1.0, lowertransl=1.0),
+        diffusion_train=dict(beta_scheduler="scaled_linear", diffusion_steps=1000, model_mean_type="start_x",
+                             model_var_type="fixed_large"),
+        diffusion_test=dict(beta_scheduler="scaled_linear", diffusion_steps=1000, model_mean_type="start_x",
+                            model_var_type="fixed_large", respace="15,15,8,6,6", num_inference_timesteps=50,
+                            classifier_free_guidance_scale=0),
+        inference_type=inference_type,
+    )
+    model = ns.builder.build_architecture(model_cfg, database=None)
+    full = synth.synth_full_state(seed, cfg, vae_cfgs)
+    missing, unexpected = model.model.load_state_dict(full, strict=True), None
+    model.eval()
+    return model, full
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+def main():
+    ns = _ref_import.load_reference()
+    torch.set_num_threads(8)
+    out = {}
+    from oracle import denoiser as od, diffusion as odf, rotation as orot, vae as ovae
+
+    # ---- (i) schedule tables -------------------------------------------------------------
+    diff = ns.arch.build_diffusion(dict(beta_scheduler="scaled_linear", diffusion_steps=1000,
+                                        model_mean_type="start_x", model_var_type="fixed_large",
+                                        respace="15,15,8,6,6", num_inference_timesteps=50,
+                                        classifier_free_guidance_scale=0))
+    sch = odf.SpacedSchedule()
+    assert sch.timestep_map == diff.timestep_map
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next",
+              "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "sqrt_alphas_cumprod",
+              "sqrt_one_minus_alphas_cumprod"):
+        assert np.array_equal(getattr(sch, k), getattr(diff, k)), k
+    np.savez(os.path.join(HERE, "schedule.npz"), timestep_map=np.array(diff.timestep_map),
+             betas=diff.betas, alphas_cumprod=diff.alphas_cumprod,
+             sqrt_recip_alphas_cumprod=diff.sqrt_recip_alphas_cumprod,
+             sqrt_recipm1_alphas_cumprod=diff.sqrt_recipm1_alphas_cumprod)
+    print("schedule ok")
+
+    # ---- (ii) rotation conversions ---------------------------------------------------------
+    g = np.random.Generator(np.random.PCG64(7))
+    aa = g.uniform(-0.3, 0.3, size=(64, 3)).astype(np.float32)
+    aa_small = (g.standard_normal((16, 3)) * 1e-8).astype(np.float32)
+    axis = g.standard_normal((16, 3)); axis /= np.linalg.norm(axis, axis=-1, keepdims=True)
+    aa_pi = (axis * (np.pi - g.uniform(0, 1e-3, size=(16, 1)))).astype(np.float32)
+    aa_big = g.uniform(-2.5, 2.5, size=(32, 3)).astype(np.float32)
+    aa_all = torch.from_numpy(np.concatenate([aa, aa_small, aa_pi, aa_big], 0))
+    d6 = ns.rc.matrix_to_rotation_6d(ns.rc.axis_angle_to_matrix(aa_all))
+    d6_in = torch.from_numpy(g.standard_normal((128, 6)).astype(np.float32))
+    aa_out = ns.rc.matrix_to_axis_angle(ns.rc.rotation_6d_to_matrix(d6_in))
+    aa_rt = ns.rc.matrix_to_axis_angle(ns.rc.rotation_6d_to_matrix(d6))
+    np.savez(os.path.join(HERE, "rotation.npz"), aa_in=t2n(aa_all), d6_out=t2n(d6), d6_in=t2n(d6_in),
+             aa_out=t2n(aa_out), aa_roundtrip=t2n(aa_rt))
+    e1 = (orot.matrix_to_rotation_6d(orot.axis_angle_to_matrix(aa_all)) - d6).abs().max().item()
+    e2 = (orot.matrix_to_axis_angle(orot.rotation_6d_to_matrix(d6_in)) - aa_out).abs().max().item()
+    print("rotation oracle-vs-ref max abs", e1, e2)
+
+    # ---- (iii)-(v),(viii): model-level goldens --------------------------------------------
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, L, arch in (("L2_allenc", 2, "all_encoder"), ("L8_encdec", 8, "encoder_decoder")):
+            cfg = synth.default_model_cfg(num_layers=L)
+            vkw = dict(num_layers=4, ff_size=512) if arch == "encoder_decoder" else {}
+            vae_cfgs = synth.synth_vae_cfgs(decoder_arch=arch, **vkw)
+            model, full = build_reference_model(ns, cfg, vae_cfgs, seed=0, tmpdir=os.path.join(tmp, tag))
+            run_model_goldens(ns, model, full, cfg, vae_cfgs, tag)
+
+
+def run_model_goldens(ns, model, full, cfg, vae_cfgs, tag):
+    from oracle import denoiser as od, diffusion as odf, vae as ovae, pipeline as opipe
+    B = 2
+    net = model.model
+    res = {}
+    # -- denoiser forward at 4 timesteps (CFG mix), real query masks and all-ones masks
+    data = synth.synth_batch(B, seed=1234)
+    g = np.random.Generator(np.random.PCG64(99))
+    x = torch.from_numpy(g.standard_normal((B, 43, 512)).astype(np.float32))
+    motion_mask = torch.ones(B, 43); motion_mask[:, [10, 21, 32]] = 0
+    xf = od.encode_conditions(full, data["word"], data["audio"], data["speaker_ids"])
+    qm_real = od.make_query_masks(motion_mask)
+    qm_ones = {k: torch.ones_like(v) for k, v in qm_real.items()}
+    with torch.no_grad():
+        ref_xf = net.get_precompute_condition(text=data["word"], audio=data["audio"],
+                                              speaker_ids=data["speaker_ids"], device="cpu", re_dict=1)["xf_out"]
+        for k in xf:
+            assert torch.allclose(xf[k], ref_xf[k], atol=1e-6), k
+        for t in (999, 514, 99, 0):
+            ts = torch.full((B,), t, dtype=torch.long)
+            for mtag, qm in (("real", qm_real), ("ones", qm_ones)):
+                ref = net(x, ts, motion_mask=motion_mask, xf_out=ref_xf, re_dict=1,
+                          query_mask=copy.deepcopy(qm))
+                mine = od.denoiser_forward(full, cfg, x, ts, motion_mask, xf, qm)
+                keep = [r for r in range(43) if r not in (10, 20, 30)]
+                err = (ref - mine).abs().max().item()
+                errk = (ref[:, keep] - mine[:, keep]).abs().max().item()
+                print(tag, "denoiser t=%d mask=%s oracle-vs-ref max abs %.3e (rows!=10,20,30: %.3e) |ref| %.3f"
+                      % (t, mtag, err, errk, ref.abs().max().item()))
+                res["den_%s_t%d" % (mtag, t)] = t2n(ref)
+    np.savez(os.path.join(HERE, "denoiser_%s.npz" % tag), **res)
+
+    # -- VAE encode (with explicit eps) / decode of a fixed latent
+    sch = odf.SpacedSchedule()
+    res = {}
+    gre = net.gesture_rep_encoder
+    data = synth.synth_batch(B, seed=1234)
+    with torch.no_grad(), taped_noise(synth.NoiseTape(555)):
+        lat_ref, mask_ref = gre.encode(data["motion_upper"], data["motion_lower"], data["motion_face"],
+                                       data["motion_hands"], data["trans"].clone(), data["facial"],
+                                       data["contact"], data["motion_mask"])
+    tape = synth.NoiseTape(555)
+    d2 = synth.synth_batch(B, seed=1234)
+    lat_mine, mask_mine = ovae.gesture_encode(full, vae_cfgs, d2, [tape.draw((B * 10, 1, 512)) for _ in range(4)])
+    print(tag, "vae encode oracle-vs-ref max abs %.3e |ref| %.3f" % ((lat_ref - lat_mine).abs().max().item(),
+                                                                      lat_ref.abs().max().item()))
+    assert torch.equal(mask_ref, mask_mine)
+    res["enc_latent"] = t2n(lat_ref)
+    zl = torch.from_numpy(g.standard_normal((B, 43, 512)).astype(np.float32))
+    with torch.no_grad():
+        dec_ref = gre.decode(zl)
+    dec_mine = ovae.gesture_decode(full, vae_cfgs, zl)
+    for nm, a, b in zip(("upper", "lower", "face", "hands", "transl", "exps", "contact"), dec_ref, dec_mine):
+        print(tag, "vae decode %s oracle-vs-ref max abs %.3e |ref| %.3f" % (nm, (a - b).abs().max().item(), a.abs().max().item()))
+        res["dec_" + nm] = t2n(a)
+    np.savez(os.path.join(HERE, "vae_%s.npz" % tag), **res)
+
+    # -- end to end: MotionDiffusion.forward(**data)
+    e2e_B = 2 if cfg["num_layers"] <= 2 else 1
+    gi = [0] * 25 + list(range(25))
+    runs = [("base", dict(), False)]
+    runs.append(("guided", dict(use_inversion=True, insertion_guidance=True, guidance_iters=gi, guidance_lr=0.1), True))
+    if cfg["num_layers"] <= 2:
+        runs.append(("invonly", dict(use_inversion=True), True))
+        runs.append(("guidedprev", dict(use_inversion=True, insertion_guidance=True, guidance_iters=gi, guidance_lr=0.1,
+                                        use_prev_latent=True), True))
+        runs.append(("prevonly", dict(use_prev_latent=True), False))
+    res = {}
+    for rtag, ikw, need_re in runs:
+        data = synth.synth_batch(e2e_B, seed=4321)
+        re_dict = opipe.synthetic_re_dict(e2e_B, seed=77) if need_re else None
+        prev = None
+        if ikw.get("use_prev_latent"):
+            prev = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal((e2e_B, 43, 512)).astype(np.float32))
+        net.database = (lambda *a, **k: re_dict) if need_re else None
+        rkw = dict(ikw)
+        if prev is not None:
+            rkw["prev_latent"] = prev.clone()
+        with torch.no_grad(), taped_noise(synth.NoiseTape(2024)), contextlib.redirect_stdout(open(os.devnull, "w")):
+            ref = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(rkw)))
+        data2 = synth.synth_batch(e2e_B, seed=4321)
+        okw = {k: v for k, v in ikw.items()}
+        mine = opipe.motion_diffusion_forward(full, cfg, vae_cfgs, sch, data2, synth.NoiseTape(2024), re_dict=re_dict,
+                                              prev_latent=prev.clone() if prev is not None else None, **okw)
+        for k in ("prev_latentout", "pred_upper", "pred_lower", "pred_facepose", "pred_hands", "pred_transl", "pred_exps"):
+            print(tag, rtag, k, "oracle-vs-ref max abs %.3e |ref| %.3f" % ((ref[k] - mine[k]).abs().max().item(),
+                                                                            ref[k].abs().max().item()))
+            res["%s_%s" % (rtag, k)] = t2n(ref[k])
+    net.database = None
+    np.savez(os.path.join(HERE, "e2e_%s.npz" % tag), **res)
+
+
+if __name__ == "__main__":
+    main()
