@@ -13,12 +13,31 @@ import torch.nn.functional as F
 T_TOKENS = 43
 
 
+# Checker-side switches (defaults = the reference's arithmetic):
+#   bf16      : round both GEMM operands to bfloat16 (fp32 accumulate), i.e. what the HIP path's
+#               MFMA GEMMs consume, so structural parity can be checked at a tight tolerance.
+#   masked_ln : "torch" = F.layer_norm in fp32 on the -1e6-offset rows (implementation-defined
+#               rounding of a mean near -1e6, see DESIGN.md "masked query rows");
+#               "exact" = the same LayerNorm evaluated in fp64 on the fp32-quantised row.
+OPTS = {"bf16": False, "masked_ln": "torch"}
+
+
 def linear(P, name, x):
-    return F.linear(x, P[name + ".weight"], P[name + ".bias"])
+    w = P[name + ".weight"]
+    if OPTS["bf16"]:
+        return F.linear(x.bfloat16().float(), w.bfloat16().float(), P[name + ".bias"])
+    return F.linear(x, w, P[name + ".bias"])
 
 
 def layer_norm(P, name, x):
-    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], 1e-5)
+    y = F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], 1e-5)
+    if OPTS["masked_ln"] == "exact":
+        big = x.abs().amax(dim=-1) > 1e5
+        if bool(big.any()):
+            y64 = F.layer_norm(x.double(), (x.shape[-1],), P[name + ".weight"].double(),
+                               P[name + ".bias"].double(), 1e-5).float()
+            y = torch.where(big.unsqueeze(-1), y64, y)
+    return y
 
 
 def timestep_embedding(timesteps, dim, max_period=10000):

@@ -1,0 +1,41 @@
+// Internal helpers shared by the HIP translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/rg_gesture.h"
+
+struct rg_handle {
+  int device = 0;
+  int num_cus = 256;
+  std::string err;
+};
+
+#define RG_REQUIRE(h, cond, msg)                                   \
+  do {                                                             \
+    if (!(cond)) {                                                 \
+      if (h) (h)->err = std::string(__func__) + ": " + (msg);      \
+      return RG_ERR_INVALID;                                       \
+    }                                                              \
+  } while (0)
+
+#define RG_CHECK_LAUNCH(h)                                                         \
+  do {                                                                             \
+    hipError_t e__ = hipGetLastError();                                            \
+    if (e__ != hipSuccess) {                                                       \
+      if (h) (h)->err = std::string(__func__) + ": " + hipGetErrorString(e__);     \
+      return RG_ERR_HIP;                                                           \
+    }                                                                              \
+  } while (0)
+
+static inline hipStream_t rg_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// grid for a grid-stride memory-bound kernel: enough blocks to fill 256 CUs x 8, no more.
+static inline int rg_grid_1d(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}

@@ -1,0 +1,201 @@
+// Sampler elementwise kernels: DDIM update / inversion update, CFG mix + DDIM, in-sequence
+// replacement, insertion-guidance update, exemplar splice.  All HBM-bandwidth bound:
+// 16 B per lane coalesced accesses, grid-stride, no LDS.  (include/rg_gesture.h cites the
+// reference lines each one replaces.)
+#include "rg_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// The reference evaluates eps and the update as separate fp32 torch ops; keep the same
+// operation order and forbid FMA contraction so results match the fp32 oracle bit for bit.
+#pragma clang fp contract(off)
+__device__ __forceinline__ float ddim_one(float x, float x0, float c_recip, float c_recipm1,
+                                          float c_a, float c_b) {
+  float eps = (c_recip * x - x0) / c_recipm1;
+  return x0 * c_a + c_b * eps;
+}
+
+__global__ void __launch_bounds__(kBlock) ddim_update_kernel(const float4* __restrict__ x,
+                                                            const float4* __restrict__ x0,
+                                                            float4* __restrict__ xo, int64_t n4,
+                                                            float c_recip, float c_recipm1,
+                                                            float c_a, float c_b) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    float4 a = x[i], b = x0[i], r;
+    r.x = ddim_one(a.x, b.x, c_recip, c_recipm1, c_a, c_b);
+    r.y = ddim_one(a.y, b.y, c_recip, c_recipm1, c_a, c_b);
+    r.z = ddim_one(a.z, b.z, c_recip, c_recipm1, c_a, c_b);
+    r.w = ddim_one(a.w, b.w, c_recip, c_recipm1, c_a, c_b);
+    xo[i] = r;
+  }
+}
+
+__device__ __forceinline__ float cfg_one(float oc, float ou, float jc, float ju, float w_c, float w_u) {
+  // reference order: out_text*both*js + out_text*text*js + out_none*retr/js + out_none*none/js;
+  // with (both,text) and (retr,none) pre-summed on the host (one of each pair is 0 for t>100).
+  return oc * w_c * jc + ou * w_u * ju;
+}
+
+__global__ void __launch_bounds__(kBlock) cfg_ddim_kernel(const float4* __restrict__ out,
+                                                         const float4* __restrict__ x,
+                                                         float4* __restrict__ xo, float4* __restrict__ x0o,
+                                                         const float* __restrict__ js, int64_t n4, int td4,
+                                                         int d4, float w_c, float w_u, float c_recip,
+                                                         float c_recipm1, float c_a, float c_b) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    int t = (int)((i % td4) / d4);
+    float jc = js[t];
+    float ju = 1.0f / jc;
+    float4 oc = out[i], ou = out[i + n4], a = x[i], p, r;
+    p.x = cfg_one(oc.x, ou.x, jc, ju, w_c, w_u);
+    p.y = cfg_one(oc.y, ou.y, jc, ju, w_c, w_u);
+    p.z = cfg_one(oc.z, ou.z, jc, ju, w_c, w_u);
+    p.w = cfg_one(oc.w, ou.w, jc, ju, w_c, w_u);
+    r.x = ddim_one(a.x, p.x, c_recip, c_recipm1, c_a, c_b);
+    r.y = ddim_one(a.y, p.y, c_recip, c_recipm1, c_a, c_b);
+    r.z = ddim_one(a.z, p.z, c_recip, c_recipm1, c_a, c_b);
+    r.w = ddim_one(a.w, p.w, c_recip, c_recipm1, c_a, c_b);
+    xo[i] = r;
+    if (x0o) x0o[i] = p;
+  }
+}
+
+// One wave per token row: the wave first decides m = any(in_seq[row] != 0) with a ballot,
+// then rewrites the row.  dim is a multiple of 4.
+__global__ void __launch_bounds__(kBlock) inseq_replace_kernel(float* __restrict__ x,
+                                                              const float* __restrict__ in_seq,
+                                                              const float* __restrict__ noise, int rows,
+                                                              int dim, float s_ab, float s_1mab) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * kBlock) >> 6;
+  const int d4 = dim >> 2;
+  for (int r = wave; r < rows; r += nwaves) {
+    const float4* s = reinterpret_cast<const float4*>(in_seq + (int64_t)r * dim);
+    bool nz = false;
+    for (int j = lane; j < d4; j += 64) {
+      float4 v = s[j];
+      nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    }
+    if (__ballot(nz) == 0ull) continue;
+    const float4* nn = reinterpret_cast<const float4*>(noise + (int64_t)r * dim);
+    float4* xr = reinterpret_cast<float4*>(x + (int64_t)r * dim);
+    for (int j = lane; j < d4; j += 64) {
+      float4 v = s[j], e = nn[j], o;
+      o.x = s_ab * v.x + s_1mab * e.x;
+      o.y = s_ab * v.y + s_1mab * e.y;
+      o.z = s_ab * v.z + s_1mab * e.z;
+      o.w = s_ab * v.w + s_1mab * e.w;
+      xr[j] = o;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) guidance_kernel(float* __restrict__ x, const float* __restrict__ in_seq,
+                                                         int rows, int dim, int g_iter, float lr,
+                                                         float two_over_numel) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * kBlock) >> 6;
+  const int d4 = dim >> 2;
+  for (int r = wave; r < rows; r += nwaves) {
+    const float4* s = reinterpret_cast<const float4*>(in_seq + (int64_t)r * dim);
+    bool nz = false;
+    for (int j = lane; j < d4; j += 64) {
+      float4 v = s[j];
+      nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+    }
+    if (__ballot(nz) == 0ull) continue;  // gradient is exactly 0 on unmasked rows
+    float4* xr = reinterpret_cast<float4*>(x + (int64_t)r * dim);
+    for (int j = lane; j < d4; j += 64) {
+      float4 y = s[j], v = xr[j];
+      for (int it = 0; it < g_iter; ++it) {
+        v.x = v.x - lr * (two_over_numel * (v.x - y.x));
+        v.y = v.y - lr * (two_over_numel * (v.y - y.y));
+        v.z = v.z - lr * (two_over_numel * (v.z - y.z));
+        v.w = v.w - lr * (two_over_numel * (v.w - y.w));
+      }
+      xr[j] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBlock) splice_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                       int d4, int nrows, int src_row0, int dst_row0,
+                                                       int hands_off) {
+  // rows [0,nrows): upper block; rows [nrows, 2*nrows): hands block (offset hands_off token rows)
+  int64_t total = (int64_t)2 * nrows * d4;
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int r = (int)(i / d4), c = (int)(i % d4);
+    int off = (r >= nrows) ? hands_off : 0;
+    int rr = (r >= nrows) ? r - nrows : r;
+    dst[(int64_t)(dst_row0 + off + rr) * d4 + c] = src[(int64_t)(src_row0 + off + rr) * d4 + c];
+  }
+}
+
+}  // namespace
+
+extern "C" int rg_ddim_update(rg_handle* h, const float* x, const float* x0, float* x_out, int64_t n,
+                              float c_recip, float c_recipm1, float c_a, float c_b, void* stream) {
+  RG_REQUIRE(h, x && x0 && x_out, "null pointer");
+  RG_REQUIRE(h, n > 0 && n % 4 == 0, "n must be a positive multiple of 4");
+  int64_t n4 = n / 4;
+  hipLaunchKernelGGL(ddim_update_kernel, dim3(rg_grid_1d(n4, kBlock)), dim3(kBlock), 0, rg_stream(stream),
+                     (const float4*)x, (const float4*)x0, (float4*)x_out, n4, c_recip, c_recipm1, c_a, c_b);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_cfg_ddim_update(rg_handle* h, const float* out, const float* x, float* x_out, float* x0_out,
+                                  const float* js, int B, int T, int D, float w_c, float w_u, float c_recip,
+                                  float c_recipm1, float c_a, float c_b, void* stream) {
+  RG_REQUIRE(h, out && x && x_out && js, "null pointer");
+  RG_REQUIRE(h, B > 0 && T > 0 && D > 0 && D % 4 == 0, "bad shape");
+  int64_t n4 = (int64_t)B * T * D / 4;
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(rg_grid_1d(n4, kBlock)), dim3(kBlock), 0, rg_stream(stream),
+                     (const float4*)out, (const float4*)x, (float4*)x_out, (float4*)x0_out, js, n4, T * D / 4,
+                     D / 4, w_c, w_u, c_recip, c_recipm1, c_a, c_b);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_inseq_replace(rg_handle* h, float* x, const float* in_seq, const float* noise, int rows,
+                                int dim, float s_ab, float s_1mab, void* stream) {
+  RG_REQUIRE(h, x && in_seq && noise, "null pointer");
+  RG_REQUIRE(h, rows > 0 && dim > 0 && dim % 4 == 0, "bad shape");
+  int grid = rg_grid_1d((int64_t)rows * 64, kBlock);
+  hipLaunchKernelGGL(inseq_replace_kernel, dim3(grid), dim3(kBlock), 0, rg_stream(stream), x, in_seq, noise,
+                     rows, dim, s_ab, s_1mab);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_guidance_update(rg_handle* h, float* x, const float* in_seq, int rows, int dim, int g_iter,
+                                  float lr, void* stream) {
+  RG_REQUIRE(h, x && in_seq, "null pointer");
+  RG_REQUIRE(h, rows > 0 && dim > 0 && dim % 4 == 0 && g_iter >= 0, "bad shape");
+  if (g_iter == 0) return RG_OK;
+  int grid = rg_grid_1d((int64_t)rows * 64, kBlock);
+  float two_over_numel = 2.0f / ((float)rows * (float)dim);
+  hipLaunchKernelGGL(guidance_kernel, dim3(grid), dim3(kBlock), 0, rg_stream(stream), x, in_seq, rows, dim,
+                     g_iter, lr, two_over_numel);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_splice_rows(rg_handle* h, const float* src, float* dst, int T, int D, int n_lat, int b_src,
+                              int b_dst, int r0, int r1, int q0, int q1, void* stream) {
+  RG_REQUIRE(h, src && dst, "null pointer");
+  RG_REQUIRE(h, D % 4 == 0 && r1 - r0 == q1 - q0 && r0 >= 0 && q0 >= 0 && r1 <= n_lat && q1 <= n_lat,
+             "bad row ranges");
+  int nrows = r1 - r0;
+  if (nrows <= 0) return RG_OK;
+  int d4 = D / 4;
+  hipLaunchKernelGGL(splice_kernel, dim3(rg_grid_1d((int64_t)2 * nrows * d4, kBlock)), dim3(kBlock), 0,
+                     rg_stream(stream), (const float4*)src, (float4*)dst, d4, nrows, b_src * T + r0,
+                     b_dst * T + q0, n_lat + 1);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}

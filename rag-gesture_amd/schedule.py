@@ -1,0 +1,78 @@
+"""Diffusion schedule tables for the sampler (host side, float64 numpy).
+
+Mirrors the reference's `build_diffusion` for the inference configuration
+(mogen/models/architectures/diffusion_architecture.py:25-61 ->
+ utils/gaussian_diffusion.py:229-268 betas, :1629-1711 space_timesteps,
+ :1714-1738 SpacedDiffusion, :382-440 derived tables).  The per-step fp32 coefficient
+tables handed to the HIP kernels reproduce `_extract_into_tensor` (:1613-1626): the
+float64 table entry is cast to float32 first, then sqrt etc. are taken in float32.
+"""
+import numpy as np
+
+
+def named_betas(name, n):
+    if name == "linear":
+        scale = 1000 / n
+        return np.linspace(scale * 0.0001, scale * 0.02, n, dtype=np.float64)
+    if name == "scaled_linear":
+        return np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, n, dtype=np.float64) ** 2
+    raise NotImplementedError("unknown beta schedule: %s" % name)
+
+
+def spaced_steps(num_timesteps, section_counts):
+    counts = [int(x) for x in section_counts.split(",")]
+    size_per, extra = divmod(num_timesteps, len(counts))
+    start, steps = 0, []
+    for i, c in enumerate(counts):
+        size = size_per + (1 if i < extra else 0)
+        if size < c:
+            raise ValueError("cannot divide section of %d steps into %d" % (size, c))
+        stride = 1 if c <= 1 else (size - 1) / (c - 1)
+        cur = 0.0
+        for _ in range(c):
+            steps.append(start + round(cur))
+            cur += stride
+        start += size
+    return sorted(set(steps))
+
+
+class Schedule:
+    def __init__(self, beta_scheduler="scaled_linear", diffusion_steps=1000, respace="15,15,8,6,6",
+                 **_ignored):
+        base_ac = np.cumprod(1.0 - named_betas(beta_scheduler, diffusion_steps))
+        use = set(spaced_steps(diffusion_steps, respace)) if respace else set(range(diffusion_steps))
+        last, betas, self.timestep_map = 1.0, [], []
+        for i, ac in enumerate(base_ac):
+            if i in use:
+                betas.append(1 - ac / last)
+                last = ac
+                self.timestep_map.append(i)
+        self.betas = np.array(betas, dtype=np.float64)
+        self.num_timesteps = len(betas)
+        ac = np.cumprod(1.0 - self.betas)
+        self.alphas_cumprod = ac
+        self.alphas_cumprod_prev = np.append(1.0, ac[:-1])
+        self.alphas_cumprod_next = np.append(ac[1:], 0.0)
+        f32 = np.float32
+        one = f32(1.0)
+        # fp32 coefficient tables, one entry per respaced step i
+        self.c_recip = np.sqrt(1.0 / ac).astype(f32)            # sqrt_recip_alphas_cumprod
+        self.c_recipm1 = np.sqrt(1.0 / ac - 1).astype(f32)      # sqrt_recipm1_alphas_cumprod
+        self.s_ab = np.sqrt(ac).astype(f32)                     # q_sample: sqrt_alphas_cumprod
+        self.s_1mab = np.sqrt(1.0 - ac).astype(f32)             # q_sample: sqrt_one_minus_alphas_cumprod
+        abp, abn = self.alphas_cumprod_prev.astype(f32), self.alphas_cumprod_next.astype(f32)
+        self.c_prev_a = np.sqrt(abp)                            # th.sqrt(alpha_bar_prev) in fp32
+        self.c_prev_b = np.sqrt(one - abp)                      # th.sqrt(1 - alpha_bar_prev - 0)
+        self.c_next_a = np.sqrt(abn)
+        self.c_next_b = np.sqrt(one - abn)
+
+    def cfg_weights(self, scale_func_cfg, i):
+        """CFG mix weights (w_cond, w_uncond) at respaced step i
+        (reference raggesture.py:925-954 `scale_func_retr`, evaluated in Python float64)."""
+        t = self.timestep_map[i]
+        if t > 100:
+            w = (1 - (1000 - t) / 1000) * scale_func_cfg["coarse_scale"] + 1
+            return float(w), float(1 - w)
+        both, text, retr = (scale_func_cfg[k] for k in ("both_coef", "text_coef", "retr_coef"))
+        none = 1 - both - text - retr
+        return float(both + text), float(retr + none)
