@@ -77,6 +77,65 @@ int rg_guidance_update(rg_handle* h, float* x, const float* in_seq, int rows, in
 int rg_splice_rows(rg_handle* h, const float* src, float* dst, int T, int D, int n_lat,
                    int b_src, int b_dst, int r0, int r1, int q0, int q1, void* stream);
 
+/* ---------------------------------------------------------------- fused bf16-MFMA GEMM
+ * out[M,N] = epilogue( A'[M,K] * W[N,K]^T ), bf16 operands, fp32 accumulate (MFMA 16x16x32).
+ * It replaces every nn.Linear on the hot path together with the elementwise ops around it:
+ *   A' can be built on the fly from fp32 sources: identity cast, LayerNorm
+ *   (efficient_attention.py:29,31,36,72-74 `self.norm(x)`), or the StylizationBlock front half
+ *   LN -> *(1+scale)+shift -> SiLU (stylization_block.py:36-39);
+ *   the epilogue adds bias / a token-periodic table (positional embeddings,
+ *   diffusion_transformer.py:646-659) / a residual (efficient_attention.py:44,100;
+ *   diffusion_transformer.py:86), applies GELU (diffusion_transformer.py:85) or the per-head
+ *   softmax over head_dim=32 of the queries (efficient_attention.py:32,78), and can emit
+ *   per-row partial (sum, sumsq) so the consumer's LayerNorm needs no extra pass.
+ * The descriptor is a HOST struct read at call time. */
+
+#define RG_MAX_SEG 4
+
+// A-operand transforms applied while an fp32 source tile is staged into LDS as bf16
+enum { RG_A_IDENT = 0, RG_A_LN = 1, RG_A_STYL = 2 };
+
+typedef struct rg_a_segment {
+  const float* src;    // fp32 source, row-major
+  int ld;              // row stride of src (floats)
+  int mode;            // RG_A_IDENT / RG_A_LN / RG_A_STYL
+  const float* stats;  // [rows][nparts][2] partial (sum, sumsq) over the segment's seg_len columns
+  int nparts;
+  int pad_;
+  const float* gamma;  // [seg_len] LayerNorm weight (LN, STYL)
+  const float* beta;   // [seg_len] LayerNorm bias
+  const float* scale_shift;  // STYL: [2*seg_len] = AdaLN scale | shift for this (step, layer, block)
+} rg_a_segment;
+
+typedef struct rg_gemm_desc {
+  int M, N, K;
+  int a_is_bf16;          // 1: A is bf16 [M, lda]; 0: A is built from fp32 segments
+  const void* A;          // bf16 A (a_is_bf16)
+  int lda;
+  int a_row_mod;          // >0: A row index = row % a_row_mod (row-duplicating GEMMs)
+  int seg_len;            // K columns per fp32 segment (K = nseg * seg_len, last may be short)
+  int nseg;
+  rg_a_segment seg[RG_MAX_SEG];
+  int gb_group;           // >0: gamma/beta of every segment are offset by (n0 / gb_group) * gb_stride
+  int gb_stride;
+  const void* W;          // bf16 [Np, ldw]  (rows = output features, K contiguous, zero padded)
+  int ldw;
+  int act;                // 0 none, 1 GELU(erf)
+  const float* bias;      // [N] or null
+  const float* tbias;     // [tb_period, N] or null: + tbias[(row % tb_period) * N + col]
+  int tb_period;
+  int softmax_cols;       // columns [0, softmax_cols) get a softmax over each group of 32 columns
+  const float* residual;  // fp32 [M, ldr] or null
+  int ldr;
+  int out_bf16;           // 1: out is bf16, 0: fp32
+  void* out;
+  int ldo;
+  int pad2_;
+  float* stats_out;       // [M][N/64][2] partial (sum, sumsq) of the final fp32 output, or null
+} rg_gemm_desc;
+
+int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,106 @@
+"""Host-side descriptor builder for rg_gemm (include/rg_gesture.h: rg_gemm_desc)."""
+import ctypes
+
+import torch
+
+from . import capi
+
+A_IDENT, A_LN, A_STYL = 0, 1, 2
+MAX_SEG = 4
+_vp = ctypes.c_void_p
+
+
+class ASegment(ctypes.Structure):
+    _fields_ = [("src", _vp), ("ld", ctypes.c_int), ("mode", ctypes.c_int), ("stats", _vp),
+                ("nparts", ctypes.c_int), ("pad_", ctypes.c_int), ("gamma", _vp), ("beta", _vp),
+                ("scale_shift", _vp)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("M", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int), ("a_is_bf16", ctypes.c_int),
+                ("A", _vp), ("lda", ctypes.c_int), ("a_row_mod", ctypes.c_int), ("seg_len", ctypes.c_int),
+                ("nseg", ctypes.c_int), ("seg", ASegment * MAX_SEG), ("gb_group", ctypes.c_int),
+                ("gb_stride", ctypes.c_int), ("W", _vp), ("ldw", ctypes.c_int), ("act", ctypes.c_int),
+                ("bias", _vp), ("tbias", _vp), ("tb_period", ctypes.c_int), ("softmax_cols", ctypes.c_int),
+                ("residual", _vp), ("ldr", ctypes.c_int), ("out_bf16", ctypes.c_int), ("out", _vp),
+                ("ldo", ctypes.c_int), ("pad2_", ctypes.c_int), ("stats_out", _vp)]
+
+
+assert ctypes.sizeof(ASegment) == 56 and ctypes.sizeof(GemmDesc) == 352
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise capi.RgError("device tensor expected")
+    if dtype is not None and t.dtype != dtype:
+        raise capi.RgError("expected %s, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def pack_weight(w, device=None):
+    """fp32 [N,K] (nn.Linear layout) -> bf16 [ceil64(N), ceil64(K)], zero padded, on device."""
+    n, k = w.shape
+    np_, kp = (n + 63) // 64 * 64, (k + 63) // 64 * 64
+    out = torch.zeros(np_, kp, dtype=torch.bfloat16, device=device or w.device)
+    out[:n, :k] = w.to(out.device).to(torch.bfloat16)
+    return out
+
+
+class Seg:
+    """One fp32 K-segment of the A operand."""
+
+    def __init__(self, src, ld=None, mode=A_IDENT, stats=None, gamma=None, beta=None, scale_shift=None,
+                 col_offset=0):
+        self.src, self.mode, self.stats, self.gamma, self.beta, self.ss = src, mode, stats, gamma, beta, scale_shift
+        self.ld = src.stride(-2) if ld is None else ld
+        self.col_offset = col_offset
+
+
+def make_desc(*, M, N, K, W, out, A=None, segs=None, seg_len=None, bias=None, tbias=None, tb_period=0,
+              residual=None, act=0, softmax_cols=0, stats_out=None, a_row_mod=0, gb_group=0, gb_stride=0,
+              ldo=None, ldr=None):
+    d = GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    if A is not None:
+        d.a_is_bf16 = 1
+        d.A = _p(A, torch.bfloat16)
+        d.lda = A.stride(-2)
+    else:
+        d.a_is_bf16 = 0
+        d.nseg = len(segs)
+        d.seg_len = seg_len if seg_len is not None else ((K + 63) // 64 * 64 if len(segs) == 1 else 512)
+        for i, s in enumerate(segs):
+            e = d.seg[i]
+            e.src = _p(s.src, torch.float32) + 4 * s.col_offset
+            e.ld, e.mode = s.ld, s.mode
+            if s.mode != A_IDENT:
+                e.stats = _p(s.stats, torch.float32)
+                e.nparts = s.stats.shape[-2]
+                e.gamma, e.beta = _p(s.gamma, torch.float32), _p(s.beta, torch.float32)
+            if s.mode == A_STYL:
+                e.scale_shift = _p(s.ss, torch.float32)
+    d.a_row_mod, d.gb_group, d.gb_stride = a_row_mod, gb_group, gb_stride
+    d.W, d.ldw = _p(W, torch.bfloat16), W.stride(0)
+    d.act, d.softmax_cols = act, softmax_cols
+    d.bias = _p(bias, torch.float32)
+    d.tbias, d.tb_period = _p(tbias, torch.float32), tb_period
+    d.residual = _p(residual, torch.float32)
+    d.ldr = (residual.stride(-2) if ldr is None else ldr) if residual is not None else 0
+    d.out_bf16 = 1 if out.dtype == torch.bfloat16 else 0
+    d.out = _p(out)
+    d.ldo = out.stride(-2) if ldo is None else ldo
+    d.stats_out = _p(stats_out, torch.float32)
+    return d
+
+
+def launch(h, desc, stream=None):
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    rc = h.lib.rg_gemm(h._h, ctypes.byref(desc), ctypes.c_void_p(s))
+    if rc != 0:
+        raise capi.RgError("rg_gemm failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
+
+
+def gemm(h, stream=None, **kw):
+    launch(h, make_desc(**kw), stream)

@@ -1,0 +1,129 @@
+"""GPU: fused bf16-MFMA GEMM (rg_gemm) against a plain PyTorch fp32 reference of the same op,
+fed the same bf16-rounded operands."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.Generator(np.random.PCG64(seed)).standard_normal(shape) * scale).astype(np.float32))
+
+
+def bf(x):
+    return x.bfloat16().float()
+
+
+@pytest.fixture(scope="module")
+def h(rg):
+    assert torch.cuda.is_available()
+    return rg.capi.get_handle(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(86, 512, 512), (2752, 1536, 512), (300, 1024, 2048), (129, 512, 768)])
+def test_plain_bias_fp32_A(rg, h, M, N, K):
+    G = rg.gemm
+    a, w, b = _rand((M, K), 1), _rand((N, K), 2, 0.05), _rand((N,), 3)
+    out = torch.empty(M, N, device="cuda")
+    G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out, segs=[G.Seg(a.cuda())], seg_len=K, bias=b.cuda())
+    ref = F.linear(bf(a), bf(w), b)
+    assert (out.cpu() - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_bf16_A_gelu_bf16_out(rg, h):
+    G = rg.gemm
+    M, N, K = 2752, 1024, 512
+    a, w, b = _rand((M, K), 4), _rand((N, K), 5, 0.05), _rand((N,), 6)
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out, A=a.cuda().bfloat16(), bias=b.cuda(), act=1)
+    ref = F.gelu(F.linear(bf(a), bf(w), b))
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2
+
+
+def test_ragged_vae_shapes(rg, h):
+    """K = 78 (not a multiple of 8, odd row stride) and N = 61: the VAE's skel_embedding / final_layer."""
+    G = rg.gemm
+    M = 170
+    a, w, b = _rand((M, 78), 7), _rand((512, 78), 8, 0.1), _rand((512,), 9)
+    out = torch.empty(M, 512, device="cuda")
+    G.gemm(h, M=M, N=512, K=78, W=G.pack_weight(w, "cuda"), out=out, segs=[G.Seg(a.cuda())], bias=b.cuda())
+    assert (out.cpu() - F.linear(bf(a), bf(w), b)).abs().max() <= 2e-3
+    a2, w2, b2 = _rand((M, 512), 10), _rand((61, 512), 11, 0.05), _rand((61,), 12)
+    out2 = torch.full((M, 61), 7.0, device="cuda")
+    G.gemm(h, M=M, N=61, K=512, W=G.pack_weight(w2, "cuda"), out=out2, segs=[G.Seg(a2.cuda())], seg_len=512, bias=b2.cuda())
+    assert (out2.cpu() - F.linear(bf(a2), bf(w2), b2)).abs().max() <= 2e-3
+
+
+def test_ln_prologue_softmax_stats_residual(rg, h):
+    """LayerNorm-on-load from partial stats, per-head softmax on the first 512 columns,
+    partial-stats output, residual, token-periodic bias, row duplication."""
+    G = rg.gemm
+    M, N, K, T = 172, 1536, 512, 43
+    x = _rand((M, K), 13) * 1.7 + 0.3
+    gam, bet = _rand((K,), 14, 0.1) + 1, _rand((K,), 15, 0.1)
+    w, b = _rand((N, K), 16, 0.05), _rand((N,), 17)
+    xs = x.view(M, 8, 64)
+    stats = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous()  # [M,8,2]
+    out = torch.empty(M, N, device="cuda")
+    st_out = torch.zeros(M, N // 64, 2, device="cuda")
+    G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out,
+           segs=[G.Seg(x.cuda(), mode=G.A_LN, stats=stats.cuda(), gamma=gam.cuda(), beta=bet.cuda())], seg_len=512,
+           bias=b.cuda(), softmax_cols=512, stats_out=st_out)
+    xn = F.layer_norm(x, (K,), gam, bet)
+    ref = F.linear(bf(xn), bf(w), b)
+    ref[:, :512] = F.softmax(ref[:, :512].view(M, 16, 32), dim=-1).view(M, 512)
+    assert (out.cpu() - ref).abs().max() <= 3e-3
+    o = out.cpu().view(M, N // 64, 64)
+    assert (st_out.cpu()[..., 0] - o.sum(-1)).abs().max() <= 1e-3
+    assert (st_out.cpu()[..., 1] - (o * o).sum(-1)).abs().max() <= 1e-3
+    # residual + tbias + row duplication (embed-style)
+    Mh = M // 2
+    res, tb = _rand((M, 512), 18), _rand((T, 512), 19)
+    w2 = _rand((512, K), 20, 0.05)
+    out2 = torch.empty(M, 512, device="cuda")
+    G.gemm(h, M=M, N=512, K=K, W=G.pack_weight(w2, "cuda"), out=out2, segs=[G.Seg(x[:Mh].contiguous().cuda())],
+           seg_len=512, a_row_mod=Mh, residual=res.cuda(), tbias=tb.cuda(), tb_period=T)
+    ref2 = F.linear(bf(x[:Mh]), bf(w2)).repeat(2, 1) + res + tb.repeat(M // T, 1)
+    assert (out2.cpu() - ref2).abs().max() <= 3e-3
+
+
+def test_styl_prologue_segments(rg, h):
+    """StylizationBlock front half on load, 3 STYL segments + 1 identity segment (the ca_mix GEMM
+    shape), per-N-tile gamma/beta selection (the CA query GEMM)."""
+    G = rg.gemm
+    M, D = 215, 512
+    y3 = _rand((M, 3 * D), 21)
+    x1 = _rand((M, D), 22)
+    gam, bet = _rand((3, D), 23, 0.1) + 1, _rand((3, D), 24, 0.1)
+    ss = _rand((3, 2 * D), 25, 0.3)
+    w, b = _rand((D, 4 * D), 26, 0.03), _rand((D,), 27)
+    stats = []
+    for c in range(3):
+        yc = y3[:, c * D:(c + 1) * D].reshape(M, 4, 128)
+        stats.append(torch.stack([yc.sum(-1), (yc * yc).sum(-1)], dim=-1).contiguous().cuda())
+    y3d = y3.cuda()
+    segs = [G.Seg(y3d, ld=3 * D, mode=G.A_STYL, stats=stats[c], gamma=gam[c].cuda(), beta=bet[c].cuda(),
+                  scale_shift=ss[c].cuda(), col_offset=c * D) for c in range(3)]
+    segs.append(G.Seg(x1.cuda()))
+    out = torch.empty(M, D, device="cuda")
+    G.gemm(h, M=M, N=D, K=4 * D, W=G.pack_weight(w, "cuda"), out=out, segs=segs, seg_len=D, bias=b.cuda())
+    parts = []
+    for c in range(3):
+        hc = F.layer_norm(y3[:, c * D:(c + 1) * D], (D,), gam[c], bet[c])
+        parts.append(F.silu(hc * (1 + ss[c, :D]) + ss[c, D:]))
+    parts.append(x1)
+    ref = F.linear(bf(torch.cat(parts, -1)), bf(w), b)
+    assert (out.cpu() - ref).abs().max() <= 5e-3
+    # per-N-group gamma/beta: N = 1536 in 3 groups of 512
+    x = _rand((M, D), 28)
+    xs = x.view(M, 8, 64)
+    st = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous().cuda()
+    w3 = _rand((3 * D, D), 29, 0.05)
+    out3 = torch.empty(M, 3 * D, device="cuda")
+    G.gemm(h, M=M, N=3 * D, K=D, W=G.pack_weight(w3, "cuda"), out=out3,
+           segs=[G.Seg(x.cuda(), mode=G.A_LN, stats=st, gamma=gam.cuda(), beta=bet.cuda())], seg_len=D,
+           gb_group=512, gb_stride=512)
+    ref3 = torch.cat([F.linear(bf(F.layer_norm(x, (D,), gam[c], bet[c])), bf(w3[c * D:(c + 1) * D])) for c in range(3)], -1)
+    assert (out3.cpu() - ref3).abs().max() <= 3e-3
