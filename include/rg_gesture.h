@@ -132,9 +132,51 @@ typedef struct rg_gemm_desc {
   int ldo;
   int pad2_;
   float* stats_out;       // [M][N/64][2] partial (sum, sumsq) of the final fp32 output, or null
+  const void* W_lo;       // null, or bf16 [Np, ldw] = bf16(W - float(bf16(W))): selects the precise
+                          // "bf16x3" mode (hi*hi + hi*lo + lo*hi), fp32 A segments only
 } rg_gemm_desc;
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
+
+/* out[i,:] = table[idx[i],:]  (nn.Embedding lookup of speaker ids, diffusion_transformer.py:544-548).
+ * idx is int64 on device; dim % 4 == 0. */
+int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* out, int n, int dim,
+                   void* stream);
+
+/* ---------------------------------------------------------------- linear attention
+ * Self-attention core of EfficientSelfAttention (efficient_attention.py:32-41) for R batch rows
+ * of T tokens: qkv is [R*T, ldqkv] fp32 with q (already softmaxed over head_dim by the GEMM
+ * epilogue) in columns [0,D), k in [D,2D), v in [2D,3D); src_mask [R,T] (0 = masked token:
+ * `key + (1-mask)*-1e6` and `value*mask`).  Writes y [R*T, ldy] fp32 and per-row partial
+ * LayerNorm statistics stats[R*T][D/128][2] (sum, sumsq over each 128-column head group). */
+int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
+                    float* stats, int R, int T, int D, void* stream);
+
+/* Cross-attention core of EfficientCrossAttention for ncond parallel conditions
+ * (efficient_attention.py:90-98; diffusion_transformer.py:105-118): y3[:, c*D:(c+1)*D] = Q_c A_c
+ * with Q_c = q3[:, c*D:(c+1)*D] (softmaxed), A_c = Apre[c][row] ([H][32][32], from rg_kv_reduce) for
+ * rows < Rc and Aunc[c] for the classifier-free rows [Rc,R) (cond_type 0: V = value(0) = bias, so
+ * A[d][l] = b_v[l]; efficient_attention.py:83-90).
+ * qmask [ncond][R][T] or NULL: where 0, y is rounded exactly as the reference's fp32
+ * `y + (1-query_mask)*-1e6` rounds it (grid 1/16) so that the following LayerNorm sees the
+ * same values up to the shift.  stats layout [ncond][R*T][D/128][2]. */
+int rg_ca_attention(rg_handle* h, const float* q3, const float* Apre, const float* Aunc, const float* qmask,
+                    float* y3, float* stats, int R, int Rc, int T, int D, int ncond, void* stream);
+
+/* A[b][h] = softmax_over_tokens(K[b,:,h,:])^T V[b,:,h,:]  (efficient_attention.py:82-90) for B rows
+ * of N conditioning tokens; kv is [B*N, ldkv] fp32 with k in columns [0,D) and v in [D,2D).
+ * A is [B][H][32][32].  Loop invariant over the 50 DDIM steps: run once per clip. */
+int rg_kv_reduce(rg_handle* h, const float* kv, int ldkv, float* A, int B, int N, int D, void* stream);
+
+/* Partial LayerNorm statistics of fp32 rows that no GEMM produced (the gathered speaker
+ * embeddings): stats[row][dim/64][2] = (sum, sumsq) over each 64-column part. */
+int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows, int dim, void* stream);
+
+/* Exact fp32 linear for load-time tables: out[M,N] = f_out( f_in(a)[M,K] w[N,K]^T + bias ),
+ * f = SiLU if the flag is set (time_embed MLP, diffusion_transformer.py:404-408, and the 40
+ * StylizationBlock emb_layers, stylization_block.py:35, which depend only on the timestep). */
+int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bias, float* out, int M,
+                  int N, int K, int silu_in, int silu_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,336 @@
+// Linear ("efficient") attention kernels of the denoiser, fp32 VALU with wavefront shuffles.
+//
+// The reference's attention has no TxT score matrix: per head (head_dim 32)
+//   P = softmax_over_tokens(K + mask),  A = P^T V  (32x32),  y = softmax_hd(Q) A.
+// One wave owns one head of one batch row; a 256-thread workgroup = 4 adjacent heads
+// (128 output columns), so a row's LayerNorm statistics leave the kernel as 4 partial
+// (sum, sumsq) pairs that the consumer GEMM folds into its A-operand prologue.
+//
+//  rg_sa_attention : efficient_attention.py:23-41  (EfficientSelfAttention, up to `y`)
+//  rg_ca_attention : efficient_attention.py:90-98  (y = Q A for precomputed A, + query mask)
+//  rg_kv_reduce    : efficient_attention.py:82-90  (A = softmax_N(K)^T V over conditioning tokens;
+//                    depends only on the conditioning, so it runs once per clip, not per step)
+#include "rg_common.h"
+
+namespace {
+
+constexpr int HD = 32;       // head dim
+constexpr int WAVES = 4;     // heads per workgroup
+constexpr int TMAX = 64;     // max tokens per batch row handled by the per-step kernels
+
+__device__ __forceinline__ float wave_sum32(float v) {  // sum over the 32 lanes of each half-wave
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  return v;
+}
+
+// Load a [T][32] fp32 tile (row stride ld floats) into LDS [T][32]; 8 rows per wave-instruction.
+__device__ __forceinline__ void load_tile32(float* dst, const float* src, int ld, int T, int lane) {
+  const int c4 = (lane & 7) * 4;
+  for (int r = lane >> 3; r < T; r += 8)
+    *reinterpret_cast<float4*>(dst + r * HD + c4) = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c4);
+}
+
+// y[n][l] = sum_d q[n][d] * A[d][l] for the T tokens of one head; lane -> (l = lane&31, half).
+// Areg = column l of A.  Writes y (optionally quantised like the reference's "-1e6 + y" on
+// masked query rows) and writes this wave's per-token partial sums to sstat[T][2] (its own LDS
+// slice: no atomics, so results are bitwise reproducible run to run).
+__device__ __forceinline__ void qa_and_store(const float* sq, const float (&Areg)[HD], float* yout, int ldy,
+                                             int T, int lane, const float* qmask, float* sstat) {
+  const int l = lane & 31, half = lane >> 5;
+  for (int n = half; n < T; n += 2) {
+    const float* qr = sq + n * HD;
+    float acc = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < HD; d4 += 4) {
+      float4 q = *reinterpret_cast<const float4*>(qr + d4);
+      acc = fmaf(q.x, Areg[d4], acc);
+      acc = fmaf(q.y, Areg[d4 + 1], acc);
+      acc = fmaf(q.z, Areg[d4 + 2], acc);
+      acc = fmaf(q.w, Areg[d4 + 3], acc);
+    }
+    if (qmask && qmask[n] == 0.f) {
+      // reference: y + (1 - query_mask) * -1e6 in fp32, then LayerNorm (shift invariant).
+      // z is y rounded onto the fp32 grid near -1e6 (spacing 1/16); z + 1e6 is exact.
+      const float z = acc + (-1000000.0f);
+      acc = z + 1000000.0f;
+    }
+    yout[(size_t)n * ldy + l] = acc;
+    float s = wave_sum32(acc), ss = wave_sum32(acc * acc);
+    if (l == 0) {
+      sstat[2 * n] = s;
+      sstat[2 * n + 1] = ss;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
+                                                          const float* __restrict__ src_mask, float* __restrict__ y,
+                                                          int ldy, float* __restrict__ stats, int T) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x / (D / (HD * WAVES));
+  const int hg = blockIdx.x % (D / (HD * WAVES));
+  const int h = hg * WAVES + wave;
+  const int Tp = (T + 3) & ~3;
+  float* sstat = sm;                       // [WAVES][Tp][2]
+  float* sq = sm + WAVES * 2 * Tp + wave * (3 * Tp * HD + HD * HD);
+  float* sk = sq + Tp * HD;
+  float* sv = sk + Tp * HD;
+  float* sA = sv + Tp * HD;                // [32][32]
+  const float* base = qkv + (size_t)b * T * ldqkv + h * HD;
+  load_tile32(sq, base, ldqkv, T, lane);
+  load_tile32(sk, base + D, ldqkv, T, lane);
+  load_tile32(sv, base + 2 * D, ldqkv, T, lane);
+  __syncthreads();
+  const float* mrow = src_mask + (size_t)b * T;
+
+  // softmax over tokens for column d = lane&31; the two half-waves split the tokens
+  {
+    const int d = lane & 31, half = lane >> 5;
+    float mx = -INFINITY;
+    for (int n = half; n < T; n += 2)
+      if (mrow[n] != 0.f) mx = fmaxf(mx, sk[n * HD + d]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+    for (int n = half; n < T; n += 2) {
+      // key + (1-mask)*-1e6: a masked token's weight underflows to exactly 0 in fp32
+      float e = (mrow[n] != 0.f) ? expf(sk[n * HD + d] - mx) : 0.f;
+      sk[n * HD + d] = e;
+      sum += e;
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    for (int n = half; n < T; n += 2) sk[n * HD + d] *= inv;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  // A[d][l] = sum_n P[n][d] * (V[n][l] * mask[n]); lane -> (d = lane&31, 16 l's)
+  {
+    const int d = lane & 31, l0 = (lane >> 5) * 16;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int n = 0; n < T; ++n) {
+      const float pn = sk[n * HD + d];
+      const float* vr = sv + n * HD + l0;
+#pragma unroll
+      for (int j4 = 0; j4 < 16; j4 += 4) {
+        float4 vv = *reinterpret_cast<const float4*>(vr + j4);
+        acc[j4] = fmaf(pn, vv.x, acc[j4]);
+        acc[j4 + 1] = fmaf(pn, vv.y, acc[j4 + 1]);
+        acc[j4 + 2] = fmaf(pn, vv.z, acc[j4 + 2]);
+        acc[j4 + 3] = fmaf(pn, vv.w, acc[j4 + 3]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sA[d * HD + l0 + j] = acc[j];
+  }
+  // (same wave wrote sA: a wave-level LDS fence is enough)
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  float Areg[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) Areg[d] = sA[d * HD + (lane & 31)];
+  qa_and_store(sq, Areg, y + (size_t)b * T * ldy + h * HD, ldy, T, lane, nullptr, sstat + wave * 2 * Tp);
+  __syncthreads();
+  const int ngroups = D / (HD * WAVES);
+  for (int n = threadIdx.x; n < T; n += 256) {
+    float* so = stats + (((size_t)b * T + n) * ngroups + hg) * 2;
+    so[0] = (sstat[2 * n] + sstat[2 * Tp + 2 * n]) + (sstat[4 * Tp + 2 * n] + sstat[6 * Tp + 2 * n]);
+    so[1] = (sstat[2 * n + 1] + sstat[2 * Tp + 2 * n + 1]) + (sstat[4 * Tp + 2 * n + 1] + sstat[6 * Tp + 2 * n + 1]);
+  }
+}
+
+// grid = R * ncond * (D/128); Apre layout [cond][R][H][32][32]; q3/y3 layout [M][ncond*D];
+// stats layout [cond][M][D/128][2]; qmask layout [cond][R][T].
+__global__ void __launch_bounds__(256) ca_attention_kernel(const float* __restrict__ q3, const float* __restrict__ Apre,
+                                                          const float* __restrict__ qmask, float* __restrict__ y3,
+                                                          float* __restrict__ stats, int R, int T, int D, int ncond,
+                                                          int Rc, const float* __restrict__ Aunc) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ngroups = D / (HD * WAVES);
+  const int H = D / HD;
+  int bid = blockIdx.x;
+  const int hg = bid % ngroups;
+  bid /= ngroups;
+  const int c = bid % ncond;
+  const int b = bid / ncond;
+  const int h = hg * WAVES + wave;
+  const int Tp = (T + 3) & ~3;
+  float* sstat = sm;  // [WAVES][Tp][2]
+  float* sq = sm + WAVES * 2 * Tp + wave * (Tp * HD);
+  const int ld = ncond * D;
+  load_tile32(sq, q3 + (size_t)b * T * ld + c * D + h * HD, ld, T, lane);
+  // rows [0,Rc) carry per-row conditioning; rows [Rc,R) are the classifier-free "no condition"
+  // branch whose A depends only on the weights (Aunc[cond][H][32][32])
+  const float* Ap = (b < Rc) ? Apre + ((((size_t)c * Rc + b) * H + h) * HD) * HD
+                             : Aunc + (((size_t)c * H + h) * HD) * HD;
+  float Areg[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) Areg[d] = Ap[d * HD + (lane & 31)];
+  __syncthreads();
+  const float* qm = qmask ? qmask + ((size_t)c * R + b) * T : nullptr;
+  qa_and_store(sq, Areg, y3 + (size_t)b * T * ld + c * D + h * HD, ld, T, lane, qm, sstat + wave * 2 * Tp);
+  __syncthreads();
+  for (int n = threadIdx.x; n < T; n += 256) {
+    float* so = stats + ((((size_t)c * R + b) * T + n) * ngroups + hg) * 2;
+    so[0] = (sstat[2 * n] + sstat[2 * Tp + 2 * n]) + (sstat[4 * Tp + 2 * n] + sstat[6 * Tp + 2 * n]);
+    so[1] = (sstat[2 * n + 1] + sstat[2 * Tp + 2 * n + 1]) + (sstat[4 * Tp + 2 * n + 1] + sstat[6 * Tp + 2 * n + 1]);
+  }
+}
+
+// One workgroup per (batch row, head): A[d][l] = sum_n softmax_n(K[n][d]) * V[n][l] over N tokens.
+__global__ void __launch_bounds__(256) kv_reduce_kernel(const float* __restrict__ kv, int ldkv, int D, int N,
+                                                       float* __restrict__ A, int H) {
+  __shared__ float red[8][HD];
+  __shared__ float smax[HD], sinv[HD];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int d = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts over tokens
+  const float* kb = kv + (size_t)b * N * ldkv + h * HD;
+  const float* vb = kb + D;
+  float mx = -INFINITY;
+  for (int n = part; n < N; n += 8) mx = fmaxf(mx, kb[(size_t)n * ldkv + d]);
+  red[part][d] = mx;
+  __syncthreads();
+  if (part == 0) {
+    float m = red[0][d];
+    for (int q = 1; q < 8; ++q) m = fmaxf(m, red[q][d]);
+    smax[d] = m;
+  }
+  __syncthreads();
+  mx = smax[d];
+  float sum = 0.f;
+  for (int n = part; n < N; n += 8) sum += expf(kb[(size_t)n * ldkv + d] - mx);
+  __syncthreads();
+  red[part][d] = sum;
+  __syncthreads();
+  if (part == 0) {
+    float s = 0.f;
+    for (int q = 0; q < 8; ++q) s += red[q][d];
+    sinv[d] = 1.0f / s;
+  }
+  __syncthreads();
+  const float inv = sinv[d];
+  const int l0 = part * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < N; ++n) {
+    const float pn = expf(kb[(size_t)n * ldkv + d] - mx) * inv;
+    const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)n * ldkv + l0);
+    acc.x = fmaf(pn, vv.x, acc.x);
+    acc.y = fmaf(pn, vv.y, acc.y);
+    acc.z = fmaf(pn, vv.z, acc.z);
+    acc.w = fmaf(pn, vv.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(A + (((size_t)b * H + h) * HD + d) * HD + l0) = acc;
+}
+
+// Exact fp32 linear for tiny, load-time problems (time-embedding tables): out[m][n] = a[m].w[n] + bias,
+// one wave per output column, optional SiLU on the input and/or output.
+__global__ void __launch_bounds__(256) linear_f32_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int M, int N, int K, int silu_in, int silu_out) {
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= N) return;
+  const float* wr = w + (size_t)wave * K;
+  for (int m = 0; m < M; ++m) {
+    const float* ar = a + (size_t)m * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      float x = ar[k];
+      if (silu_in) x = x / (1.0f + expf(-x));
+      acc = fmaf(x, wr[k], acc);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    acc += __shfl_xor(acc, 8);
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (lane == 0) {
+      float r = acc + (bias ? bias[wave] : 0.f);
+      if (silu_out) r = r / (1.0f + expf(-r));
+      out[(size_t)m * N + wave] = r;
+    }
+  }
+}
+
+// stats[row][p] = (sum, sumsq) of x[row][64p .. 64p+63]; one wave per (row, 64-column part).
+__global__ void __launch_bounds__(256) row_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                       int rows, int dim) {
+  const int parts = dim / 64;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= rows * parts) return;
+  const float v = x[(size_t)(wave / parts) * dim + (wave % parts) * 64 + lane];
+  float s = v, ss = v * v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    s += __shfl_xor(s, o);
+    ss += __shfl_xor(ss, o);
+  }
+  if (lane == 0) {
+    stats[2 * (size_t)wave] = s;
+    stats[2 * (size_t)wave + 1] = ss;
+  }
+}
+
+}  // namespace
+
+extern "C" int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows, int dim, void* stream) {
+  RG_REQUIRE(h, x && stats, "null pointer");
+  RG_REQUIRE(h, rows > 0 && dim > 0 && dim % 64 == 0, "bad shape");
+  const int64_t waves = (int64_t)rows * (dim / 64);
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, rg_stream(stream), x,
+                     stats, rows, dim);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
+                               float* stats, int R, int T, int D, void* stream) {
+  RG_REQUIRE(h, qkv && src_mask && y && stats, "null pointer");
+  RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape");
+  const int Tp = (T + 3) & ~3;
+  const size_t lds = (WAVES * 2 * Tp + WAVES * (3 * Tp * HD + HD * HD)) * sizeof(float);
+  hipLaunchKernelGGL(sa_attention_kernel, dim3(R * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream), qkv,
+                     ldqkv, D, src_mask, y, ldy, stats, T);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_ca_attention(rg_handle* h, const float* q3, const float* Apre, const float* Aunc,
+                               const float* qmask, float* y3, float* stats, int R, int Rc, int T, int D, int ncond,
+                               void* stream) {
+  RG_REQUIRE(h, q3 && Apre && y3 && stats, "null pointer");
+  RG_REQUIRE(h, Rc >= 0 && Rc <= R && (Rc == R || Aunc), "rows beyond Rc need Aunc");
+  RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * WAVES) == 0 && R > 0 && ncond > 0, "bad shape");
+  const int Tp = (T + 3) & ~3;
+  const size_t lds = (WAVES * 2 * Tp + WAVES * Tp * HD) * sizeof(float);
+  hipLaunchKernelGGL(ca_attention_kernel, dim3(R * ncond * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream),
+                     q3, Apre, qmask, y3, stats, R, T, D, ncond, Rc, Aunc);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_kv_reduce(rg_handle* h, const float* kv, int ldkv, float* A, int B, int N, int D, void* stream) {
+  RG_REQUIRE(h, kv && A, "null pointer");
+  RG_REQUIRE(h, B > 0 && N > 0 && D % HD == 0 && ldkv % 4 == 0, "bad shape");
+  hipLaunchKernelGGL(kv_reduce_kernel, dim3(B * (D / HD)), dim3(256), 0, rg_stream(stream), kv, ldkv, D, N, A,
+                     D / HD);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bias, float* out, int M,
+                             int N, int K, int silu_in, int silu_out, void* stream) {
+  RG_REQUIRE(h, a && w && out, "null pointer");
+  RG_REQUIRE(h, M > 0 && N > 0 && K > 0, "bad shape");
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((N * 64 + 255) / 256), dim3(256), 0, rg_stream(stream), a, w, bias,
+                     out, M, N, K, silu_in, silu_out);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}

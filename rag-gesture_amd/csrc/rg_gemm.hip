@@ -36,6 +36,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
   return __builtin_bit_cast(unsigned short, b);
 }
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
@@ -47,15 +48,20 @@ __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erf
 
 struct AStage {            // per-thread staging registers for one K-tile
   uint4 w[2];              // W chunks (bf16 x8)
+  uint4 wlo[2];            // low-order W chunks (SPLIT)
   uint4 abf[2];            // A chunks when A is bf16
   float4 af[2][2];         // A chunks when A is fp32 (8 floats per chunk)
   float4 g[2], b[2], sc[2], sh[2];  // gamma / beta / scale / shift for this thread's 8 columns
 };
 
-template <bool A_BF16>
+// SPLIT: "bf16x3" precise mode.  Both operands are split into hi = bf16(v) and lo = bf16(v - hi)
+// and the product is accumulated as hi*hi + hi*lo + lo*hi (fp32 accumulate): ~2^-17 relative
+// operand precision at 3 MFMAs per tile, used to check parity against the fp32 reference.
+template <bool A_BF16, bool SPLIT>
 __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // [buf][A|W][8 KiB]  = 32 KiB; the epilogue reuses it as fp32 [64][68]
+  // [buf][A|W(|Alo|Wlo)][8 KiB] = 32 (64) KiB; the epilogue reuses it as fp32 [64][68]
+  constexpr int NPLANE = SPLIT ? 4 : 2;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -100,6 +106,9 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
     for (int j = 0; j < 2; ++j) {
       const int n = n0 + srow + 32 * j;  // W is zero padded to a multiple of 64 rows / 64 cols
       st.w[j] = *reinterpret_cast<const uint4*>(Wb + (size_t)n * p.ldw + k0);
+      if constexpr (SPLIT)
+        st.wlo[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.W_lo) +
+                                                    (size_t)n * p.ldw + k0);
     }
     if constexpr (A_BF16) {
       const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A);
@@ -168,12 +177,13 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
   };
 
   auto store_tile = [&](int kt, int buf) {
-    unsigned char* sA = smem + buf * 2 * TILE_BYTES;
+    unsigned char* sA = smem + buf * NPLANE * TILE_BYTES;
     unsigned char* sW = sA + TILE_BYTES;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = srow + 32 * j;
       *reinterpret_cast<uint4*>(sW + lds_off(row, kch)) = st.w[j];
+      if constexpr (SPLIT) *reinterpret_cast<uint4*>(sW + 2 * TILE_BYTES + lds_off(row, kch)) = st.wlo[j];
       if constexpr (A_BF16) {
         *reinterpret_cast<uint4*>(sA + lds_off(row, kch)) = st.abf[j];
       } else {
@@ -199,6 +209,13 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
         }
         uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
         *reinterpret_cast<uint4*>(sA + lds_off(row, kch)) = o;
+        if constexpr (SPLIT) {
+          float r[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = v[e] - bf2f(f2bf(v[e]));
+          uint4 ol = make_uint4(pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7]));
+          *reinterpret_cast<uint4*>(sA + 2 * TILE_BYTES + lds_off(row, kch)) = ol;
+        }
       }
     }
   };
@@ -217,7 +234,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) load_tile(kt + 1);
-    const unsigned char* sA = smem + buf * 2 * TILE_BYTES;
+    const unsigned char* sA = smem + buf * NPLANE * TILE_BYTES;
     const unsigned char* sW = sA + TILE_BYTES;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -226,6 +243,21 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
       for (int i = 0; i < 2; ++i) {
         af[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wr * 32 + i * 16 + frow, 4 * s + fq));
         bfr[i] = *reinterpret_cast<const bf16x8*>(sW + lds_off(wc * 32 + i * 16 + frow, 4 * s + fq));
+      }
+      if constexpr (SPLIT) {
+        bf16x8 al[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          al[i] = *reinterpret_cast<const bf16x8*>(sA + 2 * TILE_BYTES + lds_off(wr * 32 + i * 16 + frow, 4 * s + fq));
+          bl[i] = *reinterpret_cast<const bf16x8*>(sW + 2 * TILE_BYTES + lds_off(wc * 32 + i * 16 + frow, 4 * s + fq));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bl[j], acc[i][j], 0, 0, 0);
+          }
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -357,10 +389,14 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + BN - 1) / BN;
   dim3 grid(mt * nt), block(NT);
   const size_t lds = 2 * 2 * TILE_BYTES;  // 32 KiB (>= 64*68*4 epilogue tile)
-  if (d->a_is_bf16)
-    hipLaunchKernelGGL(gemm_kernel<true>, grid, block, lds, rg_stream(stream), *d);
-  else
-    hipLaunchKernelGGL(gemm_kernel<false>, grid, block, lds, rg_stream(stream), *d);
+  if (d->W_lo) {
+    RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
+    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 2 * lds, rg_stream(stream), *d);
+  } else if (d->a_is_bf16) {
+    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, lds, rg_stream(stream), *d);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, rg_stream(stream), *d);
+  }
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -135,7 +135,27 @@ __global__ void __launch_bounds__(kBlock) splice_kernel(const float4* __restrict
   }
 }
 
+__global__ void __launch_bounds__(kBlock) gather_rows_kernel(const float4* __restrict__ table,
+                                                            const int64_t* __restrict__ idx, float4* __restrict__ out,
+                                                            int n, int d4) {
+  int64_t total = (int64_t)n * d4;
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    int r = (int)(i / d4), c = (int)(i % d4);
+    out[i] = table[idx[r] * d4 + c];
+  }
+}
+
 }  // namespace
+
+extern "C" int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* out, int n, int dim,
+                              void* stream) {
+  RG_REQUIRE(h, table && idx && out, "null pointer");
+  RG_REQUIRE(h, n > 0 && dim > 0 && dim % 4 == 0, "bad shape");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rg_grid_1d((int64_t)n * dim / 4, kBlock)), dim3(kBlock), 0,
+                     rg_stream(stream), (const float4*)table, idx, (float4*)out, n, dim / 4);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
 
 extern "C" int rg_ddim_update(rg_handle* h, const float* x, const float* x0, float* x_out, int64_t n,
                               float c_recip, float c_recipm1, float c_a, float c_b, void* stream) {

@@ -1,0 +1,252 @@
+"""Host side of the MI355X denoiser: weight packing, once-per-clip conditioning precompute and
+the per-step launch sequence of `ReGestureTransformer.forward` at inference
+(reference: mogen/models/transformers/diffusion_transformer.py:620-668 `forward`,
+raggesture.py:1041-1113 `forward_test`, diffusion_transformer.py:105-127 `DecoderLayer`).
+
+Everything numeric runs in the C-ABI HIP extension (capi / gemm); torch only owns the device
+buffers.  What is hoisted out of the 50-step loop, all exact algebra:
+  * the 40 StylizationBlock `emb_layers` and the time_embed MLP depend only on the timestep:
+    one [steps, layers, 5, 2*D] table per model, built at load time in fp32;
+  * the cross-attention K/V projections and A = softmax_N(K)^T V depend only on the
+    conditioning: built once per clip (`set_conditions`);
+  * the classifier-free rows' A is the value bias broadcast (cond_type 0 zeroes the value input
+    and softmax(K) sums to 1), built at load time;
+  * `ca_mix(cat_c(x + out_c(h_c)))` = [h_text|h_audio|h_spk|x] @ [Wm_c Wo_c ... | sum_c Wm_c]^T + b:
+    one K=2048 GEMM instead of three 512x512 GEMMs plus the 1536->512 mix.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import capi, gemm as G
+
+CONDS = ("xf_text", "xf_audio", "xf_spk")
+BLOCKS = ("sa_block", "ca_blocks.xf_text", "ca_blocks.xf_audio", "ca_blocks.xf_spk", "ffn")
+
+
+def _timestep_embedding(timesteps, dim, max_period=10000):
+    """reference: diffusion_transformer.py:27-46 (host, fp32; 50 rows at load time)."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+class DenoiserWeights:
+    """Device-resident packed weights of one ReGestureTransformer (bf16 GEMM operands [N,K]
+    zero-padded to 64, fp32 biases / LayerNorm parameters / tables)."""
+
+    def __init__(self, state, cfg, schedule, device="cuda", prefix="", precision="bf16"):
+        """precision: "bf16" (MFMA operands rounded to bf16, the production path) or "fp32"
+        (bf16x3 split operands: ~fp32 products at 3 MFMAs per tile, used for parity checks)."""
+        assert precision in ("bf16", "fp32")
+        self.precision = precision
+        self.cfg = cfg
+        self.schedule = schedule
+        self.dev = torch.device(device)
+        self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        D, L = cfg["latent_dim"], cfg["num_layers"]
+        self.D, self.L, self.H = D, L, cfg["num_heads"]
+        self.TE, self.FF = cfg["time_embed_dim"], cfg["ff_size"]
+        assert D % 128 == 0 and D // self.H == 32, "kernels are specialised for head_dim 32"
+        n_lat = cfg["max_seq_len"] // cfg["frame_chunk_size"]
+        self.n_lat, self.T = n_lat, 4 * n_lat + 3
+        sd = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else state
+        f32 = lambda t: t.detach().to(torch.float32).to(self.dev).contiguous()
+        pw = lambda t: G.pack_weight(t.detach().to(torch.float32), self.dev, split=(precision == "fp32"))
+        g = lambda name: sd[name].detach().to(torch.float32)
+
+        # --- embedding / head / conditioning projections
+        self.w_embed, self.b_embed = pw(g("joint_embed.weight")), f32(g("joint_embed.bias"))
+        pos = g("sequence_embedding.pe").permute(1, 0, 2)[0, :n_lat]
+        sep = torch.zeros(1, D)
+        pos_cat = torch.cat([pos, sep, pos, sep, pos, sep, pos], dim=0)
+        self.tbias = f32(pos_cat + g("global_positional_embedding.pe")[:self.T, 0])
+        self.w_out, self.b_out = pw(g("out.weight")), f32(g("out.bias"))
+        self.w_text, self.b_text = pw(g("text_pre_proj.weight")), f32(g("text_pre_proj.bias"))
+        self.w_audio, self.b_audio = pw(g("audio_pre_proj.weight")), f32(g("audio_pre_proj.bias"))
+        self.spk_table = f32(g("speaker_embedding.weight"))
+        self.num_speakers = self.spk_table.shape[0]
+
+        # --- per layer
+        self.layers = []
+        for l in range(L):
+            p = "temporal_decoder_blocks.%d." % l
+            lw = {}
+            lw["sa_g"], lw["sa_b"] = f32(g(p + "sa_block.norm.weight")), f32(g(p + "sa_block.norm.bias"))
+            lw["w_qkv"] = pw(torch.cat([g(p + "sa_block.%s.weight" % n) for n in ("query", "key", "value")], 0))
+            lw["b_qkv"] = f32(torch.cat([g(p + "sa_block.%s.bias" % n) for n in ("query", "key", "value")], 0))
+            lw["sa_sg"], lw["sa_sb"] = f32(g(p + "sa_block.proj_out.norm.weight")), f32(g(p + "sa_block.proj_out.norm.bias"))
+            lw["w_sao"], lw["b_sao"] = pw(g(p + "sa_block.proj_out.out_layers.2.weight")), f32(g(p + "sa_block.proj_out.out_layers.2.bias"))
+            cq = [p + "ca_blocks.%s." % c for c in CONDS]
+            lw["ca_g"] = f32(torch.stack([g(q + "norm.weight") for q in cq]))
+            lw["ca_b"] = f32(torch.stack([g(q + "norm.bias") for q in cq]))
+            lw["w_q3"] = pw(torch.cat([g(q + "query.weight") for q in cq], 0))
+            lw["b_q3"] = f32(torch.cat([g(q + "query.bias") for q in cq], 0))
+            lw["tn_g"] = [f32(g(q + "text_norm.weight")) for q in cq]
+            lw["tn_b"] = [f32(g(q + "text_norm.bias")) for q in cq]
+            lw["w_kv"] = [pw(torch.cat([g(q + "key.weight"), g(q + "value.weight")], 0)) for q in cq]
+            lw["b_kv"] = [f32(torch.cat([g(q + "key.bias"), g(q + "value.bias")], 0)) for q in cq]
+            lw["ca_sg"] = [f32(g(q + "proj_out.norm.weight")) for q in cq]
+            lw["ca_sb"] = [f32(g(q + "proj_out.norm.bias")) for q in cq]
+            # classifier-free rows: A[c][h][d][l] = b_v[h*32 + l]
+            bv = torch.stack([g(q + "value.bias") for q in cq])  # [3, D]
+            lw["a_unc"] = f32(bv.view(3, self.H, 1, 32).expand(3, self.H, 32, 32))
+            # fused ca_mix o proj_out.out_layers: [D, 4D]
+            wm = g(p + "ca_mix.weight").double()
+            fused, bias = [], g(p + "ca_mix.bias").double()
+            for ci, q in enumerate(cq):
+                wmc = wm[:, ci * D:(ci + 1) * D]
+                fused.append(wmc @ g(q + "proj_out.out_layers.2.weight").double())
+                bias = bias + wmc @ g(q + "proj_out.out_layers.2.bias").double()
+            fused.append(wm[:, :D] + wm[:, D:2 * D] + wm[:, 2 * D:])
+            lw["w_mix"], lw["b_mix"] = pw(torch.cat(fused, 1).float()), f32(bias.float())
+            lw["w_ff1"], lw["b_ff1"] = pw(g(p + "ffn.linear1.weight")), f32(g(p + "ffn.linear1.bias"))
+            lw["w_ff2"], lw["b_ff2"] = pw(g(p + "ffn.linear2.weight")), f32(g(p + "ffn.linear2.bias"))
+            lw["ff_sg"], lw["ff_sb"] = f32(g(p + "ffn.proj_out.norm.weight")), f32(g(p + "ffn.proj_out.norm.bias"))
+            lw["w_ffo"], lw["b_ffo"] = pw(g(p + "ffn.proj_out.out_layers.2.weight")), f32(g(p + "ffn.proj_out.out_layers.2.bias"))
+            self.layers.append(lw)
+
+        # --- timestep tables: ss[step][layer][block] = emb_layers(SiLU(time_embed(t_step)))  (fp32, exact)
+        S = schedule.num_timesteps
+        self.S = S
+        temb = f32(_timestep_embedding(torch.tensor(schedule.timestep_map, dtype=torch.long), D))
+        e1 = torch.empty(S, self.TE, device=self.dev)
+        emb = torch.empty(S, self.TE, device=self.dev)
+        self.h.call("linear_f32", temb, f32(g("time_embed.0.weight")), f32(g("time_embed.0.bias")), e1, S, self.TE, D, 0, 1)
+        self.h.call("linear_f32", e1, f32(g("time_embed.2.weight")), f32(g("time_embed.2.bias")), emb, S, self.TE, self.TE, 0, 0)
+        self.ss = torch.empty(S, L, 5, 2 * D, device=self.dev)
+        tmp = torch.empty(S, 2 * D, device=self.dev)
+        for l in range(L):
+            for bi, blk in enumerate(BLOCKS):
+                q = "temporal_decoder_blocks.%d.%s.proj_out.emb_layers.1." % (l, blk)
+                self.h.call("linear_f32", emb, f32(g(q + "weight")), f32(g(q + "bias")), tmp, S, 2 * D, self.TE, 1, 0)
+                self.ss[:, l, bi].copy_(tmp)
+        torch.cuda.synchronize(self.dev)
+        # per-joint CFG scale (raggesture.py:909-922), default all ones
+        pjs = cfg.get("per_joint_scale") or dict(upper=1.0, hands=1.0, face=1.0, lowertransl=1.0)
+        js = torch.ones(self.T)
+        n = n_lat
+        js[0:n], js[n + 1:2 * n + 1] = pjs["upper"], pjs["hands"]
+        js[2 * n + 2:3 * n + 2], js[3 * n + 3:] = pjs["face"], pjs["lowertransl"]
+        self.js = f32(js)
+
+
+class DenoiserSession:
+    """Buffers + conditioning state for B clips (R = 2B rows: conditional rows first, then the
+    classifier-free rows).  Not re-entrant; one per (model, batch size, stream)."""
+
+    def __init__(self, weights, B):
+        w = self.w = weights
+        self.h = w.h
+        self.B, self.R = B, 2 * B
+        D, T, dev = w.D, w.T, w.dev
+        self.M = M = self.R * T
+        f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
+        self.st_a, self.st_b, self.st_c = f(M, D // 64, 2), f(M, D // 64, 2), f(M, D // 64, 2)
+        self.qkv, self.q3 = f(M, 3 * D), f(M, 3 * D)
+        self.y_sa, self.st_sa = f(M, D), f(M, D // 128, 2)
+        self.y3, self.st3 = f(M, 3 * D), f(3, M, D // 128, 2)
+        self.g = torch.empty(M, w.FF, device=dev, dtype=torch.bfloat16 if w.precision == "bf16" else torch.float32)
+        self.yf, self.st_f = f(M, D), f(M, D // 64, 2)
+        self.head = f(M, D)
+        self.a_pre = f(w.L, 3, B, w.H, 32, 32)
+        self.src_mask = torch.ones(self.R, T, device=dev)
+        self.qmask = torch.ones(3, self.R, T, device=dev)
+
+    # ------------------------------------------------------------------ once per clip
+    def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None):
+        """word [B,Nt,768], audio [B,Na,768], speaker_ids [B,Ns] int64, motion_mask [B,T];
+        query_masks: dict cond -> [B,T] or None (no query masking).
+        reference: raggesture.py:957-1013 (conditions), diffusion_architecture.py:146-166 (masks)."""
+        w, h, B, D = self.w, self.h, self.B, self.w.D
+        dev = w.dev
+        self.src_mask.copy_(motion_mask.to(dev).float().repeat(2, 1))
+        if query_masks is None:
+            self.qmask.fill_(1.0)
+        else:
+            for ci, c in enumerate(CONDS):
+                self.qmask[ci].copy_(query_masks[c].to(dev).float().repeat(2, 1))
+        srcs = []
+        for name, x, wt, bt in (("xf_text", word, w.w_text, w.b_text), ("xf_audio", audio, w.w_audio, w.b_audio)):
+            x = x.to(dev).float().contiguous()
+            n_tok, kin = x.shape[1], x.shape[2]
+            xf = torch.empty(B * n_tok, D, device=dev)
+            st = torch.empty(B * n_tok, D // 64, 2, device=dev)
+            G.gemm(h, M=B * n_tok, N=D, K=kin, W=wt, out=xf, segs=[G.Seg(x.view(B * n_tok, kin))], seg_len=None,
+                   bias=bt, stats_out=st)
+            srcs.append((xf, st, n_tok))
+        ids = speaker_ids.to(dev).long().contiguous()
+        n_tok = ids.shape[1]
+        if w.num_speakers == 1:
+            # reference quirk: zeros of shape [B, B, D] (diffusion_transformer.py:545-546)
+            n_tok = B
+            xf = torch.zeros(B * n_tok, D, device=dev)
+        else:
+            xf = torch.empty(B * n_tok, D, device=dev)
+            h.call("gather_rows", w.spk_table, ids.view(-1), xf, B * n_tok, D)
+        # LayerNorm statistics of rows that no GEMM produced
+        st = torch.empty(B * n_tok, D // 64, 2, device=dev)
+        h.call("row_stats", xf, st, B * n_tok, D)
+        srcs.append((xf, st, n_tok))
+        kv_max = max(s[2] for s in srcs)
+        kv = torch.empty(B * kv_max, 2 * D, device=dev)
+        for l, lw in enumerate(w.layers):
+            for ci in range(3):
+                xf, st, n_tok = srcs[ci]
+                G.gemm(h, M=B * n_tok, N=2 * D, K=D, W=lw["w_kv"][ci], out=kv,
+                       segs=[G.Seg(xf, mode=G.A_LN, stats=st, gamma=lw["tn_g"][ci], beta=lw["tn_b"][ci])],
+                       seg_len=D, bias=lw["b_kv"][ci], ldo=2 * D)
+                h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci], B, n_tok, D)
+        self._keep = srcs
+
+    # ------------------------------------------------------------------ per step
+    def forward(self, x, step):
+        """x [B,T,D] fp32 (device) at respaced step index `step`; returns the head output
+        [2B,T,D] (rows [0,B) conditional, [B,2B) classifier-free) in self.head."""
+        w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
+        xa, xb, xc = self.xa, self.xb, self.xc
+        sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c
+        # h = joint_embed(x) + positional tables, duplicated for the two CFG branches
+        G.gemm(h, M=M, N=D, K=D, W=w.w_embed, out=xa, segs=[G.Seg(x.view(B * T, D))], seg_len=D, a_row_mod=B * T,
+               bias=w.b_embed, tbias=w.tbias, tb_period=T, stats_out=sa_)
+        for l, lw in enumerate(w.layers):
+            ss = w.ss[step, l]
+            # --- self attention
+            G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv,
+                   segs=[G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])], seg_len=D,
+                   bias=lw["b_qkv"], softmax_cols=D)
+            h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D)
+            G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb,
+                   segs=[G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"],
+                               scale_shift=ss[0])], seg_len=D, bias=lw["b_sao"], residual=xa, stats_out=sb_)
+            # --- three parallel cross attentions on the same input
+            G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
+                   segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
+                   bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
+            h.call("ca_attention", self.q3, self.a_pre[l], lw["a_unc"], self.qmask, self.y3, self.st3, R, B, T, D, 3)
+            segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3[c], gamma=lw["ca_sg"][c],
+                          beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
+            segs.append(G.Seg(xb))
+            G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, segs=segs, seg_len=D, bias=lw["b_mix"])
+            # --- FFN
+            G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, segs=[G.Seg(xc)], seg_len=D, bias=lw["b_ff1"], act=1)
+            if w.precision == "bf16":
+                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f)
+            else:
+                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, segs=[G.Seg(self.g)], seg_len=w.FF,
+                       bias=lw["b_ff2"], stats_out=self.st_f)
+            G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa,
+                   segs=[G.Seg(self.yf, mode=G.A_STYL, stats=self.st_f, gamma=lw["ff_sg"], beta=lw["ff_sb"],
+                               scale_shift=ss[4])], seg_len=D, bias=lw["b_ffo"], residual=xc, stats_out=sa_)
+        G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, segs=[G.Seg(xa)], seg_len=D, bias=w.b_out)
+        return self.head
+
+    def cfg_ddim(self, x, x_out, step, c_a, c_b, x0_out=None):
+        """CFG mix of self.head + DDIM (or inversion) update of x -> x_out."""
+        w, sch = self.w, self.w.schedule
+        wc, wu = sch.cfg_weights(w.cfg["scale_func_cfg"], step)
+        self.h.call("cfg_ddim_update", self.head, x, x_out, x0_out, w.js, self.B, w.T, w.D, wc, wu,
+                    float(sch.c_recip[step]), float(sch.c_recipm1[step]), float(c_a), float(c_b))

@@ -23,10 +23,10 @@ class GemmDesc(ctypes.Structure):
                 ("gb_stride", ctypes.c_int), ("W", _vp), ("ldw", ctypes.c_int), ("act", ctypes.c_int),
                 ("bias", _vp), ("tbias", _vp), ("tb_period", ctypes.c_int), ("softmax_cols", ctypes.c_int),
                 ("residual", _vp), ("ldr", ctypes.c_int), ("out_bf16", ctypes.c_int), ("out", _vp),
-                ("ldo", ctypes.c_int), ("pad2_", ctypes.c_int), ("stats_out", _vp)]
+                ("ldo", ctypes.c_int), ("pad2_", ctypes.c_int), ("stats_out", _vp), ("W_lo", _vp)]
 
 
-assert ctypes.sizeof(ASegment) == 56 and ctypes.sizeof(GemmDesc) == 352
+assert ctypes.sizeof(ASegment) == 56 and ctypes.sizeof(GemmDesc) == 360
 
 
 def _p(t, dtype=None):
@@ -39,13 +39,27 @@ def _p(t, dtype=None):
     return t.data_ptr()
 
 
-def pack_weight(w, device=None):
-    """fp32 [N,K] (nn.Linear layout) -> bf16 [ceil64(N), ceil64(K)], zero padded, on device."""
+class PackedWeight:
+    """bf16 [ceil64(N), ceil64(K)] zero-padded GEMM operand; `lo` holds bf16(W - float(hi)) when the
+    weight was packed for the precise (bf16x3) mode."""
+
+    def __init__(self, hi, lo=None):
+        self.hi, self.lo = hi, lo
+
+
+def pack_weight(w, device=None, split=False):
+    """fp32 [N,K] (nn.Linear layout) -> PackedWeight on device."""
     n, k = w.shape
     np_, kp = (n + 63) // 64 * 64, (k + 63) // 64 * 64
-    out = torch.zeros(np_, kp, dtype=torch.bfloat16, device=device or w.device)
-    out[:n, :k] = w.to(out.device).to(torch.bfloat16)
-    return out
+    dev = device or w.device
+    wf = w.to(dev).float()
+    hi = torch.zeros(np_, kp, dtype=torch.bfloat16, device=dev)
+    hi[:n, :k] = wf.to(torch.bfloat16)
+    lo = None
+    if split:
+        lo = torch.zeros(np_, kp, dtype=torch.bfloat16, device=dev)
+        lo[:n, :k] = (wf - hi[:n, :k].float()).to(torch.bfloat16)
+    return PackedWeight(hi, lo)
 
 
 class Seg:
@@ -82,7 +96,8 @@ def make_desc(*, M, N, K, W, out, A=None, segs=None, seg_len=None, bias=None, tb
             if s.mode == A_STYL:
                 e.scale_shift = _p(s.ss, torch.float32)
     d.a_row_mod, d.gb_group, d.gb_stride = a_row_mod, gb_group, gb_stride
-    d.W, d.ldw = _p(W, torch.bfloat16), W.stride(0)
+    d.W, d.ldw = _p(W.hi, torch.bfloat16), W.hi.stride(0)
+    d.W_lo = _p(W.lo, torch.bfloat16) if (W.lo is not None and A is None) else None
     d.act, d.softmax_cols = act, softmax_cols
     d.bias = _p(bias, torch.float32)
     d.tbias, d.tb_period = _p(tbias, torch.float32), tb_period

@@ -1,0 +1,79 @@
+"""DDIM sampling / inversion / insertion-guided loops on top of DenoiserSession.
+
+Mirrors the reference's samplers for the inference configuration (START_X prediction, eta = 0,
+no clipping): mogen/models/utils/gaussian_diffusion.py
+  :1042-1135 ddim_sample_loop(_progressive)   -> ddim_sample_loop
+  :1137-1230 ddim_reverse_sample_loop          -> ddim_reverse_sample_loop
+  :1233-1395 ddim_guided_sample_loop           -> ddim_guided_sample_loop
+  :910-1001  ddim_sample (in_seq replacement + DDIM update)
+Every step is a fixed sequence of kernel launches with no host read-back (CFG weights and
+DDIM coefficients come from 50-entry host tables), so a whole loop can be captured into one
+graph (`GraphedLoop`).  Noise is explicit: the caller supplies the tensors the reference would
+have drawn from torch's global generator.
+"""
+import torch
+
+from . import capi
+
+
+def _step(sess, x, i, in_seq=None, noise=None):
+    """One ddim_sample call at respaced index i, in place on x [B,T,D]."""
+    sch, w, h = sess.w.schedule, sess.w, sess.h
+    if in_seq is not None:
+        h.call("inseq_replace", x, in_seq, noise, sess.B * w.T, w.D, float(sch.s_ab[i]), float(sch.s_1mab[i]))
+    sess.forward(x, i)
+    sess.cfg_ddim(x, x, i, sch.c_prev_a[i], sch.c_prev_b[i])
+
+
+def ddim_sample_loop(sess, x, in_seq=None, inseq_noise=None):
+    """x: start noise [B,T,D] (updated in place and returned).  in_seq [B,T,D] or None;
+    inseq_noise [S,B,T,D] = the randn_like(in_seq) draws, indexed by step."""
+    S = sess.w.schedule.num_timesteps
+    for i in range(S - 1, -1, -1):
+        _step(sess, x, i, in_seq, None if in_seq is None else inseq_noise[i])
+    return x
+
+
+def ddim_reverse_sample_loop(sess, x, out):
+    """DDIM inversion of x [B,T,D] (clean -> noise); out [S,B,T,D] receives every level
+    (out[k] = latent at alphas_cumprod_next[k]), x is updated in place to out[S-1]."""
+    sch = sess.w.schedule
+    for i in range(sch.num_timesteps):
+        sess.forward(x, i)
+        sess.cfg_ddim(x, x, i, sch.c_next_a[i], sch.c_next_b[i])
+        out[i].copy_(x)
+    return out
+
+
+def ddim_guided_sample_loop(sess, x, inverted, guidance_iters, guidance_lr, inseq_noise, in_seq=None):
+    """Insertion-guided sampling.  inverted [S,B,T,D] (zero rows = not guided); on every step but
+    the first the reference sets in_seq = inverted[i], runs g_iter gradient steps on
+    mse(x*mask, in_seq) and then ddim_sample re-inserts q_sample(in_seq) on the masked rows."""
+    sch, w, h = sess.w.schedule, sess.w, sess.h
+    S = sch.num_timesteps
+    assert len(guidance_iters) == S == inverted.shape[0]
+    for i in range(S - 1, -1, -1):
+        if i != S - 1:
+            in_seq = inverted[i]
+            h.call("guidance_update", x, in_seq, sess.B * w.T, w.D, int(guidance_iters[i]), float(guidance_lr))
+        _step(sess, x, i, in_seq, None if in_seq is None else inseq_noise[i])
+    return x
+
+
+class GraphedLoop:
+    """Capture fn() (a fixed launch sequence over static buffers) into a HIP graph and replay it.
+    torch.cuda.CUDAGraph is used purely as the capture/replay plumbing."""
+
+    def __init__(self, fn, warmup=True):
+        if warmup:  # first call outside capture: lazy module loads, allocator warm-up
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                fn()
+            torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            fn()
+
+    def replay(self):
+        self.graph.replay()

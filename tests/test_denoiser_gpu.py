@@ -1,0 +1,146 @@
+"""GPU: the HIP denoiser (bf16 MFMA GEMMs, fp32 everything else) against
+  (a) the golden vectors produced by the real reference (fp32 CPU), and
+  (b) the oracle run with bf16-rounded GEMM operands and exact LayerNorm on -1e6 rows,
+      which is what the kernels implement -> tighter tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as od, diffusion as odf
+
+pytestmark = pytest.mark.gpu
+KEEP = [r for r in range(43) if r not in (10, 20, 30)]
+STEP_OF_T = {999: 49, 514: 34, 99: 7, 0: 0}
+
+
+def relerr(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+@pytest.fixture(scope="module")
+def setup(rg):
+    assert torch.cuda.is_available()
+    out = {}
+    for L in (2, 8):
+        cfg = rg.synth.default_model_cfg(num_layers=L)
+        P = rg.synth.synth_denoiser_state(0, cfg)
+        sch = rg.schedule.Schedule()
+        W = rg.denoiser.DenoiserWeights(P, cfg, sch, "cuda")
+        out[L] = (cfg, P, W)
+    out["fp32"] = (cfg, P, rg.denoiser.DenoiserWeights(P, cfg, sch, "cuda", precision="fp32"))
+    return out
+
+
+def _inputs(rg, B=2):
+    data = rg.synth.synth_batch(B, seed=1234)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(99)).standard_normal((B, 43, 512)).astype(np.float32))
+    mm = torch.ones(B, 43)
+    mm[:, [10, 21, 32]] = 0
+    return data, x, mm
+
+
+def _hip_x0(rg, W, sess, x, step):
+    xd = x.cuda()
+    sess.forward(xd, step)
+    x0 = torch.empty_like(xd)
+    sch = W.schedule
+    sess.cfg_ddim(xd, torch.empty_like(xd), step, sch.c_prev_a[step], sch.c_prev_b[step], x0_out=x0)
+    torch.cuda.synchronize()
+    return x0.cpu()
+
+
+def test_timestep_tables_exact(rg, setup):
+    """The load-time emb tables are fp32-exact restatements of time_embed + emb_layers."""
+    cfg, P, W = setup[2]
+    ts = torch.tensor(W.schedule.timestep_map)
+    emb = od.linear(P, "time_embed.2", torch.nn.functional.silu(od.linear(P, "time_embed.0", od.timestep_embedding(ts, 512))))
+    for l in range(2):
+        for bi, blk in enumerate(rg.denoiser.BLOCKS):
+            ref = od.linear(P, "temporal_decoder_blocks.%d.%s.proj_out.emb_layers.1" % (l, blk), torch.nn.functional.silu(emb))
+            assert (W.ss[:, l, bi].cpu() - ref).abs().max() <= 2e-5
+
+
+@pytest.mark.parametrize("L,tag", [(2, "L2_allenc"), (8, "L8_encdec")])
+def test_forward_vs_reference_golden(rg, setup, golden_dir, L, tag):
+    cfg, P, W = setup[L]
+    g = np.load(os.path.join(golden_dir, "denoiser_%s.npz" % tag))
+    data, x, mm = _inputs(rg)
+    sess = rg.denoiser.DenoiserSession(W, 2)
+    for masks in ("ones", "real"):
+        qm = od.make_query_masks(mm) if masks == "real" else None
+        sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
+        for t, step in STEP_OF_T.items():
+            x0 = _hip_x0(rg, W, sess, x, step)
+            ref = torch.from_numpy(g["den_%s_t%d" % (masks, t)])
+            rows = KEEP if masks == "real" else list(range(43))
+            e = relerr(x0[:, rows], ref[:, rows])
+            print(tag, masks, "t=%d rel err vs reference golden %.3e" % (t, e))
+            # bf16 GEMM operands vs the fp32 reference; the stated tolerance is 2e-2 relative on x0
+            assert e <= 2e-2
+
+
+def test_precise_mode_vs_reference_golden(rg, setup, golden_dir):
+    """fp32-equivalent (bf16x3) GEMM mode, L=8, against the real reference's fp32 output.
+    Without query masks every row must agree tightly; this is the structural parity check
+    (all hoists/fusions are exact algebra)."""
+    cfg, P, W = setup["fp32"]
+    g = np.load(os.path.join(golden_dir, "denoiser_L8_encdec.npz"))
+    data, x, mm = _inputs(rg)
+    sess = rg.denoiser.DenoiserSession(W, 2)
+    sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, None)
+    for t, step in STEP_OF_T.items():
+        x0 = _hip_x0(rg, W, sess, x, step)
+        ref = torch.from_numpy(g["den_ones_t%d" % t])
+        e, ea = relerr(x0, ref), (x0 - ref).abs().max().item()
+        print("precise mode t=%d rel err vs reference golden %.3e  max abs %.3e" % (t, e, ea))
+        assert e <= 1e-4
+
+
+def test_precise_mode_masked_rows_vs_exact_ln_oracle(rg, setup):
+    """With the reference's query masks, rows 10/20/30 go through LayerNorm(y - 1e6).  The kernels
+    evaluate that LayerNorm exactly on the fp32-quantised row; the oracle does the same when
+    masked_ln="exact" (torch's fp32 LayerNorm differs there by a platform-dependent rounding of
+    a mean near -1e6)."""
+    cfg, P, W = setup["fp32"]
+    data, x, mm = _inputs(rg)
+    sess = rg.denoiser.DenoiserSession(W, 2)
+    qm = od.make_query_masks(mm)
+    sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
+    xf = od.encode_conditions(P, data["word"], data["audio"], data["speaker_ids"])
+    od.OPTS.update(masked_ln="exact")
+    try:
+        for t, step in ((999, 49), (99, 7)):
+            ref = od.denoiser_forward(P, cfg, x, torch.full((2,), t, dtype=torch.long), mm, xf, qm)
+            x0 = _hip_x0(rg, W, sess, x, step)
+            e = relerr(x0, ref)
+            print("precise mode, real masks, t=%d rel err vs exact-LN oracle (all 43 rows) %.3e" % (t, e))
+            assert e <= 1e-3
+    finally:
+        od.OPTS.update(masked_ln="torch")
+
+
+def test_sample_loop_graph_matches_eager_and_oracle(rg, setup):
+    """50-step base loop: graph replay == eager launches bit for bit; final latent vs fp32 oracle."""
+    cfg, P, W = setup[2]
+    data, x, mm = _inputs(rg)
+    sess = rg.denoiser.DenoiserSession(W, 2)
+    qm = od.make_query_masks(mm)
+    sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
+    xe = x.cuda()
+    rg.sampler.ddim_sample_loop(sess, xe)
+    torch.cuda.synchronize()
+    xg = x.cuda()
+    xs = xg.clone()
+    loop = rg.sampler.GraphedLoop(lambda: rg.sampler.ddim_sample_loop(sess, xg))
+    xg.copy_(xs)
+    loop.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(xg, xe)
+    xf = od.encode_conditions(P, data["word"], data["audio"], data["speaker_ids"])
+    model = lambda a, t: od.denoiser_forward(P, cfg, a, t, mm, xf, qm)
+    ref = odf.ddim_sample_loop(odf.SpacedSchedule(), model, x, lambda s: torch.zeros(s))
+    e = relerr(xe.cpu()[:, KEEP], ref[:, KEEP])
+    print("50-step loop rel err vs fp32 oracle %.3e" % e)
+    assert e <= 2e-2
