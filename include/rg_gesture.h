@@ -76,6 +76,12 @@ int rg_guidance_update(rg_handle* h, float* x, const float* in_seq, int rows, in
  *   (diffusion_architecture.py:386-407).  src/dst are [*,T,D]. */
 int rg_splice_rows(rg_handle* h, const float* src, float* dst, int T, int D, int n_lat,
                    int b_src, int b_dst, int r0, int r1, int q0, int q1, void* stream);
+/* The same splice repeated for nrep (diffusion level) slabs: slab s reads batch item
+ * b_src + s*src_rep_stride and writes b_dst + s*dst_rep_stride (the 50 per-timestep inverted
+ * latents, diffusion_architecture.py:399-407). */
+int rg_splice_rows_rep(rg_handle* h, const float* src, float* dst, int T, int D, int n_lat,
+                       int b_src, int b_dst, int r0, int r1, int q0, int q1, int nrep,
+                       int src_rep_stride, int dst_rep_stride, void* stream);
 
 /* ---------------------------------------------------------------- fused bf16-MFMA GEMM
  * out[M,N] = epilogue( A'[M,K] * W[N,K]^T ), bf16 operands, fp32 accumulate (MFMA 16x16x32).
@@ -120,7 +126,7 @@ typedef struct rg_gemm_desc {
   int gb_stride;
   const void* W;          // bf16 [Np, ldw]  (rows = output features, K contiguous, zero padded)
   int ldw;
-  int act;                // 0 none, 1 GELU(erf)
+  int act;                // 0 none, 1 GELU(erf), 2 ReLU
   const float* bias;      // [N] or null
   const float* tbias;     // [tb_period, N] or null: + tbias[(row % tb_period) * N + col]
   int tb_period;
@@ -177,6 +183,46 @@ int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows, int dim, 
  * StylizationBlock emb_layers, stylization_block.py:35, which depend only on the timestep). */
 int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bias, float* out, int M,
                   int N, int K, int silu_in, int silu_out, void* stream);
+
+/* ---------------------------------------------------------------- body-part VAEs + rotations
+ * Softmax multi-head attention core of torch.nn.MultiheadAttention for short sequences
+ * (detr_utils.py:364-366, 427-433): o[b,i,h,:] = softmax_j(q[b,i,h,:].k[b,j,h,:]/sqrt(hd)) v[b,j,h,:].
+ * q [B*Sq, ldq], k/v [B*Sk, ld], head h in columns [h*hd, (h+1)*hd); Sk <= 192; no padding mask
+ * (the reference always passes full-length clips, gesture_vae.py:124-160). */
+int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+           int ldo, int B, int H, int Sq, int Sk, int hd, void* stream);
+
+/* nn.LayerNorm(dim), eps 1e-5, fp32 rows (detr_utils.py norm1/norm2/norm3, encoder/decoder norm). */
+int rg_layernorm(rg_handle* h, const float* x, const float* gamma, const float* beta, float* out, int rows,
+                 int dim, void* stream);
+
+/* out[i] = a[i] + b[i % period]: positional embeddings / `with_pos_embed` (detr_utils.py:357-358). */
+int rg_add_rows(rg_handle* h, const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream);
+
+/* Row gather/scatter between [groups, rows_per, dim] tensors (token prepend, latent slicing:
+ * gesture_vae.py:150-158, 214-216; diffusion_transformer.py:239-254, 273-278). rows_src_per = 0
+ * broadcasts the same source rows to every group. */
+int rg_copy_rows(rg_handle* h, const float* src, float* dst, int groups, int nrows_per, int dim, int rows_src_per,
+                 int src_row0, int rows_dst_per, int dst_row0, void* stream);
+
+/* Column copy dst[r, dcol+c] = src[r, scol+c]; columns flagged in rel_mask are made relative to the
+ * first frame of their clip (frames rows per clip): `trans[:,:,0] -= trans[:,0:1,0]`
+ * (diffusion_transformer.py:231-232). */
+int rg_copy_cols(rg_handle* h, const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol, int rows,
+                 int ncols, int frames, unsigned rel_mask, void* stream);
+
+/* Reparameterisation with explicit noise, scattered into the [B,T,D] diffusion latent:
+ * latent[b, row_off + c, :] = mu + exp(logvar)^0.5 * eps, mu/logvar = tokens 0/1 of the encoder
+ * output enc [B*n_chunks, seq, D] (gesture_vae.py:173-193). */
+int rg_vae_reparam(rg_handle* h, const float* enc, int seq, const float* eps, float* latent, int B, int n_chunks,
+                   int D, int T, int row_off, void* stream);
+
+/* axis-angle [rows, joints*3] -> 6D [rows, joints*6] written at column col_off of out, and back
+ * (rotation_conversions.py:416-430 + 535-550; 511-532 + 433-447). */
+int rg_aa_to_6d(rg_handle* h, const float* aa, int ld_in, float* out, int ld_out, int col_off, int rows, int joints,
+                void* stream);
+int rg_6d_to_aa(rg_handle* h, const float* d6, int ld_in, int col_off, float* out, int ld_out, int rows, int joints,
+                void* stream);
 
 #ifdef __cplusplus
 }

@@ -43,7 +43,11 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+// SiLU on the A-operand prologue path: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the libm
+// expf + IEEE divide; the result is rounded to bf16 (or split hi/lo) right after.
+__device__ __forceinline__ float silu_f(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 struct AStage {            // per-thread staging registers for one K-tile
@@ -316,6 +320,9 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
   if (p.act == 1) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
   }
   if (p.residual && row_ok) {
     const float* rp = p.residual + (size_t)grow * p.ldr + gcol;

@@ -124,14 +124,18 @@ __global__ void __launch_bounds__(kBlock) guidance_kernel(float* __restrict__ x,
 
 __global__ void __launch_bounds__(kBlock) splice_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
                                                        int d4, int nrows, int src_row0, int dst_row0,
-                                                       int hands_off) {
+                                                       int hands_off, int nrep, int64_t src_rep_rows,
+                                                       int64_t dst_rep_rows) {
   // rows [0,nrows): upper block; rows [nrows, 2*nrows): hands block (offset hands_off token rows)
-  int64_t total = (int64_t)2 * nrows * d4;
+  const int64_t per = (int64_t)2 * nrows * d4;
+  const int64_t total = per * nrep;
   for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-    int r = (int)(i / d4), c = (int)(i % d4);
+    const int s = (int)(i / per);
+    const int64_t w = i % per;
+    int r = (int)(w / d4), c = (int)(w % d4);
     int off = (r >= nrows) ? hands_off : 0;
     int rr = (r >= nrows) ? r - nrows : r;
-    dst[(int64_t)(dst_row0 + off + rr) * d4 + c] = src[(int64_t)(src_row0 + off + rr) * d4 + c];
+    dst[(s * dst_rep_rows + dst_row0 + off + rr) * d4 + c] = src[(s * src_rep_rows + src_row0 + off + rr) * d4 + c];
   }
 }
 
@@ -205,17 +209,23 @@ extern "C" int rg_guidance_update(rg_handle* h, float* x, const float* in_seq, i
   return RG_OK;
 }
 
-extern "C" int rg_splice_rows(rg_handle* h, const float* src, float* dst, int T, int D, int n_lat, int b_src,
-                              int b_dst, int r0, int r1, int q0, int q1, void* stream) {
+extern "C" int rg_splice_rows_rep(rg_handle* h, const float* src, float* dst, int T, int D, int n_lat, int b_src,
+                                  int b_dst, int r0, int r1, int q0, int q1, int nrep, int src_rep_stride,
+                                  int dst_rep_stride, void* stream) {
   RG_REQUIRE(h, src && dst, "null pointer");
-  RG_REQUIRE(h, D % 4 == 0 && r1 - r0 == q1 - q0 && r0 >= 0 && q0 >= 0 && r1 <= n_lat && q1 <= n_lat,
+  RG_REQUIRE(h, D % 4 == 0 && r1 - r0 == q1 - q0 && r0 >= 0 && q0 >= 0 && r1 <= n_lat && q1 <= n_lat && nrep > 0,
              "bad row ranges");
   int nrows = r1 - r0;
   if (nrows <= 0) return RG_OK;
   int d4 = D / 4;
-  hipLaunchKernelGGL(splice_kernel, dim3(rg_grid_1d((int64_t)2 * nrows * d4, kBlock)), dim3(kBlock), 0,
+  hipLaunchKernelGGL(splice_kernel, dim3(rg_grid_1d((int64_t)2 * nrows * d4 * nrep, kBlock)), dim3(kBlock), 0,
                      rg_stream(stream), (const float4*)src, (float4*)dst, d4, nrows, b_src * T + r0,
-                     b_dst * T + q0, n_lat + 1);
+                     b_dst * T + q0, n_lat + 1, nrep, (int64_t)src_rep_stride * T, (int64_t)dst_rep_stride * T);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
+}
+
+extern "C" int rg_splice_rows(rg_handle* h, const float* src, float* dst, int T, int D, int n_lat, int b_src,
+                              int b_dst, int r0, int r1, int q0, int q1, void* stream) {
+  return rg_splice_rows_rep(h, src, dst, T, D, n_lat, b_src, b_dst, r0, r1, q0, q1, 1, 0, 0, stream);
 }

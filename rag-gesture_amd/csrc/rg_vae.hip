@@ -1,0 +1,333 @@
+// Kernels of the four body-part TransformerVAEs (everything that is not an nn.Linear; the
+// linears go through rg_gemm) and the SMPL-X rotation conversions around them.
+//
+//  rg_mha            : torch.nn.MultiheadAttention core, softmax(Q K^T / sqrt(hd)) V, short sequences
+//                      (reference: utils/detr_utils.py:364-366, 427-433 via nn.MultiheadAttention)
+//  rg_layernorm      : nn.LayerNorm over the last dim (detr_utils.py:368,371,...)
+//  rg_add_rows       : out = a + b[row % period]   (positional embeddings, `with_pos_embed`)
+//  rg_vae_reparam    : z = mu + exp(0.5*logvar) * eps scattered into the [B,43,D] latent
+//                      (gesture_vae.py:173-193, diffusion_transformer.py:239-254)
+//  rg_aa_to_6d / rg_6d_to_aa : rotation_conversions.py:416-550 (quaternion route of the old
+//                      PyTorch3D fork, incl. the 1e-6 small-angle branches)
+#include "rg_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------ MHA
+// grid = (B*H, ceil(Sq/QB)); 256 threads; K/V of one (batch, head) staged in LDS
+// (K rows padded by one float: lanes read different keys at the same d).
+constexpr int QB = 32;
+
+__global__ void __launch_bounds__(256) mha_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                 int ldk, const float* __restrict__ v, int ldv, float* __restrict__ o,
+                                                 int ldo, int H, int Sq, int Sk, int hd, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int q0 = blockIdx.y * QB;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int kst = hd + 1;
+  float* sK = sm;                        // [Sk][hd+1]
+  float* sV = sK + Sk * kst;             // [Sk][hd]
+  float* sQ = sV + Sk * hd;              // [4 waves][hd]
+  float* sP = sQ + 4 * hd;               // [4 waves][Sk]
+  for (int i = threadIdx.x; i < Sk * hd; i += 256) {
+    const int j = i / hd, d = i % hd;
+    sK[j * kst + d] = k[((size_t)b * Sk + j) * ldk + h * hd + d];
+    sV[j * hd + d] = v[((size_t)b * Sk + j) * ldv + h * hd + d];
+  }
+  __syncthreads();
+  const int qend = min(q0 + QB, Sq);
+  float* myQ = sQ + wave * hd;
+  float* myP = sP + wave * Sk;
+  for (int r = q0 + wave; r < qend; r += 4) {
+    const float* qr = q + ((size_t)b * Sq + r) * ldq + h * hd;
+    for (int d = lane; d < hd; d += 64) myQ[d] = qr[d] * scale;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float sc[3];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = lane + 64 * t;
+      float s = -INFINITY;
+      if (j < Sk) {
+        s = 0.f;
+        const float* kr = sK + j * kst;
+        for (int d = 0; d < hd; ++d) s = fmaf(myQ[d], kr[d], s);
+      }
+      sc[t] = s;
+      mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = lane + 64 * t;
+      const float e = (j < Sk) ? expf(sc[t] - mx) : 0.f;
+      sc[t] = e;
+      sum += e;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) sum += __shfl_xor(sum, off);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int j = lane + 64 * t;
+      if (j < Sk) myP[j] = sc[t] * inv;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    float* orow = o + ((size_t)b * Sq + r) * ldo + h * hd;
+    for (int d = lane; d < hd; d += 64) {
+      float acc = 0.f;
+      for (int j = 0; j < Sk; ++j) acc = fmaf(myP[j], sV[j * hd + d], acc);
+      orow[d] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------ LayerNorm, one wave per row
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float* __restrict__ out, int rows,
+                                                       int dim, float eps) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * dim;
+  float s = 0.f;
+  for (int i = lane; i < dim; i += 64) s += xr[i];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)dim;
+  float ss = 0.f;
+  for (int i = lane; i < dim; i += 64) {
+    const float d = xr[i] - mean;
+    ss += d * d;
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) ss += __shfl_xor(ss, off);
+  const float rstd = rsqrtf(ss / (float)dim + eps);
+  float* orow = out + (size_t)row * dim;
+  for (int i = lane; i < dim; i += 64) orow[i] = (xr[i] - mean) * rstd * g[i] + b[i];
+}
+
+__global__ void __launch_bounds__(256) add_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                      float4* __restrict__ out, int64_t n4, int64_t period4) {
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 x = a[i], y = b[i % period4];
+    out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+  }
+}
+
+// copy `nrows_per` rows per group from src (row stride ld_src, rows_src_per rows per group, starting at
+// src_row0 inside the group) to dst (rows_dst_per rows per group, starting at dst_row0).
+__global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int groups, int nrows_per, int dim, int rows_src_per,
+                                                       int src_row0, int rows_dst_per, int dst_row0) {
+  const int64_t total = (int64_t)groups * nrows_per * dim;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % dim);
+    const int64_t r = i / dim;
+    const int g = (int)(r / nrows_per), rr = (int)(r % nrows_per);
+    dst[((int64_t)g * rows_dst_per + dst_row0 + rr) * dim + c] =
+        src[((int64_t)g * rows_src_per + src_row0 + rr) * dim + c];
+  }
+}
+
+// z[b, row_off + c, :] = mu + exp(logvar)^0.5 * eps  with mu = enc[(b*n_chunks+c), 0, :], logvar = enc[.., 1, :]
+__global__ void __launch_bounds__(256) vae_reparam_kernel(const float* __restrict__ enc, int seq, const float* __restrict__ eps,
+                                                         float* __restrict__ latent, int B, int n_chunks, int D, int T,
+                                                         int row_off) {
+  const int64_t total = (int64_t)B * n_chunks * D;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    const int64_t bc = i / D;
+    const int b = (int)(bc / n_chunks), c = (int)(bc % n_chunks);
+    const float mu = enc[(bc * seq + 0) * D + d];
+    const float lv = enc[(bc * seq + 1) * D + d];
+    const float sd = sqrtf(expf(lv));  // logvar.exp().pow(0.5)
+    latent[((int64_t)b * T + row_off + c) * D + d] = mu + sd * eps[i];
+  }
+}
+
+// ------------------------------------------------------------------------------ rotations
+#pragma clang fp contract(off)
+__device__ __forceinline__ void aa_to_6d_one(const float* a, float* o) {
+  const float x = a[0], y = a[1], z = a[2];
+  const float angle = sqrtf(x * x + y * y + z * z);
+  const float half = 0.5f * angle;
+  const float s = (fabsf(angle) < 1e-6f) ? (0.5f - (angle * angle) / 48.0f) : (sinf(half) / angle);
+  const float r = cosf(half), i = x * s, j = y * s, k = z * s;
+  const float two_s = 2.0f / (r * r + i * i + j * j + k * k);
+  o[0] = 1 - two_s * (j * j + k * k);
+  o[1] = two_s * (i * j - k * r);
+  o[2] = two_s * (i * k + j * r);
+  o[3] = two_s * (i * j + k * r);
+  o[4] = 1 - two_s * (i * i + k * k);
+  o[5] = two_s * (j * k - i * r);
+}
+
+__device__ __forceinline__ float sqrt_pos(float v) { return v > 0.f ? sqrtf(v) : 0.f; }
+__device__ __forceinline__ float copysign_ref(float a, float b) { return ((a < 0.f) != (b < 0.f)) ? -a : a; }
+
+__device__ __forceinline__ void sixd_to_aa_one(const float* d6, float* o) {
+  // rotation_6d_to_matrix: Gram-Schmidt, F.normalize eps 1e-12
+  float a1[3] = {d6[0], d6[1], d6[2]}, a2[3] = {d6[3], d6[4], d6[5]};
+  float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+  float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+  const float dot = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+  float b2[3] = {a2[0] - dot * b1[0], a2[1] - dot * b1[1], a2[2] - dot * b1[2]};
+  float n2 = fmaxf(sqrtf(b2[0] * b2[0] + b2[1] * b2[1] + b2[2] * b2[2]), 1e-12f);
+  b2[0] /= n2; b2[1] /= n2; b2[2] /= n2;
+  float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+  // matrix rows are b1, b2, b3: m[r][c]
+  const float m00 = b1[0], m11 = b2[1], m22 = b3[2];
+  const float o0 = 0.5f * sqrt_pos(1 + m00 + m11 + m22);
+  const float qx = 0.5f * sqrt_pos(1 + m00 - m11 - m22);
+  const float qy = 0.5f * sqrt_pos(1 - m00 + m11 - m22);
+  const float qz = 0.5f * sqrt_pos(1 - m00 - m11 + m22);
+  const float o1 = copysign_ref(qx, b3[1] - b2[2]);  // m21 - m12
+  const float o2 = copysign_ref(qy, b1[2] - b3[0]);  // m02 - m20
+  const float o3 = copysign_ref(qz, b2[0] - b1[1]);  // m10 - m01
+  const float norm = sqrtf(o1 * o1 + o2 * o2 + o3 * o3);
+  const float half = atan2f(norm, o0);
+  const float angle = 2.0f * half;
+  const float s = (fabsf(angle) < 1e-6f) ? (0.5f - (angle * angle) / 48.0f) : (sinf(half) / angle);
+  o[0] = o1 / s; o[1] = o2 / s; o[2] = o3 / s;
+}
+
+__global__ void __launch_bounds__(256) aa_to_6d_kernel(const float* __restrict__ aa, int ld_in, float* __restrict__ out,
+                                                      int ld_out, int col_off, int rows, int joints) {
+  const int64_t total = (int64_t)rows * joints;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / joints), j = (int)(i % joints);
+    float a[3], o[6];
+    const float* p = aa + (size_t)r * ld_in + j * 3;
+    a[0] = p[0]; a[1] = p[1]; a[2] = p[2];
+    aa_to_6d_one(a, o);
+    float* q = out + (size_t)r * ld_out + col_off + j * 6;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) q[e] = o[e];
+  }
+}
+
+__global__ void __launch_bounds__(256) sixd_to_aa_kernel(const float* __restrict__ d6, int ld_in, int col_off,
+                                                        float* __restrict__ out, int ld_out, int rows, int joints) {
+  const int64_t total = (int64_t)rows * joints;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / joints), j = (int)(i % joints);
+    float a[6], o[3];
+    const float* p = d6 + (size_t)r * ld_in + col_off + j * 6;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) a[e] = p[e];
+    sixd_to_aa_one(a, o);
+    float* q = out + (size_t)r * ld_out + j * 3;
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+  }
+}
+
+// generic strided 2-D copy of fp32 columns: dst[r, dcol + c] = src[r, scol + c] (+ optional
+// "subtract first frame" on selected columns, used for trans x/z re-zeroing)
+__global__ void __launch_bounds__(256) copy_cols_kernel(const float* __restrict__ src, int ld_src, int scol,
+                                                       float* __restrict__ dst, int ld_dst, int dcol, int rows,
+                                                       int ncols, int frames, unsigned rel_mask) {
+  const int64_t total = (int64_t)rows * ncols;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / ncols), c = (int)(i % ncols);
+    float vv = src[(size_t)r * ld_src + scol + c];
+    if (frames > 0 && c < 32 && ((rel_mask >> c) & 1u)) vv = vv - src[(size_t)(r / frames) * frames * ld_src + scol + c];
+    dst[(size_t)r * ld_dst + dcol + c] = vv;
+  }
+}
+
+}  // namespace
+
+static inline int grid_for(int64_t n) { return rg_grid_1d(n, 256); }
+
+extern "C" int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
+                      int ldo, int B, int H, int Sq, int Sk, int hd, void* stream) {
+  RG_REQUIRE(h, q && k && v && o, "null pointer");
+  RG_REQUIRE(h, B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 192 && hd > 0 && hd <= 256, "bad shape (Sk <= 192)");
+  const size_t lds = ((size_t)Sk * (hd + 1) + (size_t)Sk * hd + 4 * hd + 4 * Sk) * sizeof(float);
+  RG_REQUIRE(h, lds <= 160 * 1024, "K/V of one head do not fit LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mha_kernel, dim3(B * H, (Sq + QB - 1) / QB), dim3(256), lds, rg_stream(stream), q, ldq, k, ldk, v,
+                     ldv, o, ldo, H, Sq, Sk, hd, 1.0f / sqrtf((float)hd));
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_layernorm(rg_handle* h, const float* x, const float* gamma, const float* beta, float* out, int rows,
+                            int dim, void* stream) {
+  RG_REQUIRE(h, x && gamma && beta && out, "null pointer");
+  RG_REQUIRE(h, rows > 0 && dim > 0, "bad shape");
+  hipLaunchKernelGGL(layernorm_kernel, dim3(((int64_t)rows * 64 + 255) / 256), dim3(256), 0, rg_stream(stream), x, gamma,
+                     beta, out, rows, dim, 1e-5f);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_add_rows(rg_handle* h, const float* a, const float* b, float* out, int64_t n, int64_t period,
+                           void* stream) {
+  RG_REQUIRE(h, a && b && out, "null pointer");
+  RG_REQUIRE(h, n > 0 && period > 0 && n % 4 == 0 && period % 4 == 0, "sizes must be multiples of 4");
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(n / 4)), dim3(256), 0, rg_stream(stream), (const float4*)a,
+                     (const float4*)b, (float4*)out, n / 4, period / 4);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_copy_rows(rg_handle* h, const float* src, float* dst, int groups, int nrows_per, int dim,
+                            int rows_src_per, int src_row0, int rows_dst_per, int dst_row0, void* stream) {
+  RG_REQUIRE(h, src && dst, "null pointer");
+  RG_REQUIRE(h, groups > 0 && nrows_per > 0 && dim > 0, "bad shape");
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((int64_t)groups * nrows_per * dim)), dim3(256), 0,
+                     rg_stream(stream), src, dst, groups, nrows_per, dim, rows_src_per, src_row0, rows_dst_per, dst_row0);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_vae_reparam(rg_handle* h, const float* enc, int seq, const float* eps, float* latent, int B,
+                              int n_chunks, int D, int T, int row_off, void* stream) {
+  RG_REQUIRE(h, enc && eps && latent, "null pointer");
+  RG_REQUIRE(h, B > 0 && n_chunks > 0 && D > 0 && seq >= 2 && row_off + n_chunks <= T, "bad shape");
+  hipLaunchKernelGGL(vae_reparam_kernel, dim3(grid_for((int64_t)B * n_chunks * D)), dim3(256), 0, rg_stream(stream), enc,
+                     seq, eps, latent, B, n_chunks, D, T, row_off);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_aa_to_6d(rg_handle* h, const float* aa, int ld_in, float* out, int ld_out, int col_off, int rows,
+                           int joints, void* stream) {
+  RG_REQUIRE(h, aa && out, "null pointer");
+  RG_REQUIRE(h, rows > 0 && joints > 0, "bad shape");
+  hipLaunchKernelGGL(aa_to_6d_kernel, dim3(grid_for((int64_t)rows * joints)), dim3(256), 0, rg_stream(stream), aa, ld_in,
+                     out, ld_out, col_off, rows, joints);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_6d_to_aa(rg_handle* h, const float* d6, int ld_in, int col_off, float* out, int ld_out, int rows,
+                           int joints, void* stream) {
+  RG_REQUIRE(h, d6 && out, "null pointer");
+  RG_REQUIRE(h, rows > 0 && joints > 0, "bad shape");
+  hipLaunchKernelGGL(sixd_to_aa_kernel, dim3(grid_for((int64_t)rows * joints)), dim3(256), 0, rg_stream(stream), d6,
+                     ld_in, col_off, out, ld_out, rows, joints);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_copy_cols(rg_handle* h, const float* src, int ld_src, int scol, float* dst, int ld_dst, int dcol,
+                            int rows, int ncols, int frames, unsigned rel_mask, void* stream) {
+  RG_REQUIRE(h, src && dst, "null pointer");
+  RG_REQUIRE(h, rows > 0 && ncols > 0 && ncols <= 32 * 8, "bad shape");
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for((int64_t)rows * ncols)), dim3(256), 0, rg_stream(stream), src,
+                     ld_src, scol, dst, ld_dst, dcol, rows, ncols, frames, rel_mask);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}

@@ -1,0 +1,287 @@
+"""Drop-in for the reference's inference entry points:
+
+    model = build_architecture(cfg.model, database=train_dataset)   # mogen/models/builder.py:22-26
+    model.load_state_dict(ckpt["state_dict"]); model.eval()
+    with torch.no_grad(): out = model(**data)                       # tools/visualize.py:189-200
+
+`MotionDiffusion.forward(**kwargs)` mirrors the eval branch of
+mogen/models/architectures/diffusion_architecture.py:117-176, 213-582 (same kwargs, same
+`inference_kwargs` flags and compatibility asserts, same result keys; the input dict itself is
+returned, mutated, exactly like the reference's `results = kwargs`).  All arithmetic runs in the
+HIP extension; there is no CPU fallback.
+
+Differences that are deliberate and documented in DESIGN.md:
+  * exemplar DDIM inversions of all clips run as ONE batch (the reference loops at batch 1);
+  * randomness: by default torch's generator on the device; `inference_kwargs["noise_tape"]`
+    (an object with draw(shape)) replays explicit noise in the reference's consumption order
+     for parity tests.
+"""
+import copy
+import os
+
+import torch
+import yaml
+
+from . import capi, denoiser, sampler, schedule as sched_mod, vae as vae_mod
+
+MODELS = {}
+
+
+def register_module(cls):
+    MODELS[cls.__name__] = cls
+    return cls
+
+
+def build_architecture(cfg, **kwargs):
+    """Same contract as mogen/models/builder.py:22-26 (pops `type`, instantiates)."""
+    cfg = dict(cfg)
+    return MODELS[cfg.pop("type")](**cfg, **kwargs)
+
+
+def build_submodule(cfg, **kwargs):
+    cfg = dict(cfg)
+    return MODELS[cfg.pop("type")](**cfg, **kwargs)
+
+
+class _TorchNoise:
+    def __init__(self, device, generator=None):
+        self.device, self.generator = device, generator
+
+    def draw(self, shape, device=None):
+        return torch.randn(*shape, device=self.device, generator=self.generator)
+
+
+@register_module
+class ReGestureTransformer:
+    """Configuration holder mirroring raggesture.py:887-922 / diffusion_transformer.py:335-420
+    constructor keys; the packed device weights are built in load_state_dict()."""
+
+    def __init__(self, retrieval_cfg=None, scale_func_cfg=None, per_joint_scale=None, retrieval_train=False,
+                 use_retrieval_for_test=False, input_feats=None, max_seq_len=240, frame_chunk_size=16,
+                 latent_dim=512, time_embed_dim=2048, num_layers=8, sa_block_cfg=None, ca_block_cfg=None,
+                 vae_cfg=None, ffn_cfg=None, text_encoder=None, audio_encoder=None, speaker_embedding=None,
+                 use_cache_for_text=False, init_cfg=None, body_part_cat_axis="time", database=None, **_unused):
+        assert not retrieval_train
+        assert body_part_cat_axis == "time", "Only time axis is supported for body part categorization"
+        for enc in (text_encoder, audio_encoder):
+            assert enc is None or (enc.get("pretrained_model") is None and enc.get("num_layers", 0) == 0
+                                   and not enc.get("use_text_proj", False)), \
+                "only the shipped configuration (pre-extracted features, pre_proj only) is on the hot path"
+        self.cfg = dict(
+            latent_dim=latent_dim, time_embed_dim=time_embed_dim, num_layers=num_layers,
+            num_heads=(sa_block_cfg or {}).get("num_heads", 16), ff_size=(ffn_cfg or {}).get("ffn_dim", 1024),
+            max_seq_len=max_seq_len, frame_chunk_size=frame_chunk_size,
+            text_latent_dim=(text_encoder or {}).get("latent_dim", 768),
+            num_speakers=(speaker_embedding or {}).get("num_speakers", 25),
+            scale_func_cfg=scale_func_cfg, per_joint_scale=per_joint_scale,
+        )
+        assert scale_func_cfg is not None, "the shipped config always runs the CFG mix (scale_func_cfg)"
+        self.vae_cfgs = self._read_vae_cfgs(vae_cfg)
+        self.retrieval_cfg, self.use_retrieval_for_test = retrieval_cfg, use_retrieval_for_test
+        self.database = None
+        if retrieval_cfg is not None and use_retrieval_for_test:
+            from . import retrieval
+            self.database = retrieval.RetrievalDatabase(**retrieval_cfg, dataset=database)
+        self.weights = self.gesture_rep_encoder = None
+
+    @staticmethod
+    def _read_vae_cfgs(vae_cfg):
+        """vae_cfg holds YAML paths (diffusion_transformer.py:151-154) or, for synthetic models,
+        the dicts themselves under the same keys."""
+        out = {}
+        for part in vae_mod.PARTS:
+            v = vae_cfg["%s_cfg" % part]
+            if isinstance(v, str):
+                with open(v, "r", encoding="utf-8") as f:
+                    v = yaml.safe_load(f)
+            out[part] = dict(v)
+            out[part].setdefault("frame_chunk_size", vae_cfg.get("frame_chunk_size", 15))
+        return out
+
+    def post_process(self, motion):
+        return motion
+
+
+@register_module
+class MotionDiffusion:
+    def __init__(self, model=None, loss_recon=None, loss_gen=None, loss_contact=None, loss_laplace=None,
+                 diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
+                 genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
+                 body_part_lossweights=None, device="cuda", precision="bf16", **kwargs):
+        # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
+        self.model = build_submodule(model, **kwargs)
+        dt = dict(diffusion_test)
+        self.schedule = sched_mod.Schedule(beta_scheduler=dt["beta_scheduler"], diffusion_steps=dt["diffusion_steps"],
+                                           respace=dt.get("respace"))
+        assert dt.get("model_mean_type", "start_x") == "start_x" and dt.get("classifier_free_guidance_scale", 0) == 0
+        self.inference_type = inference_type
+        assert inference_type == "ddim", "only the DDIM inference path is implemented (config: inference_type='ddim')"
+        self.device, self.precision = torch.device(device), precision
+        self.training = False
+        self._sessions = {}
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, state, strict=True):
+        """Accepts the reference's key names: `model.` prefixed (mmcv checkpoint of MotionDiffusion,
+        tools/visualize.py:141) or un-prefixed ReGestureTransformer keys."""
+        if "state_dict" in state and not torch.is_tensor(state["state_dict"]):
+            state = state["state_dict"]
+        if any(k.startswith("model.") for k in state):
+            state = {k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}
+        m = self.model
+        m.weights = denoiser.DenoiserWeights(state, m.cfg, self.schedule, self.device, precision=self.precision)
+        m.gesture_rep_encoder = vae_mod.GestureRepEncoder(state, m.vae_cfgs, self.device, self.precision)
+        self._sessions = {}
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self, *a):
+        return self
+
+    def _session(self, B, role="sample"):
+        key = (B, role)
+        if key not in self._sessions:
+            self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B)
+        return self._sessions[key]
+
+    def __call__(self, **kwargs):
+        return self.forward(**kwargs)
+
+    # ------------------------------------------------------------------ forward (eval)
+    def forward(self, **kwargs):
+        if self.model.weights is None:
+            raise capi.RgError("weights not loaded: call load_state_dict() first")
+        dev = self.device
+        W, S = self.model.weights, self.schedule.num_timesteps
+        h = W.h
+        inference_kwargs = kwargs.get("inference_kwargs", {})
+        use_outpaint = inference_kwargs.pop("outpaint", False)
+        use_inversion = inference_kwargs.pop("use_inversion", False)
+        inversion_start_time = inference_kwargs.pop("inversion_start_time", -1)
+        inference_kwargs.pop("visualize_inversion", False)  # diagnostic decode of all levels: out of scope
+        use_insertion_guidance = inference_kwargs.pop("insertion_guidance", False)
+        guidance_iters = inference_kwargs.pop("guidance_iters", [10] * 50)
+        guidance_lr = inference_kwargs.pop("guidance_lr", 0.1)
+        use_prev_latent = inference_kwargs.pop("use_prev_latent", False)
+        prev_latent = inference_kwargs.pop("prev_latent", None)
+        tape = inference_kwargs.pop("noise_tape", None) or _TorchNoise(dev)
+        if use_prev_latent:
+            assert not use_outpaint
+        if use_outpaint:
+            assert not use_inversion
+            assert not use_insertion_guidance
+        if use_insertion_guidance:
+            assert not use_outpaint
+            assert use_inversion
+
+        gre = self.model.gesture_rep_encoder
+        B = kwargs["motion_upper"].shape[0]
+        D = gre.vae_latent_dim
+        eps_list = [tape.draw((B * 10, 1, D)) for _ in range(4)]
+        motion, motion_mask = gre.encode(kwargs["motion_upper"], kwargs["motion_lower"], kwargs["motion_face"],
+                                         kwargs["motion_hands"], kwargs["trans"], kwargs["facial"], kwargs["contact"],
+                                         kwargs["motion_mask"].float(), eps_list)
+        T = motion.shape[1]
+        n_lat = (T - 3) // 4
+        up_i, ha_i, fa_i, lt_i = (list(range(0, n_lat)), list(range(n_lat + 1, 2 * n_lat + 1)),
+                                  list(range(2 * n_lat + 2, 3 * n_lat + 2)), list(range(3 * n_lat + 3, T)))
+        # cross-attention query masks: the reference's index arithmetic gives rows 10, 20, 30
+        # ([(T-3)//4, 2*(T-3)//4, 3*(T-3)//4], diffusion_architecture.py:155), not the separators.
+        qmask = torch.ones_like(motion_mask)
+        qmask[:, [(T - 3) // 4, 2 * (T - 3) // 4, 3 * (T - 3) // 4]] = 0
+        query_masks = {c: qmask for c in denoiser.CONDS}
+
+        kwargs.update({"motion_mask": motion_mask, "text": kwargs["word"], "raw_text": kwargs.get("raw_word"),
+                       "text_times": kwargs.get("text_segments")})
+        sess = self._session(B)
+        sess.set_conditions(kwargs["word"], kwargs["audio"], kwargs["speaker_ids"], motion_mask, query_masks)
+        retrieval_dict = kwargs.get("re_dict")
+        if retrieval_dict is None and self.model.database is not None:
+            retrieval_dict = self.model.database(kwargs, kwargs.get("motion_length"), dev, idx=kwargs.get("sample_name"),
+                                                 retrieval_method=kwargs.get("retrieval_method", "discourse"),
+                                                 gesture_rep_encoder=gre, noise=tape)
+        results = kwargs
+        results["retrieval_dict"] = copy.copy(retrieval_dict)
+
+        if use_outpaint:
+            rml = retrieval_dict["raw_motion_latents"]
+            assert rml.shape[1] == 1
+            retrieval_motion_latents = rml.squeeze(1).to(dev).float().contiguous()
+        if use_prev_latent and prev_latent is not None:
+            prev_latent = prev_latent.to(dev).float()
+            masked = torch.zeros_like(prev_latent)
+            for idx in (up_i, ha_i, fa_i, lt_i):
+                h.call("copy_rows", prev_latent, masked, B, 1, D, T, idx[-1], T, idx[0])
+            prev_latent = masked
+
+        start_noise, invl = None, None
+        if use_inversion:
+            start_noise = tape.draw((B, T, D)).to(dev).contiguous()
+            ex = []  # (clip index, q_idx)
+            for b in range(B):
+                for q_idx in retrieval_dict["retr_uncropped_latents"][b].keys():
+                    ex.append((b, q_idx))
+            if use_insertion_guidance:
+                invl = torch.zeros(S, B, T, D, device=dev)
+            if ex:
+                E = len(ex)
+                lat = lambda b, q: retrieval_dict["retr_uncropped_latents"][b][q]
+                cat = lambda key: torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0)
+                esess = self._session(E, "invert")
+                eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
+                esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
+                                     cat("retr_motion_mask").float(), eqm)
+                x_e = cat("retr_motion_latent").float().contiguous()
+                inv = torch.empty(S, E, T, D, device=dev)
+                sampler.ddim_reverse_sample_loop(esess, x_e, inv)
+                for e, (b, q_idx) in enumerate(ex):
+                    r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
+                    q0, q1 = retrieval_dict["query_startends"][b][q_idx]
+                    assert r1 - r0 == q1 - q0
+                    lvl = inversion_start_time % S
+                    h.call("splice_rows", inv[lvl], start_noise, T, D, n_lat, e, b, r0, r1, q0, q1)
+                    if use_insertion_guidance:
+                        h.call("splice_rows_rep", inv, invl, T, D, n_lat, e, b, r0, r1, q0, q1, S, E, B)
+            if use_insertion_guidance and use_prev_latent and prev_latent is not None:
+                for idx in (up_i, ha_i, fa_i, lt_i):
+                    invl[:, :, idx[0], :] = 0
+
+        if use_inversion:
+            x = start_noise
+        else:
+            x = tape.draw((B, T, D)).to(dev).contiguous()
+        in_seq = None
+        if use_prev_latent and prev_latent is not None:
+            in_seq = prev_latent
+        elif use_outpaint:
+            in_seq = retrieval_motion_latents
+        need_noise = in_seq is not None or use_insertion_guidance
+        inseq_noise = None
+        if need_noise:
+            # the reference draws randn_like(in_seq) then randn_like(x) on every step (the latter is
+            # multiplied by sigma = 0); keep the tape aligned
+            inseq_noise = torch.empty(S, B, T, D, device=dev)
+            first = S - 1
+            cur_has = in_seq is not None
+            for i in range(S - 1, -1, -1):
+                has = cur_has if i == first or not use_insertion_guidance else True
+                if has:
+                    inseq_noise[i].copy_(tape.draw((B, T, D)).to(dev))
+                tape.draw((B, T, D)) if not isinstance(tape, _TorchNoise) else None
+        elif not isinstance(tape, _TorchNoise):
+            for _ in range(S):
+                tape.draw((B, T, D))
+        if use_insertion_guidance:
+            sampler.ddim_guided_sample_loop(sess, x, invl, guidance_iters, guidance_lr, inseq_noise, in_seq=in_seq)
+        else:
+            sampler.ddim_sample_loop(sess, x, in_seq=in_seq, inseq_noise=inseq_noise)
+        output = self.model.post_process(x)
+        results["prev_latentout"] = output
+        up, lo, fa, ha, tr, ex_, co = gre.decode(output)
+        results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
+        results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
+        results["pred_contact"] = co
+        return results

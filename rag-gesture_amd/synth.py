@@ -242,3 +242,40 @@ def synth_batch(batch, seed=1234, device="cpu"):
         sample_idx=list(range(B)), sample_name=["synthetic_%04d" % i for i in range(B)],
     )
     return d
+
+
+def reference_style_model_cfg(cfg=None, vae_cfgs=None, inference_type="ddim"):
+    """`cfg.model` in the layout of configs/raggesture_beatx/basegesture_len150_beat.py:45-160, with the
+    VAE YAML paths replaced by the hyper-parameter dicts themselves and `per_joint_scale` supplied
+    (SURVEY F6)."""
+    cfg = cfg or default_model_cfg()
+    vae_cfgs = vae_cfgs or synth_vae_cfgs()
+    d, te, H = cfg["latent_dim"], cfg["time_embed_dim"], cfg["num_heads"]
+    return dict(
+        type="MotionDiffusion",
+        model=dict(
+            type="ReGestureTransformer", input_feats=189, max_seq_len=cfg["max_seq_len"],
+            frame_chunk_size=cfg["frame_chunk_size"], latent_dim=d, time_embed_dim=te,
+            num_layers=cfg["num_layers"], body_part_cat_axis="time",
+            sa_block_cfg=dict(type="EfficientSelfAttention", latent_dim=d, num_heads=H, dropout=0, time_embed_dim=te),
+            ca_block_cfg=dict(type="EfficientCrossAttention", latent_dim=d, text_latent_dim=d, num_heads=H,
+                              dropout=0, time_embed_dim=te),
+            ffn_cfg=dict(latent_dim=d, ffn_dim=cfg["ff_size"], dropout=0, time_embed_dim=te),
+            vae_cfg=dict(upper_cfg=vae_cfgs["upper"], lowertrans_cfg=vae_cfgs["lowertrans"], face_cfg=vae_cfgs["face"],
+                         hands_cfg=vae_cfgs["hands"], latent_dim=d, frame_chunk_size=cfg["frame_chunk_size"]),
+            text_encoder=dict(pretrained_model=None, latent_dim=cfg["text_latent_dim"], num_layers=0,
+                              ff_size=2048, dropout=0, use_text_proj=False),
+            audio_encoder=dict(pretrained_model=None, latent_dim=cfg["text_latent_dim"], num_layers=0, dropout=0.1),
+            speaker_embedding=dict(num_speakers=cfg["num_speakers"]),
+            retrieval_train=False, retrieval_cfg=None,
+            scale_func_cfg=dict(cfg["scale_func_cfg"]), per_joint_scale=dict(cfg["per_joint_scale"]),
+        ),
+        loss_recon=dict(type="MSELoss", loss_weight=1, reduction="none"),
+        body_part_lossweights=dict(upper=1.0, hands=1.0, face=1.0, lowertransl=1.0),
+        diffusion_train=dict(beta_scheduler="scaled_linear", diffusion_steps=1000, model_mean_type="start_x",
+                             model_var_type="fixed_large"),
+        diffusion_test=dict(beta_scheduler="scaled_linear", diffusion_steps=1000, model_mean_type="start_x",
+                            model_var_type="fixed_large", respace="15,15,8,6,6", num_inference_timesteps=50,
+                            classifier_free_guidance_scale=0),
+        inference_type=inference_type,
+    )

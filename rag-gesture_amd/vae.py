@@ -1,0 +1,315 @@
+"""Host side of the four body-part TransformerVAEs and the GestureRepEncoder wrapper.
+
+Mirrors (same names, argument meaning):
+  mogen/models/transformers/gesture_vae.py:25-239   TransformerVAE (encode / reparameterize / decode)
+  mogen/models/utils/detr_utils.py:101-210, 335-480 Skip transformer stacks and layers
+  mogen/models/transformers/diffusion_transformer.py:131-330 GestureRepEncoder (6D packing, 4 parts,
+      separator tokens, output splitting)
+All arithmetic runs in the HIP extension: linears through rg_gemm (bf16 MFMA, or bf16x3 in
+precision="fp32"), attention/LayerNorm/rotations through the rg_vae kernels.  Token rows are
+batch-major [B*S, D] (the reference is sequence-major; attention is per sequence either way).
+The VAE hyper-parameters come from the YAML shipped with each checkpoint, so
+nothing here is specialised to one width/depth/arch.
+"""
+import torch
+
+from . import capi, gemm as G
+
+PARTS = ("upper", "hands", "face", "lowertrans")  # reference encode / RNG order
+ACT = {"relu": 2, "gelu": 1}
+
+
+def _num_blocks(n):
+    if n % 2 == 0:
+        n += 1
+    return (n - 1) // 2
+
+
+class _Lin:
+    def __init__(self, sd, name, dev, split, rows=None):
+        w = sd[name + ".weight"] if rows is None else sd[name + "_weight"][rows]
+        b = sd[name + ".bias"] if rows is None else sd[name + "_bias"][rows]
+        self.n, self.k = w.shape
+        self.w = G.pack_weight(w.detach().float(), dev, split=split)
+        self.b = b.detach().float().to(dev).contiguous()
+
+
+class _Block:
+    def __init__(self, sd, name, dev, split, cross):
+        D = sd[name + ".norm1.weight"].shape[0]
+        f = lambda k: sd[name + k].detach().float().to(dev).contiguous()
+        self.qkv = _Lin(sd, name + ".self_attn.in_proj", dev, split, rows=slice(0, 3 * D))
+        self.qk = _Lin(sd, name + ".self_attn.in_proj", dev, split, rows=slice(0, 2 * D))
+        self.v = _Lin(sd, name + ".self_attn.in_proj", dev, split, rows=slice(2 * D, 3 * D))
+        self.out = _Lin(sd, name + ".self_attn.out_proj", dev, split)
+        self.l1, self.l2 = _Lin(sd, name + ".linear1", dev, split), _Lin(sd, name + ".linear2", dev, split)
+        self.n1 = (f(".norm1.weight"), f(".norm1.bias"))
+        self.n2 = (f(".norm2.weight"), f(".norm2.bias"))
+        if cross:
+            self.cq = _Lin(sd, name + ".multihead_attn.in_proj", dev, split, rows=slice(0, D))
+            self.ckv = _Lin(sd, name + ".multihead_attn.in_proj", dev, split, rows=slice(D, 3 * D))
+            self.cout = _Lin(sd, name + ".multihead_attn.out_proj", dev, split)
+            self.n3 = (f(".norm3.weight"), f(".norm3.bias"))
+
+
+class _Stack:
+    def __init__(self, sd, name, dev, split, num_layers, cross):
+        nb = _num_blocks(num_layers)
+        self.inp = [_Block(sd, "%s.input_blocks.%d" % (name, i), dev, split, cross) for i in range(nb)]
+        self.mid = _Block(sd, name + ".middle_block", dev, split, cross)
+        self.outb = [_Block(sd, "%s.output_blocks.%d" % (name, i), dev, split, cross) for i in range(nb)]
+        self.lin = [_Lin(sd, "%s.linear_blocks.%d" % (name, i), dev, split) for i in range(nb)]
+        self.norm = (sd[name + ".norm.weight"].float().to(dev).contiguous(), sd[name + ".norm.bias"].float().to(dev).contiguous())
+
+
+class TransformerVAE:
+    """One body part.  `vcfg` = the YAML dict (latent_dim, num_heads, ff_size, num_layers,
+    decoder_arch, position_embedding, nfeats, num_frames, frame_chunk_size,
+    transformer_activation, transformer_normalize_before, vae_dist)."""
+
+    def __init__(self, state, vcfg, device="cuda", precision="bf16"):
+        assert vcfg.get("vae_dist", "normal") == "normal", "only the Normal posterior is supported"
+        self.cfg = vcfg
+        self.dev = torch.device(device)
+        self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        split = precision == "fp32"
+        D = self.D = vcfg["latent_dim"]
+        self.nfeats, self.chunk, self.frames = vcfg["nfeats"], vcfg["frame_chunk_size"], vcfg["num_frames"]
+        self.heads, self.pre = vcfg["num_heads"], bool(vcfg["transformer_normalize_before"])
+        self.act = ACT[vcfg["transformer_activation"]]
+        self.arch = vcfg["decoder_arch"]
+        dev = self.dev
+        f = lambda k: state[k].detach().float().to(dev).contiguous()
+        self.embed, self.final = _Lin(state, "skel_embedding", dev, split), _Lin(state, "final_layer", dev, split)
+        self.pe_enc, self.pe_dec, self.pe_mem = (f(n + ".pe")[:, 0].contiguous() for n in
+                                                 ("query_pos_encoder", "query_pos_decoder", "mem_pos_decoder"))
+        self.tok_pe = (f("global_motion_token") + self.pe_enc[:2]).contiguous()  # host-side constant fold
+        self.encoder = _Stack(state, "encoder", dev, split, vcfg["num_layers"], cross=False)
+        if self.arch == "all_encoder":
+            self.decoder = _Stack(state, "decoder", dev, split, vcfg["num_layers"], cross=False)
+            self.dec_heads = self.heads * 8
+        elif self.arch == "encoder_decoder":
+            self.decoder = _Stack(state, "decoder", dev, split, (vcfg["num_layers"] - 1) * 4 + 1, cross=True)
+            self.dec_heads = self.heads * 4
+        else:
+            raise ValueError("Not support architecture!")
+
+    # ---------------------------------------------------------------- building blocks
+    def _lin(self, lin, x, M, out=None, residual=None, act=0, tbias=None, tb_period=0, segs=None):
+        out = torch.empty(M, lin.n, device=self.dev) if out is None else out
+        segs = segs or [G.Seg(x)]
+        seg_len = None if len(segs) == 1 else segs[0].src.shape[-1]
+        G.gemm(self.h, M=M, N=lin.n, K=lin.k, W=lin.w, out=out, segs=segs, seg_len=seg_len, bias=lin.b,
+               residual=residual, act=act, tbias=tbias, tb_period=tb_period)
+        return out
+
+    def _ln(self, x, gb, M):
+        out = torch.empty_like(x)
+        self.h.call("layernorm", x, gb[0], gb[1], out, M, self.D)
+        return out
+
+    def _self_attn(self, blk, x, B, S, heads, pos, M):
+        D = self.D
+        if pos is None:
+            qkv = self._lin(blk.qkv, x, M)
+            q, k, v, ld = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D
+            ldv = 3 * D
+        else:
+            xp = torch.empty_like(x)
+            self.h.call("add_rows", x, pos, xp, capi.I64(x.numel()), capi.I64(x.numel()))
+            qk = self._lin(blk.qk, xp, M)
+            v = self._lin(blk.v, x, M)
+            q, k, ld, ldv = qk, qk[:, D:], 2 * D, D
+        o = torch.empty(M, D, device=self.dev)
+        self._mha(q, ld, k, ld, v, ldv, o, B, heads, S, S)
+        return o
+
+    def _mha(self, q, ldq, k, ldk, v, ldv, o, B, heads, Sq, Sk):
+        import ctypes
+        hd = self.D // heads
+        s = torch.cuda.current_stream().cuda_stream
+        vp = ctypes.c_void_p
+        rc = self.h.lib.rg_mha(self.h._h, vp(q.data_ptr()), ldq, vp(k.data_ptr()), ldk, vp(v.data_ptr()), ldv,
+                               vp(o.data_ptr()), self.D, B, heads, Sq, Sk, hd, vp(s))
+        if rc != 0:
+            raise capi.RgError("rg_mha failed: %s" % self.h.lib.rg_last_error(self.h._h).decode())
+
+    def _enc_layer(self, blk, x, B, S, heads, pos=None):
+        """detr_utils.py:335-393 TransformerEncoderLayer (forward_post / forward_pre)."""
+        M = B * S
+        if not self.pre:
+            a = self._self_attn(blk, x, B, S, heads, pos, M)
+            x = self._ln(self._lin(blk.out, a, M, residual=x), blk.n1, M)
+            hmid = self._lin(blk.l1, x, M, act=self.act)
+            return self._ln(self._lin(blk.l2, hmid, M, residual=x), blk.n2, M)
+        x2 = self._ln(x, blk.n1, M)
+        a = self._self_attn(blk, x2, B, S, heads, pos, M)
+        x = self._lin(blk.out, a, M, residual=x)
+        hmid = self._lin(blk.l1, self._ln(x, blk.n2, M), M, act=self.act)
+        return self._lin(blk.l2, hmid, M, residual=x)
+
+    def _cross_attn(self, blk, t, mem, B, S, Sk, heads):
+        D = self.D
+        q = self._lin(blk.cq, t, B * S)
+        kv = self._lin(blk.ckv, mem, B * Sk)
+        o = torch.empty(B * S, D, device=self.dev)
+        self._mha(q, D, kv, 2 * D, kv[:, D:], 2 * D, o, B, heads, S, Sk)
+        return o
+
+    def _dec_layer(self, blk, t, mem, B, S, Sk, heads):
+        """detr_utils.py:396-480 TransformerDecoderLayer (pos = query_pos = None)."""
+        M = B * S
+        if not self.pre:
+            a = self._self_attn(blk, t, B, S, heads, None, M)
+            t = self._ln(self._lin(blk.out, a, M, residual=t), blk.n1, M)
+            c = self._cross_attn(blk, t, mem, B, S, Sk, heads)
+            t = self._ln(self._lin(blk.cout, c, M, residual=t), blk.n2, M)
+            hmid = self._lin(blk.l1, t, M, act=self.act)
+            return self._ln(self._lin(blk.l2, hmid, M, residual=t), blk.n3, M)
+        t2 = self._ln(t, blk.n1, M)
+        t = self._lin(blk.out, self._self_attn(blk, t2, B, S, heads, None, M), M, residual=t)
+        t2 = self._ln(t, blk.n2, M)
+        t = self._lin(blk.cout, self._cross_attn(blk, t2, mem, B, S, Sk, heads), M, residual=t)
+        hmid = self._lin(blk.l1, self._ln(t, blk.n3, M), M, act=self.act)
+        return self._lin(blk.l2, hmid, M, residual=t)
+
+    def _skip_stack(self, st, x, layer_fn):
+        """detr_utils.py:101-210 SkipTransformerEncoder/Decoder: U-Net style skips, concat + Linear(2D->D)."""
+        M = x.shape[0]
+        xs = []
+        for blk in st.inp:
+            x = layer_fn(blk, x)
+            xs.append(x)
+        x = layer_fn(st.mid, x)
+        for blk, lin in zip(st.outb, st.lin):
+            x = self._lin(lin, None, M, segs=[G.Seg(x), G.Seg(xs.pop())])
+            x = layer_fn(blk, x)
+        return self._ln(x, st.norm, M)
+
+    # ---------------------------------------------------------------- public API
+    def encode_to_latent(self, features, eps, latent, row_off):
+        """gesture_vae.py:111-193 `encode_to_dist` with the rsample noise made explicit.
+        features [B, nframes, nfeats] fp32 (device), eps [B*n_chunks, 1, D]; writes
+        z into latent[:, row_off:row_off+n_chunks, :] ([B,T,D])."""
+        B, nframes, nf = features.shape
+        n_chunks, S = nframes // self.chunk, self.chunk + 2
+        Bn, D = B * n_chunks, self.D
+        x = self._lin(self.embed, features.reshape(B * nframes, nf), B * nframes, tbias=self.pe_enc[2:S].contiguous(),
+                      tb_period=self.chunk)
+        xseq = torch.empty(Bn * S, D, device=self.dev)
+        self.h.call("copy_rows", self.tok_pe, xseq, Bn, 2, D, 0, 0, S, 0)
+        self.h.call("copy_rows", x, xseq, Bn, self.chunk, D, self.chunk, 0, S, 2)
+        enc = self._skip_stack(self.encoder, xseq, lambda blk, t: self._enc_layer(blk, t, Bn, S, self.heads))
+        self.h.call("vae_reparam", enc, S, eps.contiguous(), latent, B, n_chunks, D, latent.shape[1], row_off)
+
+    def decode_latent(self, latent, row_off, n_chunks):
+        """gesture_vae.py:195-239 `decode` for z = latent[:, row_off:row_off+n_chunks] -> [B*num_frames, nfeats]."""
+        B, T, D = latent.shape
+        F_ = self.frames
+        if self.arch == "all_encoder":
+            S = n_chunks + F_
+            xseq = torch.zeros(B * S, D, device=self.dev)
+            self.h.call("copy_rows", latent, xseq, B, n_chunks, D, T, row_off, S, 0)
+            pos = torch.empty_like(xseq)
+            self.h.call("add_rows", xseq, self.pe_dec[:S].contiguous(), pos, capi.I64(xseq.numel()), capi.I64(S * D))
+            out = self._skip_stack(self.decoder, xseq,
+                                   lambda blk, t: self._enc_layer(blk, t, B, S, self.dec_heads, pos=pos))
+            fr = torch.empty(B * F_, D, device=self.dev)
+            self.h.call("copy_rows", out, fr, B, F_, D, S, n_chunks, F_, 0)
+        else:
+            q = torch.empty(B * F_, D, device=self.dev)
+            self.h.call("copy_rows", self.pe_dec[:F_].contiguous(), q, B, F_, D, 0, 0, F_, 0)
+            z = torch.empty(B * n_chunks, D, device=self.dev)
+            self.h.call("copy_rows", latent, z, B, n_chunks, D, T, row_off, n_chunks, 0)
+            mem = torch.empty_like(z)
+            self.h.call("add_rows", z, self.pe_mem[:n_chunks].contiguous(), mem, capi.I64(z.numel()), capi.I64(n_chunks * D))
+            fr = self._skip_stack(self.decoder, q,
+                                  lambda blk, t: self._dec_layer(blk, t, mem, B, F_, n_chunks, self.dec_heads))
+        return self._lin(self.final, fr, B * F_)
+
+
+class GestureRepEncoder:
+    """diffusion_transformer.py:131-330: four VAEs, 6D rotation packing, separator tokens."""
+
+    def __init__(self, state, vae_cfgs, device="cuda", precision="bf16", prefix="gesture_rep_encoder."):
+        self.dev = torch.device(device)
+        self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        self.vaes = {}
+        for part in PARTS:
+            p = "%s%s_vae." % (prefix, part)
+            sd = {k[len(p):]: v for k, v in state.items() if k.startswith(p)}
+            self.vaes[part] = TransformerVAE(sd, vae_cfgs[part], device, precision)
+        self.vae_latent_dim = vae_cfgs["upper"]["latent_dim"]
+        self.frame_chunk_size = vae_cfgs["upper"]["frame_chunk_size"]
+        self.uj = self.lj = self.fj = self.hj = self.tj = None
+
+    def _aa6d(self, aa, out, col_off, joints):
+        B, n, c = aa.shape
+        self.h.call("aa_to_6d", aa.contiguous(), c, out, out.shape[-1], col_off, B * n, joints)
+
+    def encode(self, motion_upper, motion_lower, motion_face, motion_hands, motion_transl, motion_facial,
+               motion_contact, motion_mask, eps_list):
+        """Same argument order as the reference + eps_list (4 tensors [B*10,1,D], order upper, hands,
+        face, lowertrans = the reference's rsample order).  Returns (latent [B,43,D], mask [B,43]).
+        Like the reference it re-zeroes x/z of `motion_transl` IN PLACE (:231-232)."""
+        dev, f = self.dev, lambda t: t.to(self.dev).float().contiguous()
+        up, lo, fa, ha = f(motion_upper), f(motion_lower), f(motion_face), f(motion_hands)
+        B, n, _ = up.shape
+        self.uj, self.lj, self.fj, self.hj = up.shape[-1] // 3, lo.shape[-1] // 3, fa.shape[-1] // 3, ha.shape[-1] // 3
+        self.tj = motion_transl.shape[-1]
+        fac, con = f(motion_facial), f(motion_contact)
+        rows = B * n
+        in_up = torch.empty(B, n, self.uj * 6, device=dev)
+        self._aa6d(up, in_up, 0, self.uj)
+        in_ha = torch.empty(B, n, self.hj * 6, device=dev)
+        self._aa6d(ha, in_ha, 0, self.hj)
+        in_fa = torch.empty(B, n, self.fj * 6 + fac.shape[-1], device=dev)
+        self._aa6d(fa, in_fa, 0, self.fj)
+        self.h.call("copy_cols", fac, fac.shape[-1], 0, in_fa, in_fa.shape[-1], self.fj * 6, rows, fac.shape[-1], 0, 0)
+        wlt = self.lj * 6 + self.tj + con.shape[-1]
+        in_lt = torch.empty(B, n, wlt, device=dev)
+        self._aa6d(lo, in_lt, 0, self.lj)
+        tr = f(motion_transl)
+        self.h.call("copy_cols", tr, self.tj, 0, in_lt, wlt, self.lj * 6, rows, self.tj, n, 0b101)
+        self.h.call("copy_cols", con, con.shape[-1], 0, in_lt, wlt, self.lj * 6 + self.tj, rows, con.shape[-1], 0, 0)
+        # replicate the reference's in-place mutation of the caller's tensor
+        tr_rel = torch.empty_like(tr)
+        self.h.call("copy_cols", in_lt, wlt, self.lj * 6, tr_rel, self.tj, 0, rows, self.tj, 0, 0)
+        motion_transl.copy_(tr_rel.to(motion_transl.device))
+        n_lat = n // self.frame_chunk_size
+        T, D = 4 * n_lat + 3, self.vae_latent_dim
+        latent = torch.zeros(B, T, D, device=dev)  # separator rows stay zero
+        for i, (part, feats) in enumerate((("upper", in_up), ("hands", in_ha), ("face", in_fa), ("lowertrans", in_lt))):
+            self.vaes[part].encode_to_latent(feats, eps_list[i].to(dev).float(), latent, i * (n_lat + 1))
+        mm = motion_mask.to(dev).float()[:, ::self.frame_chunk_size]
+        sep = torch.zeros_like(mm[:, :1])
+        return latent, torch.cat([mm, sep, mm, sep, mm, sep, mm], dim=1)
+
+    def decode(self, z_output):
+        """Returns (upper, lower, facepose, hands, transl, exps, contact) like the reference (:270-330)."""
+        B, T, D = z_output.shape
+        n_lat = (T - 3) // 4
+        z = z_output.contiguous()
+        dec = {part: self.vaes[part].decode_latent(z, i * (n_lat + 1), n_lat) for i, part in enumerate(PARTS)}
+        F_ = self.vaes["upper"].frames
+        rows = B * F_
+
+        def aa(src, col_off, joints):
+            out = torch.empty(B, F_, joints * 3, device=self.dev)
+            self.h.call("6d_to_aa", src, src.shape[-1], col_off, out, joints * 3, rows, joints)
+            return out
+
+        def cols(src, c0, nc):
+            out = torch.empty(B, F_, nc, device=self.dev)
+            self.h.call("copy_cols", src, src.shape[-1], c0, out, nc, 0, rows, nc, 0, 0)
+            return out
+
+        upper = aa(dec["upper"], 0, self.uj)
+        hands = aa(dec["hands"], 0, self.hj)
+        face = aa(dec["face"], 0, self.fj)
+        exps = cols(dec["face"], self.fj * 6, dec["face"].shape[-1] - self.fj * 6)
+        lt = dec["lowertrans"]
+        lower = aa(lt, 0, self.lj)
+        transl = cols(lt, self.lj * 6, self.tj)
+        contact = cols(lt, self.lj * 6 + self.tj, lt.shape[-1] - self.lj * 6 - self.tj)
+        return upper, lower, face, hands, transl, exps, contact
