@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the RAG-Gesture inference hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload guided|base] [--batch B]
+
+One "step" = one pass of the hot path over one batch of synthetic clips through the drop-in
+`model(**data)`: 4x VAE encode -> conditioning precompute -> [batched DDIM inversion of the
+retrieved exemplars] -> 50-step DDIM with CFG [+ insertion guidance] -> 4x VAE decode
+(150 SMPL-X frames per clip at 15 fps).  Inputs are resident in HBM before
+the timed region.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), clips
+sharded across ranks (weak scaling, B clips per rank), results all-gathered once per step.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, HIP-event
+timed in a separate instrumented step of the same workload) and `cpu_baseline` (the CPU oracle
+= a faithful port of the reference, timed on a bounded sample, rank 0 at N = 1 only).
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GI = [0] * 25 + list(range(25))  # tools/visualize.py:74-95 "decreasing_till_25"
+MFMA_BF16_PEAK = 2.5e15          # dense bf16 FLOP/s, MI355X_MICROARCH.md
+
+
+def make_re_dict(B, seed, device):
+    """Synthetic retrieval result with the schema of RetrievalDatabase.forward (raggesture.py:860-884):
+    2 exemplars per clip at latent spans retr (2,5),(6,8) -> query (1,4),(7,9)."""
+    import numpy as np
+    g = np.random.Generator(np.random.PCG64(seed))
+    T, D = 43, 512
+
+    def n(shape):
+        return torch.from_numpy(g.standard_normal(size=shape).astype(np.float32)).to(device)
+
+    mask = torch.ones(1, T, device=device)
+    mask[:, [10, 21, 32]] = 0
+    rs, qs, ls = [], [], []
+    for _ in range(B):
+        r, q, l = {}, {}, {}
+        for qi, (r0, r1, q0, q1) in enumerate(((2, 5, 1, 4), (6, 8, 7, 9))):
+            r[qi], q[qi] = (r0, r1), (q0, q1)
+            lat = n((1, T, D))
+            lat[:, [10, 21, 32]] = 0
+            l[qi] = dict(retr_motion_latent=lat, retr_text=n((1, 150, 768)), retr_audio=n((1, 499, 768)),
+                         retr_spkid=torch.full((1, 150), int(g.integers(0, 25)), dtype=torch.int64, device=device),
+                         retr_motion_mask=mask.clone())
+        rs.append(r), qs.append(q), ls.append(l)
+    return dict(retr_startends=rs, query_startends=qs, retr_uncropped_latents=ls)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["guided", "base"], default="guided")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 16 guided, 32 base)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    rg = importlib.import_module("rag-gesture_amd")
+    B = args.batch or (16 if args.workload == "guided" else 32)
+    cfg = rg.synth.default_model_cfg(num_layers=8)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs), database=None, device=dev)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+
+    data = rg.synth.synth_batch(B, seed=1234 + rank, device=dev)
+    re_dict = make_re_dict(B, 77 + rank, dev) if args.workload == "guided" else None
+    trans0 = data["trans"].clone()
+
+    def one_step():
+        d = dict(data)
+        d["trans"] = trans0.clone()  # forward re-zeroes trans in place like the reference
+        ikw = {}
+        if args.workload == "guided":
+            d["re_dict"] = re_dict
+            ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+        out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
+        packed = torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
+                            out["pred_transl"], out["pred_exps"]], dim=-1)
+        if dist is not None:  # the only collective on the path: final result gather (RCCL over xGMI)
+            gathered = torch.empty(world * B, packed.shape[1], packed.shape[2], device=dev)
+            dist.all_gather_into_tensor(gathered, packed.contiguous())
+            return gathered
+        return packed
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * 150 * args.steps / dt
+
+    # ---- roofline of the dominant kernel (HIP events around every rg_gemm launch, one extra step)
+    roofline = None
+    if rank == 0:
+        h = rg.capi.get_handle(local_rank)
+        h.lib.rg_profile_begin(h._h)
+        one_step()
+        n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        h.lib.rg_profile_end(h._h, 0, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+        ach = fl.value / (ms.value * 1e-3) if ms.value > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel<false,false> (fp32-source A, bf16 MFMA)",
+                    "achieved": round(ach / 1e12, 3), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK, 5), "traffic": None, "launches": n.value,
+                    "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
+                    "flops_per_launch_avg": round(fl.value / max(1, n.value))}
+    if dist is not None:
+        dist.barrier()
+
+    # ---- CPU baseline: the oracle (faithful port of the reference) on a bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pipeline as opipe, diffusion as odf
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        cores = max(1, min(cores, 32))  # the port is bandwidth/latency bound well below that
+        torch.set_num_threads(cores)
+        P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+        cdata = rg.synth.synth_batch(1, seed=1234)
+        ckw, cre = {}, None
+        if args.workload == "guided":
+            cre = opipe.synthetic_re_dict(1, seed=77)
+            ckw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+        tc = time.perf_counter()
+        with torch.no_grad():
+            opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, rg.synth.NoiseTape(1),
+                                           re_dict=cre, **ckw)
+        tc = time.perf_counter() - tc
+        cpu = {"value": round(150.0 / tc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": "1 clip (150 frames), same workload (%s), torch fp32 on %d host threads, %.1f s"
+                         % (args.workload, cores, tc)}
+
+    if rank == 0:
+        line = {
+            "metric": "SMPL-X frames/sec, len150 DDIM-50 + insertion guidance; 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("guided discourse-style config: use_inversion + insertion_guidance "
+                                    "decreasing_till_25, 2 exemplars/clip, len150 DDIM-50"
+                                    if args.workload == "guided" else "base diffusion len150 DDIM-50 (no guidance)"),
+                       "clips_per_gpu": B, "global_batch": world * B, "frames_per_clip": 150, "ddim_steps": 50,
+                       "denoiser": "8 layers x 512, CFG x2 rows", "vae": "all_encoder, 8 layers, synthetic hparams",
+                       "weights": "random-init at config shapes", "parallelism": "clip-sharded x%d" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

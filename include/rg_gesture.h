@@ -144,6 +144,13 @@ typedef struct rg_gemm_desc {
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
 
+/* Measurement aid (bench.py roofline): between begin and end every rg_gemm launch is bracketed by
+ * HIP events on its stream; end synchronises and returns launch count, summed kernel time and summed
+ * algorithmic FLOPs (2*M*N*K) for one kernel variant (0: fp32-source A, 1: bf16 A, 2: bf16x3). */
+int rg_profile_begin(rg_handle* h);
+int rg_profile_end(rg_handle* h, int variant, int64_t* launches_host, double* total_ms_host,
+                   double* total_flops_host);
+
 /* out[i,:] = table[idx[i],:]  (nn.Embedding lookup of speaker ids, diffusion_transformer.py:544-548).
  * idx is int64 on device; dim % 4 == 0. */
 int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* out, int n, int dim,

@@ -7,10 +7,21 @@
 
 #include "../../include/rg_gesture.h"
 
+#include <vector>
+
+struct rg_prof_rec {
+  hipEvent_t start, stop;
+  int variant;      // 0: fp32-A bf16 GEMM, 1: bf16-A GEMM, 2: bf16x3 GEMM
+  double flops;
+};
+
 struct rg_handle {
   int device = 0;
   int num_cus = 256;
   std::string err;
+  bool profiling = false;          // rg_profile_begin/end: HIP events around every rg_gemm launch
+  std::vector<rg_prof_rec> prof;
+  std::vector<hipEvent_t> ev_pool;
 };
 
 #define RG_REQUIRE(h, cond, msg)                                   \

@@ -396,6 +396,18 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + BN - 1) / BN;
   dim3 grid(mt * nt), block(NT);
   const size_t lds = 2 * 2 * TILE_BYTES;  // 32 KiB (>= 64*68*4 epilogue tile)
+  rg_prof_rec rec;
+  if (h->profiling) {
+    auto get_ev = [&]() {
+      hipEvent_t e;
+      if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); }
+      return e;
+    };
+    rec.start = get_ev(); rec.stop = get_ev();
+    rec.variant = d->W_lo ? 2 : (d->a_is_bf16 ? 1 : 0);
+    rec.flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
+    (void)hipEventRecord(rec.start, rg_stream(stream));
+  }
   if (d->W_lo) {
     RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
     hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 2 * lds, rg_stream(stream), *d);
@@ -405,5 +417,37 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
     hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, rg_stream(stream), *d);
   }
   RG_CHECK_LAUNCH(h);
+  if (h->profiling) {
+    (void)hipEventRecord(rec.stop, rg_stream(stream));
+    h->prof.push_back(rec);
+  }
+  return RG_OK;
+}
+
+// HIP-event instrumentation of the GEMM launches between begin and end (bench.py's roofline
+// figure).  Not capturable: use on eager launches only.
+extern "C" int rg_profile_begin(rg_handle* h) {
+  if (!h) return RG_ERR_INVALID;
+  h->profiling = true;
+  return RG_OK;
+}
+
+extern "C" int rg_profile_end(rg_handle* h, int variant, int64_t* launches, double* total_ms, double* total_flops) {
+  if (!h) return RG_ERR_INVALID;
+  h->profiling = false;
+  if (hipDeviceSynchronize() != hipSuccess) return RG_ERR_HIP;
+  int64_t n = 0;
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : h->prof) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.start, r.stop);
+    if (r.variant == variant) { n++; ms += t; fl += r.flops; }
+    h->ev_pool.push_back(r.start);
+    h->ev_pool.push_back(r.stop);
+  }
+  h->prof.clear();
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
   return RG_OK;
 }
