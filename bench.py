@@ -133,8 +133,12 @@ def main():
     roofline = None
     if rank == 0:
         h = rg.capi.get_handle(local_rank)
+        model.use_graphs = False  # HIP events cannot be recorded inside graph replays: same launches, eager
+        one_step()
+        torch.cuda.synchronize()
         h.lib.rg_profile_begin(h._h)
         one_step()
+        model.use_graphs = True
         n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
         h.lib.rg_profile_end(h._h, 0, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
         ach = fl.value / (ms.value * 1e-3) if ms.value > 0 else 0.0

@@ -144,6 +144,10 @@ typedef struct rg_gemm_desc {
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
 
+/* Kernel selection hook for tests: force_generic = 1 routes every rg_gemm through the generic
+ * register-staged kernel; 0 (default) lets aligned shapes use the LDS-DMA kernel. */
+int rg_set_gemm_path(rg_handle* h, int force_generic);
+
 /* Measurement aid (bench.py roofline): between begin and end every rg_gemm launch is bracketed by
  * HIP events on its stream; end synchronises and returns launch count, summed kernel time and summed
  * algorithmic FLOPs (2*M*N*K) for one kernel variant (0: fp32-source A, 1: bf16 A, 2: bf16x3). */

@@ -27,11 +27,32 @@ __device__ __forceinline__ float wave_sum32(float v) {  // sum over the 32 lanes
   return v;
 }
 
-// Load a [T][32] fp32 tile (row stride ld floats) into LDS [T][32]; 8 rows per wave-instruction.
-__device__ __forceinline__ void load_tile32(float* dst, const float* src, int ld, int T, int lane) {
+// Load NT_ [T][32] fp32 tiles (row stride ld floats, column offsets coff[i]) into LDS [T][32] each;
+// 8 rows per wave-instruction.  All global loads are issued before the first LDS store so the
+// tile costs one memory latency, not one per row group.
+template <int NT_>
+__device__ __forceinline__ void load_tiles32(float* const (&dst)[NT_], const float* src, const int (&coff)[NT_],
+                                             int ld, int T, int lane) {
+  typedef __attribute__((ext_vector_type(4))) float v4;
+  constexpr int NIT = TMAX / 8;
   const int c4 = (lane & 7) * 4;
-  for (int r = lane >> 3; r < T; r += 8)
-    *reinterpret_cast<float4*>(dst + r * HD + c4) = *reinterpret_cast<const float4*>(src + (size_t)r * ld + c4);
+  v4 reg[NT_][NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = (lane >> 3) + 8 * it;
+    if (r < T) {
+#pragma unroll
+      for (int i = 0; i < NT_; ++i) reg[i][it] = *reinterpret_cast<const v4*>(src + (size_t)r * ld + coff[i] + c4);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int r = (lane >> 3) + 8 * it;
+    if (r < T) {
+#pragma unroll
+      for (int i = 0; i < NT_; ++i) *reinterpret_cast<v4*>(dst[i] + r * HD + c4) = reg[i][it];
+    }
+  }
 }
 
 // y[n][l] = sum_d q[n][d] * A[d][l] for the T tokens of one head; lane -> (l = lane&31, half).
@@ -77,16 +98,20 @@ __global__ void __launch_bounds__(256) sa_attention_kernel(const float* __restri
   const int h = hg * WAVES + wave;
   const int Tp = (T + 3) & ~3;
   float* sstat = sm;                       // [WAVES][Tp][2]
-  float* sq = sm + WAVES * 2 * Tp + wave * (3 * Tp * HD + HD * HD);
+  float* smask = sm + WAVES * 2 * Tp;      // [Tp]  (token mask staged once: no global loads in the loops)
+  float* sq = smask + Tp + wave * (3 * Tp * HD + HD * HD);
   float* sk = sq + Tp * HD;
   float* sv = sk + Tp * HD;
   float* sA = sv + Tp * HD;                // [32][32]
   const float* base = qkv + (size_t)b * T * ldqkv + h * HD;
-  load_tile32(sq, base, ldqkv, T, lane);
-  load_tile32(sk, base + D, ldqkv, T, lane);
-  load_tile32(sv, base + 2 * D, ldqkv, T, lane);
+  {
+    float* const dsts[3] = {sq, sk, sv};
+    const int coffs[3] = {0, D, 2 * D};
+    load_tiles32<3>(dsts, base, coffs, ldqkv, T, lane);
+  }
+  for (int n = threadIdx.x; n < T; n += 256) smask[n] = src_mask[(size_t)b * T + n];
   __syncthreads();
-  const float* mrow = src_mask + (size_t)b * T;
+  const float* mrow = smask;
 
   // softmax over tokens for column d = lane&31; the two half-waves split the tokens
   {
@@ -163,9 +188,14 @@ __global__ void __launch_bounds__(256) ca_attention_kernel(const float* __restri
   const int h = hg * WAVES + wave;
   const int Tp = (T + 3) & ~3;
   float* sstat = sm;  // [WAVES][Tp][2]
-  float* sq = sm + WAVES * 2 * Tp + wave * (Tp * HD);
+  float* smask = sm + WAVES * 2 * Tp;  // [Tp]
+  float* sq = smask + Tp + wave * (Tp * HD);
   const int ld = ncond * D;
-  load_tile32(sq, q3 + (size_t)b * T * ld + c * D + h * HD, ld, T, lane);
+  {
+    float* const dsts[1] = {sq};
+    const int coffs[1] = {0};
+    load_tiles32<1>(dsts, q3 + (size_t)b * T * ld + c * D + h * HD, coffs, ld, T, lane);
+  }
   // rows [0,Rc) carry per-row conditioning; rows [Rc,R) are the classifier-free "no condition"
   // branch whose A depends only on the weights (Aunc[cond][H][32][32])
   const float* Ap = (b < Rc) ? Apre + ((((size_t)c * Rc + b) * H + h) * HD) * HD
@@ -173,8 +203,10 @@ __global__ void __launch_bounds__(256) ca_attention_kernel(const float* __restri
   float Areg[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) Areg[d] = Ap[d * HD + (lane & 31)];
+  if (qmask)
+    for (int n = threadIdx.x; n < T; n += 256) smask[n] = qmask[((size_t)c * R + b) * T + n];
   __syncthreads();
-  const float* qm = qmask ? qmask + ((size_t)c * R + b) * T : nullptr;
+  const float* qm = qmask ? smask : nullptr;
   qa_and_store(sq, Areg, y3 + (size_t)b * T * ld + c * D + h * HD, ld, T, lane, qm, sstat + wave * 2 * Tp);
   __syncthreads();
   for (int n = threadIdx.x; n < T; n += 256) {
@@ -295,7 +327,7 @@ extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const 
   RG_REQUIRE(h, qkv && src_mask && y && stats, "null pointer");
   RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape");
   const int Tp = (T + 3) & ~3;
-  const size_t lds = (WAVES * 2 * Tp + WAVES * (3 * Tp * HD + HD * HD)) * sizeof(float);
+  const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * (3 * Tp * HD + HD * HD)) * sizeof(float);
   hipLaunchKernelGGL(sa_attention_kernel, dim3(R * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream), qkv,
                      ldqkv, D, src_mask, y, ldy, stats, T);
   RG_CHECK_LAUNCH(h);
@@ -309,7 +341,7 @@ extern "C" int rg_ca_attention(rg_handle* h, const float* q3, const float* Apre,
   RG_REQUIRE(h, Rc >= 0 && Rc <= R && (Rc == R || Aunc), "rows beyond Rc need Aunc");
   RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * WAVES) == 0 && R > 0 && ncond > 0, "bad shape");
   const int Tp = (T + 3) & ~3;
-  const size_t lds = (WAVES * 2 * Tp + WAVES * Tp * HD) * sizeof(float);
+  const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * Tp * HD) * sizeof(float);
   hipLaunchKernelGGL(ca_attention_kernel, dim3(R * ncond * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream),
                      q3, Apre, qmask, y3, stats, R, T, D, ncond, Rc, Aunc);
   RG_CHECK_LAUNCH(h);

@@ -1,71 +1,56 @@
 // Fused bf16-MFMA GEMM for gfx950:  out[M,N] = epilogue( A'[M,K] * W[N,K]^T ).
+// GENERIC (register-staged) kernel: handles every shape incl. ragged K / unaligned rows; aligned
+// shapes are routed to the LDS-DMA kernel in rg_gemm_dma.hip (same tile, same epilogue).
 //
-// Shape regime (denoiser): M = rows*43 tokens (86 .. ~11k), N,K in {512..2048}.  These are
-// small GEMMs: one 64x64 output tile per 256-thread workgroup (4 waves as 2x2, each wave a
-// 32x32 sub-tile = 2x2 MFMA 16x16x32 bf16 tiles), BK = 64, double-buffered LDS with register
-// staging (global loads of tile t+1 are in flight under the MFMAs of tile t, the LDS write
-// lands after them, one barrier per K-tile).
-//
-// LDS image: [64 rows][64 bf16] per operand per buffer, 128-B rows; the 16-B chunk index is
-// XOR-swizzled with (row>>1)&7 so the ds_read_b128 fragment reads of a 16-lane group (16
-// distinct rows, two adjacent chunks) hit 16 distinct 16-B slots of the 256-B bank row.
-//
-// A' is either bf16 in HBM or is built on the fly from fp32 sources while staging
-// (identity cast / LayerNorm / StylizationBlock front half), see include/rg_gesture.h.
-// The epilogue goes through LDS (reusing the staging buffers) so every thread owns 16
-// consecutive columns of one row: bias, token-periodic bias, per-head softmax (32 columns =
-// two threads, one shuffle), GELU, residual, per-row partial LayerNorm statistics, and 16-B
-// coalesced stores.
-//
-// blockIdx -> tile: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs;
-// tiles are numbered so that one XCD walks the N-tiles of one 64-row A panel (A panel stays in
-// that XCD's L2; W is shared by all).  Pure speed: any placement is correct.
-#include "rg_common.h"
+// Shape regime (denoiser / VAE): M = rows*43 tokens (86 .. ~11k), N,K in {512..2048}: small GEMMs
+// whose cost is latency and staging, not MFMA issue.  Design for that regime:
+//   * 64(M) x 128(N) output tile per 256-thread workgroup, 4 waves as 2x2, each wave 32x64 =
+//     2x4 MFMA 16x16x32 bf16 tiles (fp32 accumulate);  BK = 64.
+//   * A' is either bf16 in HBM or is built on the fly from fp32 sources while staging
+//     (identity cast / LayerNorm / StylizationBlock front half LN*(1+scale)+shift -> SiLU).
+//     With BN = 128 each fp32 element is transformed N/128 times, and the per-column
+//     parameters (gamma, beta, scale, shift) and per-row (mean, rstd) are staged in LDS once per
+//     workgroup instead of being re-fetched per K-tile.
+//   * register-staged software pipeline, prefetch distance 2: global loads of K-tile t+2 are
+//     issued before the MFMAs of tile t, the LDS write of tile t+1 lands after them; two LDS
+//     buffers, one barrier per K-tile; two statically named register sets (no runtime-indexed
+//     register arrays).
+//   * LDS image [rows][64 bf16], 128-B rows, 16-B chunk index XOR-swizzled with (row>>1)&7 so
+//     the ds_read_b128 fragment reads of a 16-lane group hit 16 distinct 16-B slots.
+//   * epilogue through LDS (reusing the staging buffers): every thread owns 32 consecutive
+//     columns of one row = one attention head for the per-head softmax; bias, token-periodic
+//     bias, GELU/ReLU, residual, per-row partial LayerNorm statistics (one (sum,sumsq) pair per
+//     128 columns) and 16-B coalesced stores.
+//   * blockIdx -> tile: consecutive workgroups are dealt round-robin over the 8 XCDs; tiles are
+//     numbered so that one XCD walks the N-tiles of one 64-row A panel (the panel stays in that
+//     XCD's L2; W is shared by all).  Pure speed: any placement is correct.
+//   * SPLIT ("bf16x3") precise mode: operands split into hi = bf16(v), lo = bf16(v - hi) and the
+//     product accumulated as lo*hi + hi*lo + hi*hi: ~fp32 products at 3 MFMAs per tile, used to
+//     check parity against the fp32 reference.
+#include "rg_gemm_epi.h"
 
 namespace {
+using namespace rg_gemm_detail;
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-constexpr int BM = 64, BN = 64, BK = 64, NT = 256;
-constexpr int ROW_BYTES = BK * 2;            // 128
-constexpr int TILE_BYTES = BM * ROW_BYTES;   // 8 KiB per operand per buffer
-constexpr int SC_LD = 68;                    // fp32 epilogue tile row stride (floats)
-
-__device__ __forceinline__ unsigned short f2bf(float f) {
-  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
-  return __builtin_bit_cast(unsigned short, b);
-}
-__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-}
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-// SiLU on the A-operand prologue path: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of the libm
-// expf + IEEE divide; the result is rounded to bf16 (or split hi/lo) right after.
-__device__ __forceinline__ float silu_f(float v) {
-  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
-}
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
-
-struct AStage {            // per-thread staging registers for one K-tile
-  uint4 w[2];              // W chunks (bf16 x8)
-  uint4 wlo[2];            // low-order W chunks (SPLIT)
-  uint4 abf[2];            // A chunks when A is bf16
-  float4 af[2][2];         // A chunks when A is fp32 (8 floats per chunk)
-  float4 g[2], b[2], sc[2], sh[2];  // gamma / beta / scale / shift for this thread's 8 columns
+template <bool A_BF16, bool SPLIT>
+struct Stage {                 // one K-tile in flight in registers
+  u32x4 w[4];
+  u32x4 wlo[SPLIT ? 4 : 1];
+  u32x4 abf[A_BF16 ? 2 : 1];
+  f32x4 af[A_BF16 ? 1 : 2][2];
 };
 
-// SPLIT: "bf16x3" precise mode.  Both operands are split into hi = bf16(v) and lo = bf16(v - hi)
-// and the product is accumulated as hi*hi + hi*lo + lo*hi (fp32 accumulate): ~2^-17 relative
-// operand precision at 3 MFMAs per tile, used to check parity against the fp32 reference.
 template <bool A_BF16, bool SPLIT>
 __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // [buf][A|W(|Alo|Wlo)][8 KiB] = 32 (64) KiB; the epilogue reuses it as fp32 [64][68]
-  constexpr int NPLANE = SPLIT ? 4 : 2;
+  constexpr int NPL = SPLIT ? 2 : 1;                       // hi (+ lo) planes
+  constexpr int STAGE_BYTES = NPL * (A_TILE + W_TILE);
+  // LDS: [2 stages][A hi | W hi | (A lo | W lo)] | params [4 seg][4][SEG_MAX] f32 | rowstat [4][64][2] | seginfo[4]
+  unsigned char* stage_base = smem;
+  float* sPar = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);   // [nseg][4][SEG_MAX]
+  float* sRow = sPar + (A_BF16 ? 0 : p.nseg) * 4 * SEG_MAX;         // [nseg][64][2]
+  SegInfo* sSeg = reinterpret_cast<SegInfo*>(sRow + RG_MAX_SEG * BM * 2);
+
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -73,21 +58,15 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
 
   // ---- XCD-aware tile mapping
   const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
-  int bid = blockIdx.x;
-  int grp = bid / (8 * nt);
-  int rem_m = mt - grp * 8;
-  if (rem_m > 8) rem_m = 8;
-  int r = bid - grp * 8 * nt;
-  const int tile_m = grp * 8 + r % rem_m;
-  const int tile_n = r / rem_m;
+  int tile_m, tile_n;
+  tile_of_block(blockIdx.x, mt, nt, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- staging assignment: chunk id c = tid + 256*j -> row = c/8 (tid/8 + 32 j), kchunk = tid%8
-  const int srow = tid >> 3;
-  const int kch = tid & 7;
+  const int srow = tid >> 3;   // staging row 0..31 (+32 j)
+  const int kch = tid & 7;     // 16-B chunk (8 bf16) inside the 64-wide K-tile
   const unsigned short* Wb = reinterpret_cast<const unsigned short*>(p.W);
+  const unsigned short* Wl = reinterpret_cast<const unsigned short*>(p.W_lo);
   const int nk = (p.K + BK - 1) / BK;
-  const int gboff = p.gb_group > 0 ? (n0 / p.gb_group) * p.gb_stride : 0;
 
   int arow[2];
   bool arow_ok[2];
@@ -99,166 +78,192 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
     arow[j] = p.a_row_mod > 0 ? gr % p.a_row_mod : gr;
   }
 
-  float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
-  int cur_seg = -1;
+  // ---- one-time LDS tables for the fp32 prologue
+  if constexpr (!A_BF16) {
+    if (tid == 0) {
+      sSeg[0] = SegInfo{p.seg[0].src, p.seg[0].ld, p.seg[0].mode};
+      sSeg[1] = SegInfo{p.seg[1].src, p.seg[1].ld, p.seg[1].mode};
+      sSeg[2] = SegInfo{p.seg[2].src, p.seg[2].ld, p.seg[2].mode};
+      sSeg[3] = SegInfo{p.seg[3].src, p.seg[3].ld, p.seg[3].mode};
+    }
+    const int gboff = p.gb_group > 0 ? (n0 / p.gb_group) * p.gb_stride : 0;
+#pragma unroll
+    for (int s = 0; s < RG_MAX_SEG; ++s) {
+      if (s < p.nseg && p.seg[s].mode != RG_A_IDENT) {
+        const rg_a_segment sg = p.seg[s];   // s is a compile-time constant here (unrolled)
+        float* par = sPar + s * 4 * SEG_MAX;
+        for (int i = tid; i < p.seg_len; i += NT) {
+          par[i] = sg.gamma[gboff + i];
+          par[SEG_MAX + i] = sg.beta[gboff + i];
+          if (sg.mode == RG_A_STYL) {
+            par[2 * SEG_MAX + i] = 1.0f + sg.scale_shift[i];
+            par[3 * SEG_MAX + i] = sg.scale_shift[p.seg_len + i];
+          }
+        }
+        if (tid < BM) {
+          int gr = m0 + tid;
+          if (gr >= p.M) gr = p.M - 1;
+          const int ar = p.a_row_mod > 0 ? gr % p.a_row_mod : gr;
+          const float* sp = sg.stats + (size_t)ar * sg.nparts * 2;
+          float su = 0.f, sq = 0.f;
+          for (int q = 0; q < sg.nparts; ++q) {
+            su += sp[2 * q];
+            sq += sp[2 * q + 1];
+          }
+          const float inv = 1.0f / (float)p.seg_len;
+          const float mu = su * inv;
+          float var = sq * inv - mu * mu;
+          var = var < 0.f ? 0.f : var;
+          sRow[(s * BM + tid) * 2] = mu;
+          sRow[(s * BM + tid) * 2 + 1] = rsqrtf(var + 1e-5f);
+        }
+      }
+    }
+    __syncthreads();
+  }
 
-  AStage st;
+  using St = Stage<A_BF16, SPLIT>;
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](St& st, int kt) {
     const int k0 = kt * BK + kch * 8;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + srow + 32 * j;  // W is zero padded to a multiple of 64 rows / 64 cols
-      st.w[j] = *reinterpret_cast<const uint4*>(Wb + (size_t)n * p.ldw + k0);
-      if constexpr (SPLIT)
-        st.wlo[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p.W_lo) +
-                                                    (size_t)n * p.ldw + k0);
+    for (int j = 0; j < 4; ++j) {
+      const size_t off = (size_t)(n0 + srow + 32 * j) * p.ldw + k0;  // W zero-padded to 128 rows / 64 cols
+      st.w[j] = *reinterpret_cast<const u32x4*>(Wb + off);
+      if constexpr (SPLIT) st.wlo[j] = *reinterpret_cast<const u32x4*>(Wl + off);
     }
     if constexpr (A_BF16) {
       const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (arow_ok[j] && k0 + 8 <= p.K)
-          st.abf[j] = *reinterpret_cast<const uint4*>(Ab + (size_t)arow[j] * p.lda + k0);
+          st.abf[j] = *reinterpret_cast<const u32x4*>(Ab + (size_t)arow[j] * p.lda + k0);
         else
-          st.abf[j] = make_uint4(0, 0, 0, 0);
+          st.abf[j] = u32x4{0u, 0u, 0u, 0u};
       }
     } else {
       const int sidx = (kt * BK) / p.seg_len;
-      const rg_a_segment& sg = p.seg[sidx];
-      const int ks = k0 - sidx * p.seg_len;  // column inside the segment
-      if (sidx != cur_seg) {
-        cur_seg = sidx;
-        if (sg.mode != RG_A_IDENT) {
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            float s = 0.f, ss = 0.f;
-            const float* sp = sg.stats + (size_t)arow[j] * sg.nparts * 2;
-            for (int q = 0; q < sg.nparts; ++q) {
-              s += sp[2 * q];
-              ss += sp[2 * q + 1];
-            }
-            const float inv = 1.0f / (float)p.seg_len;
-            float mu = s * inv;
-            float var = ss * inv - mu * mu;
-            var = var < 0.f ? 0.f : var;
-            mean[j] = mu;
-            rstd[j] = rsqrtf(var + 1e-5f);
-          }
-        }
-      }
+      const SegInfo sg = sSeg[sidx];
+      const int ks = k0 - sidx * p.seg_len;
       const bool fast = ((sg.ld & 3) == 0) && (k0 + 8 <= p.K);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float* src = sg.src + (size_t)arow[j] * sg.ld + ks;
         if (fast) {
-          st.af[j][0] = *reinterpret_cast<const float4*>(src);
-          st.af[j][1] = *reinterpret_cast<const float4*>(src + 4);
+          st.af[j][0] = *reinterpret_cast<const f32x4*>(src);
+          st.af[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
         } else {
-          float t[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) t[e] = (k0 + e < p.K) ? src[e] : 0.f;
-          st.af[j][0] = make_float4(t[0], t[1], t[2], t[3]);
-          st.af[j][1] = make_float4(t[4], t[5], t[6], t[7]);
-        }
-      }
-      if (sg.mode != RG_A_IDENT) {
-        const float* gp = sg.gamma + gboff + ks;
-        const float* bp = sg.beta + gboff + ks;
-        st.g[0] = *reinterpret_cast<const float4*>(gp);
-        st.g[1] = *reinterpret_cast<const float4*>(gp + 4);
-        st.b[0] = *reinterpret_cast<const float4*>(bp);
-        st.b[1] = *reinterpret_cast<const float4*>(bp + 4);
-        if (sg.mode == RG_A_STYL) {
-          const float* sp = sg.scale_shift + ks;
-          st.sc[0] = *reinterpret_cast<const float4*>(sp);
-          st.sc[1] = *reinterpret_cast<const float4*>(sp + 4);
-          st.sh[0] = *reinterpret_cast<const float4*>(sp + p.seg_len);
-          st.sh[1] = *reinterpret_cast<const float4*>(sp + p.seg_len + 4);
+          const int rem = p.K - k0;
+          st.af[j][0] = f32x4{rem > 0 ? src[0] : 0.f, rem > 1 ? src[1] : 0.f, rem > 2 ? src[2] : 0.f,
+                              rem > 3 ? src[3] : 0.f};
+          st.af[j][1] = f32x4{rem > 4 ? src[4] : 0.f, rem > 5 ? src[5] : 0.f, rem > 6 ? src[6] : 0.f,
+                              rem > 7 ? src[7] : 0.f};
         }
       }
     }
   };
 
-  auto store_tile = [&](int kt, int buf) {
-    unsigned char* sA = smem + buf * NPLANE * TILE_BYTES;
-    unsigned char* sW = sA + TILE_BYTES;
+  auto store_tile = [&](const St& st, int kt, int buf) {
+    unsigned char* sA = stage_base + buf * STAGE_BYTES;
+    unsigned char* sW = sA + A_TILE;
+    unsigned char* sAl = sW + W_TILE;
+    unsigned char* sWl = sAl + A_TILE;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       const int row = srow + 32 * j;
-      *reinterpret_cast<uint4*>(sW + lds_off(row, kch)) = st.w[j];
-      if constexpr (SPLIT) *reinterpret_cast<uint4*>(sW + 2 * TILE_BYTES + lds_off(row, kch)) = st.wlo[j];
-      if constexpr (A_BF16) {
-        *reinterpret_cast<uint4*>(sA + lds_off(row, kch)) = st.abf[j];
-      } else {
-        const int sidx = (kt * BK) / p.seg_len;
-        const int mode = p.seg[sidx].mode;
-        float v[8] = {st.af[j][0].x, st.af[j][0].y, st.af[j][0].z, st.af[j][0].w,
-                      st.af[j][1].x, st.af[j][1].y, st.af[j][1].z, st.af[j][1].w};
+      *reinterpret_cast<u32x4*>(sW + lds_off(row, kch)) = st.w[j];
+      if constexpr (SPLIT) *reinterpret_cast<u32x4*>(sWl + lds_off(row, kch)) = st.wlo[j];
+    }
+    if constexpr (A_BF16) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(sA + lds_off(srow + 32 * j, kch)) = st.abf[j];
+    } else {
+      const int sidx = (kt * BK) / p.seg_len;
+      const int mode = sSeg[sidx].mode;
+      const int ks = kt * BK + kch * 8 - sidx * p.seg_len;
+      float4 g0, g1, b0, b1, c0, c1, h0, h1;
+      g0 = g1 = b0 = b1 = c0 = c1 = h0 = h1 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mode != RG_A_IDENT) {
+        const float* par = sPar + sidx * 4 * SEG_MAX + ks;
+        g0 = *reinterpret_cast<const float4*>(par);
+        g1 = *reinterpret_cast<const float4*>(par + 4);
+        b0 = *reinterpret_cast<const float4*>(par + SEG_MAX);
+        b1 = *reinterpret_cast<const float4*>(par + SEG_MAX + 4);
+        if (mode == RG_A_STYL) {
+          c0 = *reinterpret_cast<const float4*>(par + 2 * SEG_MAX);
+          c1 = *reinterpret_cast<const float4*>(par + 2 * SEG_MAX + 4);
+          h0 = *reinterpret_cast<const float4*>(par + 3 * SEG_MAX);
+          h1 = *reinterpret_cast<const float4*>(par + 3 * SEG_MAX + 4);
+        }
+      }
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const float sc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = srow + 32 * j;
+        float v[8] = {st.af[j][0][0], st.af[j][0][1], st.af[j][0][2], st.af[j][0][3],
+                      st.af[j][1][0], st.af[j][1][1], st.af[j][1][2], st.af[j][1][3]};
         if (mode != RG_A_IDENT) {
-          const float g[8] = {st.g[0].x, st.g[0].y, st.g[0].z, st.g[0].w, st.g[1].x, st.g[1].y, st.g[1].z, st.g[1].w};
-          const float b[8] = {st.b[0].x, st.b[0].y, st.b[0].z, st.b[0].w, st.b[1].x, st.b[1].y, st.b[1].z, st.b[1].w};
+          const float mu = sRow[(sidx * BM + row) * 2], rs = sRow[(sidx * BM + row) * 2 + 1];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (v[e] - mean[j]) * rstd[j] * g[e] + b[e];
+          for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu) * rs * g[e] + be[e];
           if (mode == RG_A_STYL) {
-            const float sc[8] = {st.sc[0].x, st.sc[0].y, st.sc[0].z, st.sc[0].w, st.sc[1].x, st.sc[1].y, st.sc[1].z, st.sc[1].w};
-            const float sh[8] = {st.sh[0].x, st.sh[0].y, st.sh[0].z, st.sh[0].w, st.sh[1].x, st.sh[1].y, st.sh[1].z, st.sh[1].w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e] * (1.0f + sc[e]) + sh[e]);
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e] * sc[e] + sh[e]);
           }
         }
         if (!arow_ok[j]) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = 0.f;
         }
-        uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        const uint4 o = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
         *reinterpret_cast<uint4*>(sA + lds_off(row, kch)) = o;
         if constexpr (SPLIT) {
           float r[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) r[e] = v[e] - bf2f(f2bf(v[e]));
-          uint4 ol = make_uint4(pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7]));
-          *reinterpret_cast<uint4*>(sA + 2 * TILE_BYTES + lds_off(row, kch)) = ol;
+          const uint4 ol = make_uint4(pack2(r[0], r[1]), pack2(r[2], r[3]), pack2(r[4], r[5]), pack2(r[6], r[7]));
+          *reinterpret_cast<uint4*>(sAl + lds_off(row, kch)) = ol;
         }
       }
     }
   };
 
-  f32x4 acc[2][2];
+  f32x4 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  load_tile(0);
-  store_tile(0, 0);
-  __syncthreads();
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const unsigned char* sA = smem + buf * NPLANE * TILE_BYTES;
-    const unsigned char* sW = sA + TILE_BYTES;
+  auto compute = [&](int buf) {
+    const unsigned char* sA = stage_base + buf * STAGE_BYTES;
+    const unsigned char* sW = sA + A_TILE;
+    const unsigned char* sAl = sW + W_TILE;
+    const unsigned char* sWl = sAl + A_TILE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[2], bfr[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
         af[i] = *reinterpret_cast<const bf16x8*>(sA + lds_off(wr * 32 + i * 16 + frow, 4 * s + fq));
-        bfr[i] = *reinterpret_cast<const bf16x8*>(sW + lds_off(wc * 32 + i * 16 + frow, 4 * s + fq));
-      }
-      if constexpr (SPLIT) {
-        bf16x8 al[2], bl[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          al[i] = *reinterpret_cast<const bf16x8*>(sA + 2 * TILE_BYTES + lds_off(wr * 32 + i * 16 + frow, 4 * s + fq));
-          bl[i] = *reinterpret_cast<const bf16x8*>(sW + 2 * TILE_BYTES + lds_off(wc * 32 + i * 16 + frow, 4 * s + fq));
-        }
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sW + lds_off(wc * 64 + j * 16 + frow, 4 * s + fq));
+      if constexpr (SPLIT) {
+        bf16x8 al[2], bl[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          al[i] = *reinterpret_cast<const bf16x8*>(sAl + lds_off(wr * 32 + i * 16 + frow, 4 * s + fq));
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bl[j] = *reinterpret_cast<const bf16x8*>(sWl + lds_off(wc * 64 + j * 16 + frow, 4 * s + fq));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < 4; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bfr[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bl[j], acc[i][j], 0, 0, 0);
           }
@@ -266,110 +271,66 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(kt + 1, buf ^ 1);
+  };
+
+  // ---- software pipeline: tile t lives in register set (t & 1); prefetch distance 2
+  St st0, st1;
+  load_tile(st0, 0);
+  if (nk > 1) load_tile(st1, 1);
+  store_tile(st0, 0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_tile(st0, kt + 2);
+    compute(0);
+    if (kt + 1 < nk) store_tile(st1, kt + 1, 1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 3 < nk) load_tile(st1, kt + 3);
+    compute(1);
+    if (kt + 2 < nk) store_tile(st0, kt + 2, 0);
     __syncthreads();
   }
 
-  // ---- epilogue through LDS: sC[64][SC_LD] fp32
+  // ---- epilogue through LDS: sC[64][SC_LD] fp32 (33.8 KiB <= 2 * STAGE_BYTES)
   float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        sC[(wr * 32 + i * 16 + fq * 4 + e) * SC_LD + wc * 32 + j * 16 + frow] = acc[i][j][e];
+        sC[(wr * 32 + i * 16 + fq * 4 + e) * SC_LD + wc * 64 + j * 16 + frow] = acc[i][j][e];
   __syncthreads();
 
-  const int erow = tid >> 2;           // 0..63
-  const int ecol = (tid & 3) * 16;     // 0,16,32,48
-  const int grow = m0 + erow;
-  const int gcol = n0 + ecol;
-  const bool row_ok = grow < p.M;
-  float v[16];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float4 t = *reinterpret_cast<const float4*>(sC + erow * SC_LD + ecol + 4 * q);
-    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  epilogue(p, sC, tid, m0, n0, tile_n, nt);
+}
+
+template <bool A_BF16, bool SPLIT>
+size_t lds_bytes(int nseg) {
+  const size_t stages = 2 * (SPLIT ? 2 : 1) * (A_TILE + W_TILE);
+  const size_t tables = A_BF16 ? 0 : ((size_t)nseg * 4 * SEG_MAX * 4 + RG_MAX_SEG * BM * 2 * 4 + RG_MAX_SEG * sizeof(SegInfo));
+  return stages + tables;
+}
+
+template <bool A_BF16, bool SPLIT>
+void launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  const size_t lds = lds_bytes<A_BF16, SPLIT>(d->nseg);
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_BF16, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_bytes<A_BF16, SPLIT>(RG_MAX_SEG));
+    attr = true;
   }
-  if (p.bias) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] += (gcol + e < p.N) ? p.bias[gcol + e] : 0.f;
-  }
-  if (p.tbias && row_ok) {
-    const float* tb = p.tbias + (size_t)(grow % p.tb_period) * p.N + gcol;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] += (gcol + e < p.N) ? tb[e] : 0.f;
-  }
-  if (gcol < p.softmax_cols) {  // uniform over the pair of threads that share a 32-column head
-    float mx = v[0];
-#pragma unroll
-    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, v[e]);
-    mx = fmaxf(mx, __shfl_xor(mx, 1));
-    float sum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { v[e] = expf(v[e] - mx); sum += v[e]; }
-    sum += __shfl_xor(sum, 1);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] *= inv;
-  }
-  if (p.act == 1) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = gelu_f(v[e]);
-  } else if (p.act == 2) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.f);
-  }
-  if (p.residual && row_ok) {
-    const float* rp = p.residual + (size_t)grow * p.ldr + gcol;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] += (gcol + e < p.N) ? rp[e] : 0.f;
-  }
-  if (p.stats_out) {
-    float s = 0.f, ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const float t = (gcol + e < p.N) ? v[e] : 0.f;
-      s += t; ss += t * t;
-    }
-    s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
-    s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
-    if ((tid & 3) == 0 && row_ok) {
-      float* so = p.stats_out + ((size_t)grow * nt + tile_n) * 2;
-      so[0] = s; so[1] = ss;
-    }
-  }
-  if (!row_ok) return;
-  const bool full = (gcol + 16 <= p.N);
-  if (p.out_bf16) {
-    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)grow * p.ldo + gcol;
-    if (full && (p.ldo & 7) == 0) {
-      uint4 a = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
-      uint4 b = make_uint4(pack2(v[8], v[9]), pack2(v[10], v[11]), pack2(v[12], v[13]), pack2(v[14], v[15]));
-      reinterpret_cast<uint4*>(o)[0] = a;
-      reinterpret_cast<uint4*>(o)[1] = b;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) if (gcol + e < p.N) o[e] = f2bf(v[e]);
-    }
-  } else {
-    float* o = reinterpret_cast<float*>(p.out) + (size_t)grow * p.ldo + gcol;
-    if (full && (p.ldo & 3) == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        reinterpret_cast<float4*>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) if (gcol + e < p.N) o[e] = v[e];
-    }
-  }
+  hipLaunchKernelGGL((gemm_kernel<A_BF16, SPLIT>), grid, dim3(NT), lds, s, *d);
 }
 
 }  // namespace
+
+bool rg_gemm_dma_eligible(const rg_gemm_desc* d);          // rg_gemm_dma.hip
+void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream);
 
 extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   RG_REQUIRE(h, d != nullptr, "null descriptor");
@@ -380,7 +341,7 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   if (d->a_is_bf16) {
     RG_REQUIRE(h, d->A != nullptr && (d->lda % 8) == 0, "bf16 A must have lda % 8 == 0");
   } else {
-    RG_REQUIRE(h, d->nseg >= 1 && d->nseg <= RG_MAX_SEG && d->seg_len > 0 && d->seg_len % 64 == 0 ||
+    RG_REQUIRE(h, (d->nseg >= 1 && d->nseg <= RG_MAX_SEG && d->seg_len > 0 && d->seg_len % 64 == 0) ||
                       (d->nseg == 1 && d->seg_len >= d->K),
                "bad fp32 segment layout");
     RG_REQUIRE(h, (long)d->nseg * d->seg_len >= d->K, "segments do not cover K");
@@ -388,14 +349,13 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
       RG_REQUIRE(h, d->seg[s].src != nullptr, "null segment source");
       if (d->seg[s].mode != RG_A_IDENT)
         RG_REQUIRE(h, d->seg[s].stats && d->seg[s].gamma && d->seg[s].beta && d->seg[s].nparts > 0 &&
-                          d->seg_len % 8 == 0 && d->K % 8 == 0,
-                   "LN/STYL segment needs stats, gamma, beta");
+                          d->seg_len % 8 == 0 && d->K % 8 == 0 && d->seg_len <= SEG_MAX,
+                   "LN/STYL segment needs stats, gamma, beta and seg_len <= 512");
       if (d->seg[s].mode == RG_A_STYL) RG_REQUIRE(h, d->seg[s].scale_shift, "STYL segment needs scale_shift");
     }
   }
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + BN - 1) / BN;
-  dim3 grid(mt * nt), block(NT);
-  const size_t lds = 2 * 2 * TILE_BYTES;  // 32 KiB (>= 64*68*4 epilogue tile)
+  dim3 grid(mt * nt);
   rg_prof_rec rec;
   if (h->profiling) {
     auto get_ev = [&]() {
@@ -408,13 +368,15 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
     rec.flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
     (void)hipEventRecord(rec.start, rg_stream(stream));
   }
-  if (d->W_lo) {
-    RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
-    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 2 * lds, rg_stream(stream), *d);
+  if (d->W_lo) RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
+  if (!h->force_generic_gemm && rg_gemm_dma_eligible(d)) {
+    rg_gemm_dma_launch(d, h->num_cus, stream);
+  } else if (d->W_lo) {
+    launch<false, true>(d, grid, rg_stream(stream));
   } else if (d->a_is_bf16) {
-    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, lds, rg_stream(stream), *d);
+    launch<true, false>(d, grid, rg_stream(stream));
   } else {
-    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, lds, rg_stream(stream), *d);
+    launch<false, false>(d, grid, rg_stream(stream));
   }
   RG_CHECK_LAUNCH(h);
   if (h->profiling) {
@@ -449,5 +411,13 @@ extern "C" int rg_profile_end(rg_handle* h, int variant, int64_t* launches, doub
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
+  return RG_OK;
+}
+
+// Test hook: route every GEMM through the generic register-staged kernel (1) or allow the LDS-DMA
+// kernel for aligned shapes (0, default).
+extern "C" int rg_set_gemm_path(rg_handle* h, int force_generic) {
+  if (!h) return RG_ERR_INVALID;
+  h->force_generic_gemm = force_generic != 0;
   return RG_OK;
 }

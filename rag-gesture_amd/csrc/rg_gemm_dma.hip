@@ -1,0 +1,361 @@
+// LDS-DMA variant of the fused bf16-MFMA GEMM (same 64x128x64 tile and epilogue as rg_gemm.hip)
+// for aligned shapes (K % 64 == 0, 16-B aligned rows).
+//
+// Why: at M <= ~3k token rows these GEMMs launch fewer workgroups than the chip has CUs, so the K
+// loop of a workgroup is a pure latency chain (measured: ~1 us per K-tile with a 2-deep register
+// pipeline, i.e. HBM/L2 latency / prefetch depth).  Deep prefetch needs bytes in flight without
+// VGPRs: every operand tile is fetched with global_load_lds_dwordx4 (1 KiB per wave-instruction,
+// lane-linear LDS destination) into a 4-stage LDS ring, with a counted s_waitcnt vmcnt(N) and a
+// raw s_barrier per K-tile (a __syncthreads() would drain the DMA queue).
+//   * bf16 operands (W always, A when it is bf16): the XOR swizzle of the ds_read_b128 fragment
+//     reads is applied on the SOURCE address (which 16-B chunk of the row a lane fetches), the LDS
+//     image stays lane-linear.
+//   * fp32 A sources are DMA'd raw ([64][64] fp32 per stage, chunk index XOR row&15) and
+//     converted when the MFMA fragment is read: LayerNorm / stylization / SiLU run on the 32
+//     values a lane feeds to the matrix core per K-tile, with gamma/beta/(1+scale)/shift and the
+//     per-row (rstd, -mean*rstd) staged in LDS once per workgroup.
+//   * SPLIT (bf16x3) precise mode: W hi/lo planes are both DMA'd, A hi/lo are formed in registers.
+#include "rg_gemm_epi.h"
+
+namespace {
+using namespace rg_gemm_detail;
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <bool A_BF16, bool SPLIT, int NS>
+__global__ void __launch_bounds__(NT) gemm_dma_kernel(const rg_gemm_desc p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int A_STAGE = A_BF16 ? A_TILE : 2 * A_TILE;           // fp32 tile = 16 KiB
+  constexpr int W_PLANES = SPLIT ? 2 : 1;
+  constexpr int STAGE = A_STAGE + W_PLANES * W_TILE;
+  constexpr int PER_TILE = (A_BF16 ? 2 : 4) + 4 * W_PLANES;       // DMA instructions per wave per K-tile
+  float* sPar = reinterpret_cast<float*>(smem + NS * STAGE);     // [nseg][4][SEG_MAX]
+  float* sRow = sPar + (A_BF16 ? 0 : p.nseg) * 4 * SEG_MAX;      // [RG_MAX_SEG][64][2] = (rstd, -mean*rstd)
+  SegInfo* sSeg = reinterpret_cast<SegInfo*>(sRow + RG_MAX_SEG * BM * 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
+  int tile_m, tile_n;
+  tile_of_block(blockIdx.x, mt, nt, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = p.K / BK;
+
+  auto a_row = [&](int r) {
+    int gr = m0 + r;
+    if (gr >= p.M) gr = p.M - 1;       // duplicate the last row; discarded by the epilogue's row guard
+    return p.a_row_mod > 0 ? gr % p.a_row_mod : gr;
+  };
+
+  // ---- one-time LDS tables for the fp32 prologue
+  if constexpr (!A_BF16) {
+    if (tid == 0) {
+      sSeg[0] = SegInfo{p.seg[0].src, p.seg[0].ld, p.seg[0].mode};
+      sSeg[1] = SegInfo{p.seg[1].src, p.seg[1].ld, p.seg[1].mode};
+      sSeg[2] = SegInfo{p.seg[2].src, p.seg[2].ld, p.seg[2].mode};
+      sSeg[3] = SegInfo{p.seg[3].src, p.seg[3].ld, p.seg[3].mode};
+    }
+    const int gboff = p.gb_group > 0 ? (n0 / p.gb_group) * p.gb_stride : 0;
+#pragma unroll
+    for (int s = 0; s < RG_MAX_SEG; ++s) {
+      if (s < p.nseg && p.seg[s].mode != RG_A_IDENT) {
+        const rg_a_segment sg = p.seg[s];
+        float* par = sPar + s * 4 * SEG_MAX;
+        for (int i = tid; i < p.seg_len; i += NT) {
+          par[i] = sg.gamma[gboff + i];
+          par[SEG_MAX + i] = sg.beta[gboff + i];
+          if (sg.mode == RG_A_STYL) {
+            par[2 * SEG_MAX + i] = 1.0f + sg.scale_shift[i];
+            par[3 * SEG_MAX + i] = sg.scale_shift[p.seg_len + i];
+          }
+        }
+        if (tid < BM) {
+          const float* sp = sg.stats + (size_t)a_row(tid) * sg.nparts * 2;
+          float su = 0.f, sq = 0.f;
+          for (int q = 0; q < sg.nparts; ++q) {
+            su += sp[2 * q];
+            sq += sp[2 * q + 1];
+          }
+          const float inv = 1.0f / (float)p.seg_len;
+          const float mu = su * inv;
+          float var = sq * inv - mu * mu;
+          var = var < 0.f ? 0.f : var;
+          const float rs = rsqrtf(var + 1e-5f);
+          sRow[(s * BM + tid) * 2] = rs;
+          sRow[(s * BM + tid) * 2 + 1] = -mu * rs;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-lane DMA source rows (fixed for the whole kernel)
+  // W: 16 chunks of 1 KiB (8 rows x 128 B); wave w issues chunks w, w+4, w+8, w+12.
+  //    lane -> row = 8c + (lane>>3), physical 16-B slot lane&7 holds logical chunk slot ^ ((row>>1)&7)
+  unsigned w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave + 4 * i) * 8 + (lane >> 3);
+    const int lc = (lane & 7) ^ ((row >> 1) & 7);
+    w_off[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + lc * 8;   // bf16 elements; + kt*64 per tile
+  }
+  // A bf16: 8 chunks (same row geometry), wave w issues chunks w, w+4.
+  // A fp32: 16 chunks of 1 KiB (4 rows x 256 B), wave w issues chunks w, w+4, w+8, w+12;
+  //    lane -> row = 4c + (lane>>4), physical slot lane&15 holds logical chunk slot ^ (row & 15)
+  int a_rowidx[4];
+  int a_lc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (A_BF16) {
+      const int row = (wave + 4 * (i & 1)) * 8 + (lane >> 3);
+      a_rowidx[i] = a_row(row);
+      a_lc[i] = (lane & 7) ^ ((row >> 1) & 7);
+    } else {
+      const int row = (wave + 4 * i) * 4 + (lane >> 4);
+      a_rowidx[i] = a_row(row);
+      a_lc[i] = (lane & 15) ^ (row & 15);
+    }
+  }
+  const unsigned short* Wb = reinterpret_cast<const unsigned short*>(p.W);
+  const unsigned short* Wl = reinterpret_cast<const unsigned short*>(p.W_lo);
+
+  auto issue = [&](int kt) {
+    unsigned char* st = smem + (kt % NS) * STAGE;
+    const int k0 = kt * BK;
+    if constexpr (A_BF16) {
+      const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((const void*)(Ab + (size_t)a_rowidx[i] * p.lda + k0 + a_lc[i] * 8),
+                                         (lds_void*)(st + (wave + 4 * i) * 1024), 16, 0, 0);
+    } else {
+      const int sidx = k0 / p.seg_len;
+      const SegInfo sg = sSeg[sidx];
+      const int ks = k0 - sidx * p.seg_len;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((const void*)(sg.src + (size_t)a_rowidx[i] * sg.ld + ks + a_lc[i] * 4),
+                                         (lds_void*)(st + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const void*)(Wb + (size_t)w_off[i] + k0),
+                                       (lds_void*)(st + A_STAGE + (wave + 4 * i) * 1024), 16, 0, 0);
+      if constexpr (SPLIT)
+        __builtin_amdgcn_global_load_lds((const void*)(Wl + (size_t)w_off[i] + k0),
+                                         (lds_void*)(st + A_STAGE + W_TILE + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  int cur_seg = -1;
+  float rc1[2] = {1.f, 1.f}, rc0[2] = {0.f, 0.f};
+  int seg_mode = RG_A_IDENT;
+
+  auto compute = [&](int kt) {
+    const unsigned char* st = smem + (kt % NS) * STAGE;
+    const unsigned char* sW = st + A_STAGE;
+    const unsigned char* sWl = sW + W_TILE;
+    int sidx = 0, ks0 = 0;
+    if constexpr (!A_BF16) {
+      sidx = (kt * BK) / p.seg_len;
+      ks0 = kt * BK - sidx * p.seg_len;
+      if (sidx != cur_seg) {        // wave-uniform
+        cur_seg = sidx;
+        seg_mode = sSeg[sidx].mode;
+        if (seg_mode != RG_A_IDENT) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int r = wr * 32 + i * 16 + frow;
+            rc1[i] = sRow[(sidx * BM + r) * 2];
+            rc0[i] = sRow[(sidx * BM + r) * 2 + 1];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[2], al[2], bfr[4];
+      if constexpr (A_BF16) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(st + lds_off(wr * 32 + i * 16 + frow, 4 * s + fq));
+      } else {
+        float g[8], be[8], sc[8], sh[8];
+        if (seg_mode != RG_A_IDENT) {
+          const float* par = sPar + sidx * 4 * SEG_MAX + ks0 + 32 * s + 8 * fq;
+          *reinterpret_cast<f32x4*>(g) = *reinterpret_cast<const f32x4*>(par);
+          *reinterpret_cast<f32x4*>(g + 4) = *reinterpret_cast<const f32x4*>(par + 4);
+          *reinterpret_cast<f32x4*>(be) = *reinterpret_cast<const f32x4*>(par + SEG_MAX);
+          *reinterpret_cast<f32x4*>(be + 4) = *reinterpret_cast<const f32x4*>(par + SEG_MAX + 4);
+          if (seg_mode == RG_A_STYL) {
+            *reinterpret_cast<f32x4*>(sc) = *reinterpret_cast<const f32x4*>(par + 2 * SEG_MAX);
+            *reinterpret_cast<f32x4*>(sc + 4) = *reinterpret_cast<const f32x4*>(par + 2 * SEG_MAX + 4);
+            *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(par + 3 * SEG_MAX);
+            *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(par + 3 * SEG_MAX + 4);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wr * 32 + i * 16 + frow;
+          const int lc = 8 * s + 2 * fq;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(st + r * 256 + (((lc) ^ (r & 15)) << 4));
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(st + r * 256 + (((lc + 1) ^ (r & 15)) << 4));
+          float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          if (seg_mode != RG_A_IDENT) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(fmaf(v[e], rc1[i], rc0[i]), g[e], be[e]);
+            if (seg_mode == RG_A_STYL) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = silu_f(fmaf(v[e], sc[e], sh[e]));
+            }
+          }
+          const u32x4 hi = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+          af[i] = __builtin_bit_cast(bf16x8, hi);
+          if constexpr (SPLIT) {
+            float rr[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rr[e] = v[e] - bf2f(f2bf(v[e]));
+            const u32x4 lo = {pack2(rr[0], rr[1]), pack2(rr[2], rr[3]), pack2(rr[4], rr[5]), pack2(rr[6], rr[7])};
+            al[i] = __builtin_bit_cast(bf16x8, lo);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(sW + lds_off(wc * 64 + j * 16 + frow, 4 * s + fq));
+      if constexpr (SPLIT) {
+        bf16x8 bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          bl[j] = *reinterpret_cast<const bf16x8*>(sWl + lds_off(wc * 64 + j * 16 + frow, 4 * s + fq));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- ring pipeline.  Iteration t: [wait until this wave's pieces of tile t have landed]
+  //      -> barrier (everyone's pieces landed; everyone is done reading stage (t-1) % NS)
+  //      -> issue tile t+NS-1 into stage (t-1) % NS -> MFMAs of tile t.
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t)
+    if (t < nk) issue(t);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int younger = min(NS - 2, nk - 1 - kt);   // tiles issued after tile kt and still allowed in flight
+    if (NS >= 4 && younger >= 2) wait_vmcnt<2 * PER_TILE>();
+    else if (NS >= 3 && younger == 1) wait_vmcnt<PER_TILE>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) issue(kt + NS - 1);
+    compute(kt);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue through LDS: sC[64][SC_LD] fp32 (33.8 KiB, fits in the ring)
+  float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        sC[(wr * 32 + i * 16 + fq * 4 + e) * SC_LD + wc * 64 + j * 16 + frow] = acc[i][j][e];
+  __syncthreads();
+  epilogue(p, sC, tid, m0, n0, tile_n, nt);
+}
+
+constexpr size_t LDS_MAX = 160 * 1024;
+
+template <bool A_BF16, bool SPLIT>
+size_t dma_lds_bytes(int nseg, int ns) {
+  const size_t a_stage = A_BF16 ? A_TILE : 2 * A_TILE;
+  const size_t stage = a_stage + (SPLIT ? 2 : 1) * W_TILE;
+  const size_t tables = A_BF16 ? 0 : ((size_t)nseg * 4 * SEG_MAX * 4 + RG_MAX_SEG * BM * 2 * 4 + RG_MAX_SEG * sizeof(SegInfo));
+  return ns * stage + tables;
+}
+
+template <bool A_BF16, bool SPLIT, int NS>
+void dma_launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<A_BF16, SPLIT, NS>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    attr = true;
+  }
+  const size_t lds = dma_lds_bytes<A_BF16, SPLIT>(d->nseg, NS);
+  hipLaunchKernelGGL((gemm_dma_kernel<A_BF16, SPLIT, NS>), grid, dim3(NT), lds, s, *d);
+}
+
+// ring depth for this descriptor (0: does not fit the 160 KiB LDS at all).  Grids with more
+// workgroups than CUs use a 2-stage ring (<= 80 KiB) so two workgroups share a CU and hide each
+// other's DMA latency; smaller grids are a pure latency chain and take the deepest ring that fits.
+int dma_depth(const rg_gemm_desc* d, int num_cus) {
+  const int wgs = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+  if (!d->W_lo && wgs > num_cus) {
+    const size_t need2 = d->a_is_bf16 ? dma_lds_bytes<true, false>(0, 2) : dma_lds_bytes<false, false>(d->nseg, 2);
+    if (need2 <= LDS_MAX / 2) return 2;
+  }
+  for (int ns = (d->W_lo ? 3 : 4); ns >= 3; --ns) {
+    const size_t need = d->W_lo ? dma_lds_bytes<false, true>(d->nseg, ns)
+                                : (d->a_is_bf16 ? dma_lds_bytes<true, false>(0, ns) : dma_lds_bytes<false, false>(d->nseg, ns));
+    if (need <= LDS_MAX) return ns;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// true if the descriptor satisfies the DMA kernel's alignment contract and its LDS ring fits
+bool rg_gemm_dma_eligible(const rg_gemm_desc* d) {
+  if (d->K % 64 != 0) return false;
+  if (dma_depth(d, 256) == 0) return false;
+  if (d->a_is_bf16) return (d->lda % 8) == 0 && ((uintptr_t)d->A % 16) == 0;
+  if (d->seg_len % 64 != 0) return false;
+  for (int s = 0; s < d->nseg; ++s)
+    if ((d->seg[s].ld % 4) != 0 || ((uintptr_t)d->seg[s].src % 16) != 0) return false;
+  return true;
+}
+
+void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream) {
+  const int mt = (d->M + BM - 1) / BM, nt = (d->N + BN - 1) / BN;
+  dim3 grid(mt * nt);
+  const int ns = dma_depth(d, num_cus);
+  hipStream_t s = rg_stream(stream);
+  if (d->W_lo) {
+    dma_launch<false, true, 3>(d, grid, s);
+  } else if (d->a_is_bf16) {
+    if (ns == 2) dma_launch<true, false, 2>(d, grid, s);
+    else dma_launch<true, false, 4>(d, grid, s);
+  } else if (ns == 2) {
+    dma_launch<false, false, 2>(d, grid, s);
+  } else if (ns == 4) {
+    dma_launch<false, false, 4>(d, grid, s);
+  } else {
+    dma_launch<false, false, 3>(d, grid, s);
+  }
+}

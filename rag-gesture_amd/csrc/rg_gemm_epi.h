@@ -1,0 +1,156 @@
+// Shared pieces of the two GEMM kernels (rg_gemm.hip: register-staged generic kernel,
+// rg_gemm_dma.hip: LDS-DMA kernel for aligned shapes): tile constants, bf16 helpers, and the
+// epilogue that turns the fp32 accumulator tile sC[64][132] into the fused output.
+#pragma once
+#include "rg_common.h"
+
+namespace rg_gemm_detail {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;   // native vectors: HIP's uint4/float4 wrapper
+                                                             // structs keep staging sets in scratch
+
+constexpr int BM = 64, BN = 128, BK = 64, NT = 256;
+constexpr int ROW_BYTES = BK * 2;               // 128
+constexpr int A_TILE = BM * ROW_BYTES;          // 8 KiB  (bf16)
+constexpr int W_TILE = BN * ROW_BYTES;          // 16 KiB (bf16)
+constexpr int SC_LD = BN + 4;                   // fp32 epilogue tile row stride (floats)
+constexpr int SEG_MAX = 512;                    // widest fp32 segment with LN/STYL parameters
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+// SiLU on the A-operand prologue path: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of libm expf +
+// IEEE divide; the result is rounded to bf16 (or split hi/lo) right after.
+__device__ __forceinline__ float silu_f(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+struct SegInfo {      // LDS copy of one rg_a_segment (dynamic indexing of kernargs would go to scratch)
+  const float* src;
+  int ld, mode;
+};
+
+// XCD-aware tile mapping: one XCD walks the N-tiles of one 64-row A panel.
+__device__ __forceinline__ void tile_of_block(int bid, int mt, int nt, int& tile_m, int& tile_n) {
+  const int grp = bid / (8 * nt);
+  int rem_m = mt - grp * 8;
+  if (rem_m > 8) rem_m = 8;
+  const int rr = bid - grp * 8 * nt;
+  tile_m = grp * 8 + rr % rem_m;
+  tile_n = rr / rem_m;
+}
+
+// Every thread owns 32 consecutive columns of one row of sC (= one attention head).
+__device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC, int tid, int m0, int n0, int tile_n,
+                                         int nt) {
+  const int erow = tid >> 2;           // 0..63
+  const int ecol = (tid & 3) * 32;     // 0,32,64,96 : one 32-column head per thread
+  const int grow = m0 + erow;
+  const int gcol = n0 + ecol;
+  const bool row_ok = grow < p.M;
+  float v[32];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(sC + erow * SC_LD + ecol + 4 * q);
+    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+  }
+  const bool full = (gcol + 32 <= p.N);
+  if (p.bias) {
+    if (full) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(p.bias + gcol + 4 * q);
+        v[4 * q] += t.x; v[4 * q + 1] += t.y; v[4 * q + 2] += t.z; v[4 * q + 3] += t.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] += (gcol + e < p.N) ? p.bias[gcol + e] : 0.f;
+    }
+  }
+  if (p.tbias && row_ok) {
+    const float* tb = p.tbias + (size_t)(grow % p.tb_period) * p.N + gcol;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] += (gcol + e < p.N) ? tb[e] : 0.f;
+  }
+  if (gcol < p.softmax_cols) {  // this thread's 32 columns are exactly one head
+    float mx = v[0];
+#pragma unroll
+    for (int e = 1; e < 32; ++e) mx = fmaxf(mx, v[e]);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) { v[e] = expf(v[e] - mx); sum += v[e]; }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] *= inv;
+  }
+  if (p.act == 1) {
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] = gelu_f(v[e]);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (p.residual && row_ok) {
+    const float* rp = p.residual + (size_t)grow * p.ldr + gcol;
+    if (full && (p.ldr & 3) == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
+        v[4 * q] += t.x; v[4 * q + 1] += t.y; v[4 * q + 2] += t.z; v[4 * q + 3] += t.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] += (gcol + e < p.N) ? rp[e] : 0.f;
+    }
+  }
+  if (p.stats_out) {
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float t = (gcol + e < p.N) ? v[e] : 0.f;
+      s += t; ss += t * t;
+    }
+    s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
+    s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
+    if ((tid & 3) == 0 && row_ok) {
+      float* so = p.stats_out + ((size_t)grow * nt + tile_n) * 2;
+      so[0] = s; so[1] = ss;
+    }
+  }
+  if (!row_ok) return;
+  if (p.out_bf16) {
+    unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)grow * p.ldo + gcol;
+    if (full && (p.ldo & 7) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        reinterpret_cast<uint4*>(o)[q] = make_uint4(pack2(v[8 * q], v[8 * q + 1]), pack2(v[8 * q + 2], v[8 * q + 3]),
+                                                    pack2(v[8 * q + 4], v[8 * q + 5]), pack2(v[8 * q + 6], v[8 * q + 7]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) if (gcol + e < p.N) o[e] = f2bf(v[e]);
+    }
+  } else {
+    float* o = reinterpret_cast<float*>(p.out) + (size_t)grow * p.ldo + gcol;
+    if (full && (p.ldo & 3) == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        reinterpret_cast<float4*>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) if (gcol + e < p.N) o[e] = v[e];
+    }
+  }
+}
+
+}  // namespace rg_gemm_detail

@@ -145,12 +145,12 @@ class DenoiserSession:
         self.M = M = self.R * T
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
-        self.st_a, self.st_b, self.st_c = f(M, D // 64, 2), f(M, D // 64, 2), f(M, D // 64, 2)
+        self.st_a, self.st_b, self.st_c = (f(M, D // G.STATS_COLS, 2) for _ in range(3))
         self.qkv, self.q3 = f(M, 3 * D), f(M, 3 * D)
         self.y_sa, self.st_sa = f(M, D), f(M, D // 128, 2)
         self.y3, self.st3 = f(M, 3 * D), f(3, M, D // 128, 2)
         self.g = torch.empty(M, w.FF, device=dev, dtype=torch.bfloat16 if w.precision == "bf16" else torch.float32)
-        self.yf, self.st_f = f(M, D), f(M, D // 64, 2)
+        self.yf, self.st_f = f(M, D), f(M, D // G.STATS_COLS, 2)
         self.head = f(M, D)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
         self.src_mask = torch.ones(self.R, T, device=dev)
@@ -174,7 +174,7 @@ class DenoiserSession:
             x = x.to(dev).float().contiguous()
             n_tok, kin = x.shape[1], x.shape[2]
             xf = torch.empty(B * n_tok, D, device=dev)
-            st = torch.empty(B * n_tok, D // 64, 2, device=dev)
+            st = torch.empty(B * n_tok, D // G.STATS_COLS, 2, device=dev)
             G.gemm(h, M=B * n_tok, N=D, K=kin, W=wt, out=xf, segs=[G.Seg(x.view(B * n_tok, kin))], seg_len=None,
                    bias=bt, stats_out=st)
             srcs.append((xf, st, n_tok))

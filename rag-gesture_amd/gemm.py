@@ -6,6 +6,7 @@ import torch
 from . import capi
 
 A_IDENT, A_LN, A_STYL = 0, 1, 2
+STATS_COLS = 128  # rg_gemm emits one (sum, sumsq) pair per 128 output columns
 MAX_SEG = 4
 _vp = ctypes.c_void_p
 
@@ -50,7 +51,7 @@ class PackedWeight:
 def pack_weight(w, device=None, split=False):
     """fp32 [N,K] (nn.Linear layout) -> PackedWeight on device."""
     n, k = w.shape
-    np_, kp = (n + 63) // 64 * 64, (k + 63) // 64 * 64
+    np_, kp = (n + 127) // 128 * 128, (k + 63) // 64 * 64  # rows: the kernel's BN = 128 tile
     dev = device or w.device
     wf = w.to(dev).float()
     hi = torch.zeros(np_, kp, dtype=torch.bfloat16, device=dev)

@@ -119,6 +119,8 @@ class MotionDiffusion:
         self.device, self.precision = torch.device(device), precision
         self.training = False
         self._sessions = {}
+        self._graphs = {}
+        self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -132,7 +134,36 @@ class MotionDiffusion:
         m.weights = denoiser.DenoiserWeights(state, m.cfg, self.schedule, self.device, precision=self.precision)
         m.gesture_rep_encoder = vae_mod.GestureRepEncoder(state, m.vae_cfgs, self.device, self.precision)
         self._sessions = {}
+        self._graphs = {}
         return self
+
+    def _graph_run(self, key, inputs, fn):
+        """Run fn(static_inputs) -> outputs through a cached HIP graph: `inputs` (dict of device
+        tensors or None) are copied into static buffers, the captured launch sequence is replayed
+        and clones of the outputs are returned.  Falls back to eager launches if use_graphs is off."""
+        if not self.use_graphs:
+            return fn(inputs)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static = {k: (None if v is None else torch.empty_like(v).copy_(v)) for k, v in inputs.items()}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up outside capture (lazy module loads, allocator)
+                fn(static)
+            torch.cuda.current_stream().wait_stream(side)
+            for k, v in inputs.items():
+                if v is not None:
+                    static[k].copy_(v)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = fn(static)
+            ent = self._graphs[key] = (graph, static, outs)
+        graph, static, outs = ent
+        for k, v in inputs.items():
+            if v is not None:
+                static[k].copy_(v)
+        graph.replay()
+        return tuple(o.clone() for o in outs)
 
     def eval(self):
         self.training = False
@@ -181,9 +212,15 @@ class MotionDiffusion:
         B = kwargs["motion_upper"].shape[0]
         D = gre.vae_latent_dim
         eps_list = [tape.draw((B * 10, 1, D)) for _ in range(4)]
-        motion, motion_mask = gre.encode(kwargs["motion_upper"], kwargs["motion_lower"], kwargs["motion_face"],
-                                         kwargs["motion_hands"], kwargs["trans"], kwargs["facial"], kwargs["contact"],
-                                         kwargs["motion_mask"].float(), eps_list)
+        f = lambda t: t.to(dev).float().contiguous()
+        enc_in = dict(up=f(kwargs["motion_upper"]), lo=f(kwargs["motion_lower"]), fa=f(kwargs["motion_face"]),
+                      ha=f(kwargs["motion_hands"]), tr=f(kwargs["trans"]), fac=f(kwargs["facial"]),
+                      con=f(kwargs["contact"]), e0=f(eps_list[0]), e1=f(eps_list[1]), e2=f(eps_list[2]),
+                      e3=f(eps_list[3]))
+        motion, tr_rel = self._graph_run(("enc", B), enc_in, lambda s: gre.encode_device(
+            s["up"], s["lo"], s["fa"], s["ha"], s["tr"], s["fac"], s["con"], [s["e0"], s["e1"], s["e2"], s["e3"]]))
+        kwargs["trans"].copy_(tr_rel.to(kwargs["trans"].device))  # the reference's in-place re-zeroing
+        motion_mask = gre.latent_mask(kwargs["motion_mask"].float())
         T = motion.shape[1]
         n_lat = (T - 3) // 4
         up_i, ha_i, fa_i, lt_i = (list(range(0, n_lat)), list(range(n_lat + 1, 2 * n_lat + 1)),
@@ -235,8 +272,8 @@ class MotionDiffusion:
                 esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
                                      cat("retr_motion_mask").float(), eqm)
                 x_e = cat("retr_motion_latent").float().contiguous()
-                inv = torch.empty(S, E, T, D, device=dev)
-                sampler.ddim_reverse_sample_loop(esess, x_e, inv)
+                (inv,) = self._graph_run(("invert", E), dict(x=x_e), lambda s: (
+                    sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, E, T, D, device=dev)),))
                 for e, (b, q_idx) in enumerate(ex):
                     r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
                     q0, q1 = retrieval_dict["query_startends"][b][q_idx]
@@ -274,13 +311,19 @@ class MotionDiffusion:
         elif not isinstance(tape, _TorchNoise):
             for _ in range(S):
                 tape.draw((B, T, D))
+        loop_in = dict(x=x, in_seq=in_seq, noise=inseq_noise, invl=invl)
         if use_insertion_guidance:
-            sampler.ddim_guided_sample_loop(sess, x, invl, guidance_iters, guidance_lr, inseq_noise, in_seq=in_seq)
+            gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
+            key = ("guided", B, in_seq is not None, gi, lr)
+            (x,) = self._graph_run(key, loop_in, lambda s: (sampler.ddim_guided_sample_loop(
+                sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),))
         else:
-            sampler.ddim_sample_loop(sess, x, in_seq=in_seq, inseq_noise=inseq_noise)
+            key = ("sample", B, in_seq is not None)
+            (x,) = self._graph_run(key, loop_in, lambda s: (sampler.ddim_sample_loop(
+                sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
         output = self.model.post_process(x)
         results["prev_latentout"] = output
-        up, lo, fa, ha, tr, ex_, co = gre.decode(output)
+        up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B), dict(z=output), lambda s: gre.decode(s["z"]))
         results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
         results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
         results["pred_contact"] = co

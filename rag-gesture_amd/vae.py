@@ -252,12 +252,25 @@ class GestureRepEncoder:
         """Same argument order as the reference + eps_list (4 tensors [B*10,1,D], order upper, hands,
         face, lowertrans = the reference's rsample order).  Returns (latent [B,43,D], mask [B,43]).
         Like the reference it re-zeroes x/z of `motion_transl` IN PLACE (:231-232)."""
-        dev, f = self.dev, lambda t: t.to(self.dev).float().contiguous()
-        up, lo, fa, ha = f(motion_upper), f(motion_lower), f(motion_face), f(motion_hands)
+        f = lambda t: t.to(self.dev).float().contiguous()
+        latent, tr_rel = self.encode_device(f(motion_upper), f(motion_lower), f(motion_face), f(motion_hands),
+                                            f(motion_transl), f(motion_facial), f(motion_contact),
+                                            [f(e) for e in eps_list])
+        motion_transl.copy_(tr_rel.to(motion_transl.device))  # the reference's in-place mutation
+        return latent, self.latent_mask(motion_mask)
+
+    def latent_mask(self, motion_mask):
+        mm = motion_mask.to(self.dev).float()[:, ::self.frame_chunk_size]
+        sep = torch.zeros_like(mm[:, :1])
+        return torch.cat([mm, sep, mm, sep, mm, sep, mm], dim=1)
+
+    def encode_device(self, up, lo, fa, ha, tr, fac, con, eps_list):
+        """Device-only part of encode (fixed launch sequence, graph-capturable): all arguments are
+        contiguous fp32 device tensors.  Returns (latent [B,T,D], trans with x/z made relative)."""
+        dev = self.dev
         B, n, _ = up.shape
         self.uj, self.lj, self.fj, self.hj = up.shape[-1] // 3, lo.shape[-1] // 3, fa.shape[-1] // 3, ha.shape[-1] // 3
-        self.tj = motion_transl.shape[-1]
-        fac, con = f(motion_facial), f(motion_contact)
+        self.tj = tr.shape[-1]
         rows = B * n
         in_up = torch.empty(B, n, self.uj * 6, device=dev)
         self._aa6d(up, in_up, 0, self.uj)
@@ -269,21 +282,16 @@ class GestureRepEncoder:
         wlt = self.lj * 6 + self.tj + con.shape[-1]
         in_lt = torch.empty(B, n, wlt, device=dev)
         self._aa6d(lo, in_lt, 0, self.lj)
-        tr = f(motion_transl)
         self.h.call("copy_cols", tr, self.tj, 0, in_lt, wlt, self.lj * 6, rows, self.tj, n, 0b101)
         self.h.call("copy_cols", con, con.shape[-1], 0, in_lt, wlt, self.lj * 6 + self.tj, rows, con.shape[-1], 0, 0)
-        # replicate the reference's in-place mutation of the caller's tensor
         tr_rel = torch.empty_like(tr)
         self.h.call("copy_cols", in_lt, wlt, self.lj * 6, tr_rel, self.tj, 0, rows, self.tj, 0, 0)
-        motion_transl.copy_(tr_rel.to(motion_transl.device))
         n_lat = n // self.frame_chunk_size
         T, D = 4 * n_lat + 3, self.vae_latent_dim
         latent = torch.zeros(B, T, D, device=dev)  # separator rows stay zero
         for i, (part, feats) in enumerate((("upper", in_up), ("hands", in_ha), ("face", in_fa), ("lowertrans", in_lt))):
-            self.vaes[part].encode_to_latent(feats, eps_list[i].to(dev).float(), latent, i * (n_lat + 1))
-        mm = motion_mask.to(dev).float()[:, ::self.frame_chunk_size]
-        sep = torch.zeros_like(mm[:, :1])
-        return latent, torch.cat([mm, sep, mm, sep, mm, sep, mm], dim=1)
+            self.vaes[part].encode_to_latent(feats, eps_list[i], latent, i * (n_lat + 1))
+        return latent, tr_rel
 
     def decode(self, z_output):
         """Returns (upper, lower, facepose, hands, transl, exps, contact) like the reference (:270-330)."""

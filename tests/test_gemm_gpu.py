@@ -67,7 +67,7 @@ def test_ln_prologue_softmax_stats_residual(rg, h):
     xs = x.view(M, 8, 64)
     stats = torch.stack([xs.sum(-1), (xs * xs).sum(-1)], dim=-1).contiguous()  # [M,8,2]
     out = torch.empty(M, N, device="cuda")
-    st_out = torch.zeros(M, N // 64, 2, device="cuda")
+    st_out = torch.zeros(M, N // 128, 2, device="cuda")
     G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out,
            segs=[G.Seg(x.cuda(), mode=G.A_LN, stats=stats.cuda(), gamma=gam.cuda(), beta=bet.cuda())], seg_len=512,
            bias=b.cuda(), softmax_cols=512, stats_out=st_out)
@@ -75,7 +75,7 @@ def test_ln_prologue_softmax_stats_residual(rg, h):
     ref = F.linear(bf(xn), bf(w), b)
     ref[:, :512] = F.softmax(ref[:, :512].view(M, 16, 32), dim=-1).view(M, 512)
     assert (out.cpu() - ref).abs().max() <= 3e-3
-    o = out.cpu().view(M, N // 64, 64)
+    o = out.cpu().view(M, N // 128, 128)
     assert (st_out.cpu()[..., 0] - o.sum(-1)).abs().max() <= 1e-3
     assert (st_out.cpu()[..., 1] - (o * o).sum(-1)).abs().max() <= 1e-3
     # residual + tbias + row duplication (embed-style)
