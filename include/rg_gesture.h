@@ -235,6 +235,24 @@ int rg_aa_to_6d(rg_handle* h, const float* aa, int ld_in, float* out, int ld_out
 int rg_6d_to_aa(rg_handle* h, const float* d6, int ld_in, int col_off, float* out, int ld_out, int rows, int joints,
                 void* stream);
 
+/* ---------------------------------------------------------------- retrieval sweep
+ * Score of every DB entry for ONE query relation (sense, connective), float64, the reference's
+ * operation order (rag/discourse_retrieval.py:86-222): +2 sense present, +4 exact connective among the
+ * entry's relations of that sense, +3 same speaker, + mean over those relations (prominence known on
+ * both sides) of 4/(1+2|p_db - p_q|).  The DB is integer-coded CSR: rel_off[n_entries+1] indexes
+ * rel_sense / rel_conn / rel_prom (NaN = unknown); q_conn = -1 if the connective is not in the DB
+ * vocabulary; q_prom NaN = unknown.  top_out[e] = index (within the entry) of the relation whose
+ * bounds are reported (`top_rel_idx`), -1 if the sense is absent. */
+int rg_discourse_scores(rg_handle* h, const int* spk, const int* rel_off, const int* rel_sense,
+                        const int* rel_conn, const double* rel_prom, int n_entries, int q_sense, int q_conn,
+                        int q_spk, double q_prom, double* score_out, int* top_out, void* stream);
+
+/* Tie-break similarity (rag/utils.py:109-121): out[j] = mean_{i < min(Lq, L_c)} q[i,:].feats_c[i,:]
+ * for candidate entries c = cand[j]; feats is the ragged [sum L, dim] fp32 token-feature table with
+ * int64 row offsets feat_off[n_entries+1]; fp64 accumulation. */
+int rg_text_diag_sim(rg_handle* h, const float* q, int Lq, const float* feats, const int64_t* feat_off,
+                     const int* cand, int n_cand, int dim, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

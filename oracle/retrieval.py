@@ -1,0 +1,208 @@
+"""Oracle: discourse-based exemplar retrieval and exemplar placement (test infrastructure, see
+oracle/__init__.py).
+
+Restates mogen/models/transformers/rag/discourse_retrieval.py:8-316,
+rag/utils.py:86-132 (`sort_sidx_by_textsimilarity`), :171-228 (`map_conns_to_prominence`),
+the DB dict construction raggesture.py:244-293, `RetrievalDatabase.retrieve` :470-477 and the
+placement arithmetic of `RetrievalDatabase.forward` :542-760.
+All score arithmetic is Python float64 in the reference's order; tie-break similarities are fp32
+`torch.mm` diagonals like the reference.
+"""
+import copy
+
+import torch
+
+
+def _clean(s):
+    return "".join([c for c in str(s) if c.isalnum() or c.isspace()])
+
+
+def map_conns_to_prominence(conn_list, prominence_list):
+    """reference: rag/utils.py:171-228"""
+    relevant = {}
+    residual = copy.deepcopy(conn_list)
+    for dp in prominence_list:
+        dp_word = _clean(dp[0])
+        for si, sc in enumerate(conn_list):
+            if si not in relevant:
+                relevant[si] = []
+            if residual[si] is None:
+                continue
+            sc = _clean(sc)
+            if dp_word == sc or dp_word in sc.split():
+                relevant[si].append((sc, dp[3]))
+                if dp_word == sc or dp_word == sc.split()[-1]:
+                    residual[si] = None
+                break
+    for si, dps in relevant.items():
+        if len(dps) > 1:
+            assert dps[0][0] == _clean(conn_list[si])
+            relevant[si] = (conn_list[si], sum([d[1] for d in dps]) / len(dps))
+        else:
+            relevant[si] = dps[0] if len(dps) > 0 else None
+    # the reference asserts len(relevant) == len(conn_list): an empty prominence list with a
+    # non-empty connective list trips it; mirror the dict the loop would have produced otherwise
+    if len(prominence_list) == 0:
+        relevant = {si: None for si in range(len(conn_list))}
+    assert len(relevant) == len(conn_list)
+    return relevant
+
+
+def build_db_dicts(samples):
+    """reference: raggesture.py:255-276 (one record per DB sample, in iteration order)."""
+    idx_2_text, idx_2_sense, idx_2_discbounds, idx_2_prominence = {}, {}, {}, {}
+    for smp in samples:
+        n, spk = smp["sample_name"], int(smp["speaker_id"])
+        idx_2_text[n] = (smp["text_feature"], spk)
+        idx_2_sense[n] = [spk] + [(d[1], d[0]) for d in smp["discourse"]]
+        idx_2_discbounds[n] = [(d[1], d[0], d[4], d[5], d[6], d[7]) for d in smp["discourse"]]
+        idx_2_prominence[n] = map_conns_to_prominence([d[0] for d in smp["discourse"]], smp["prominence"])
+    return dict(idx_2_text=idx_2_text, idx_2_sense=idx_2_sense, idx_2_discbounds=idx_2_discbounds,
+                idx_2_prominence=idx_2_prominence)
+
+
+def sort_sidx_by_textsimilarity(smp_indexes, encoded_text, feature_cache):
+    """reference: rag/utils.py:86-132"""
+    if len(smp_indexes) == 0:
+        return smp_indexes
+    sims = {}
+    for s in smp_indexes:
+        f = feature_cache[s][0]
+        sims[s] = torch.diagonal(torch.mm(encoded_text, f.T)).mean()
+    return sorted(sims, key=sims.get, reverse=True)
+
+
+def discourse_retrieval(discourse, prominence, speaker_id, db, encoded_text):
+    """reference: rag/discourse_retrieval.py:8-316.  Returns (sample_indexes, d_bounds, query_bounds)."""
+    d_bounds, sample_indexes, query_bounds = {}, {}, {}
+    if len(discourse) == 0:
+        return sample_indexes, d_bounds, query_bounds
+    senses = [d[1] for d in discourse]
+    conns = [d[0] for d in discourse]
+    query_bounds = {i: (d[0].lower(), d[1], d[6], d[7]) for i, d in enumerate(discourse)}
+    q_prom = map_conns_to_prominence(conns, prominence)
+    for i, cv in q_prom.items():
+        if cv is not None:
+            q_prom[i] = (senses[i], cv[1])
+    for qi, (q_sense, q_conn) in enumerate(zip(senses, conns)):
+        score, rel_bounds = {}, {}
+        for name, rec in db["idx_2_sense"].items():
+            score[name] = 0
+            spk, rels = rec[0], rec[1:]
+            if len(rels) == 0:
+                continue
+            s_senses = [d[0] for d in rels]
+            s_conns = [d[1] for d in rels]
+            s_prom = {k: (None if v is None else (s_senses[k], v[1])) for k, v in db["idx_2_prominence"][name].items()}
+            if q_sense in s_senses:
+                score[name] += 2
+                rel = [k for k, s in enumerate(s_senses) if s == q_sense]
+                top, chosen = rel[0], False
+                rel_conns = [s_conns[k] for k in rel]
+                if q_conn in rel_conns:
+                    score[name] += 4
+                    top, chosen = rel[rel_conns.index(q_conn)], True
+                if spk == speaker_id:
+                    score[name] += 3
+                ssum, cnt, diffs = 0, 0, {}
+                for k in rel:
+                    if s_prom[k] is None or q_prom[qi] is None:
+                        continue
+                    diff = abs(s_prom[k][1] - q_prom[qi][1])
+                    diffs[k] = diff
+                    ssum += 4 / (1 + 2 * diff)
+                    cnt += 1
+                if cnt > 0:
+                    score[name] += ssum / cnt
+                    best = sorted(diffs, key=diffs.get)
+                    if top != best[0] and not chosen:
+                        top = best[0]
+                rel_bounds[name] = db["idx_2_discbounds"][name][top]
+        order = sorted(score, key=score.get, reverse=True)
+        tiers = {}
+        for name in order:
+            tiers.setdefault(score[name], [])
+            if score[name] > 0:
+                tiers[score[name]].append(name)
+        ranked = []
+        for sc in sorted(tiers.keys(), reverse=True):
+            tier = tiers[sc]
+            if len(tier) > 1:
+                tier = sort_sidx_by_textsimilarity(tier, encoded_text, db["idx_2_text"])
+            ranked += tier
+            if len(ranked) >= 10:
+                break
+        sample_indexes[qi] = ranked[:10]
+        d_bounds[qi] = {}
+        for name in ranked[:10]:
+            b = rel_bounds[name]
+            d_bounds[qi][name] = (b[1], b[0], round(b[4], 3), round(b[5], 3))
+    return sample_indexes, d_bounds, query_bounds
+
+
+def select_retrieved(sample_indexes, own_name, num_retrieval=1):
+    """reference: raggesture.py:470-477"""
+    return {q: [s for s in idxs if s != own_name][:num_retrieval] for q, idxs in sample_indexes.items()}
+
+
+def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="discourse", fps=15, chunk=15,
+                    motion_len=150):
+    """reference: raggesture.py:542-760 (time -> latent-index arithmetic only).
+    Returns {query_point: (sample_name, (retr_lat_start, retr_lat_end), (start_lat, end_lat))} in
+    placement order."""
+    latent_len = motion_len // chunk
+    prev_end = -1
+    out = {}
+    for qp, smp_idxs in retr_indexes.items():
+        if len(smp_idxs) == 0 or qp not in query_bounds:
+            continue
+        _, _, q_start, q_end = query_bounds[qp]
+        if q_start > q_end:
+            continue
+        for smp in smp_idxs:
+            _, _, r_start, r_end = retr_bounds[qp][smp]
+            q_start = max(0, q_start)
+            q_end = min(motion_len / fps, q_end)
+            q_start, q_end = int(q_start * fps), int(q_end * fps)
+            q_lat_start, q_lat_end = q_start // chunk, q_end // chunk + 1
+            assert q_lat_start < q_lat_end
+            if retrieval_method in ("gesture_type", "llm") and (r_end - r_start) > 0.9:
+                r_start, r_end = max(0, r_start - 0.2), min(motion_len / fps, r_end + 0.1)
+            else:
+                r_start, r_end = max(0, r_start - 0.666), min(motion_len / fps, r_end + 0.333)
+            r_start, r_end = int(r_start * fps), int(r_end * fps)
+            if r_start == r_end:
+                continue
+            if r_end == motion_len:
+                r_end = motion_len - 1
+                r_start = max(0, r_start - 1)
+            r_lat_start, r_lat_end = r_start // chunk, r_end // chunk + 1
+            mid_lat = ((q_start + q_end) // 2) // chunk
+            n = r_lat_end - r_lat_start
+            assert n > 0
+            side = n // 2
+            if n == 1:
+                s, e = mid_lat - side, mid_lat + side + 1
+            elif n == 2:
+                s, e = mid_lat, mid_lat + side + 1
+            elif n % 2 == 1:
+                s, e = mid_lat - side - 1, mid_lat + side
+            else:
+                s, e = mid_lat - side, mid_lat + side
+            if s < 0:
+                s, e = 0, n
+            if e > latent_len:
+                s -= e - latent_len
+                e = latent_len
+            if s < prev_end:
+                s = prev_end
+                e = s + n
+                if e > latent_len:
+                    e = latent_len
+                    n = e - s
+                    if n <= 0:
+                        continue
+                    r_lat_end = r_lat_start + n
+            prev_end = e
+            out[qp] = (smp, (r_lat_start, r_lat_end), (s, e))
+    return out

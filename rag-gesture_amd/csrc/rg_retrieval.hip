@@ -1,0 +1,118 @@
+// Retrieval sweep kernels (replicated exemplar DB resident in HBM).
+//
+//  rg_discourse_scores : the per-DB-entry categorical + prominence score of
+//      rag/discourse_retrieval.py:86-222 for one query relation, in float64 with the reference's
+//      operation order (sense +2, connective +4, speaker +3, mean of 4/(1+2|dp|) over the entry's
+//      relations of that sense), plus the index of the relation whose bounds are returned
+//      (`top_rel_idx`).  One thread per DB entry over integer-coded CSR metadata: pure HBM
+//      streaming (<= ~40 B per entry).
+//  rg_text_diag_sim    : the tie-break similarity of rag/utils.py:86-132,
+//      mean(diag(q[Lq,768] . db[Ld,768]^T)) = mean over i < min(Lq,Ld) of q[i].db[i], for a list
+//      of candidate entries; fp32 products accumulated in fp64, one workgroup per candidate, 16 B
+//      per lane coalesced reads of the candidate's token features (the reference computes the full
+//      Lq x Ld matrix and takes its diagonal).
+#include "rg_common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) discourse_scores_kernel(
+    const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
+    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int n_entries, int q_sense, int q_conn,
+    int q_spk, double q_prom, double* __restrict__ score_out, int* __restrict__ top_out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_entries) return;
+  const int r0 = rel_off[e], r1 = rel_off[e + 1];
+  double score = 0.0;
+  int top = -1;
+  int first = -1, conn_hit = -1;
+  for (int r = r0; r < r1; ++r) {
+    if (rel_sense[r] == q_sense) {
+      if (first < 0) first = r;
+      if (conn_hit < 0 && q_conn >= 0 && rel_conn[r] == q_conn) conn_hit = r;
+    }
+  }
+  if (first >= 0) {
+    score += 2.0;
+    top = first;
+    bool chosen = false;
+    if (conn_hit >= 0) {
+      score += 4.0;
+      top = conn_hit;
+      chosen = true;
+    }
+    if (spk[e] == q_spk) score += 3.0;
+    double sum = 0.0, best = 0.0;
+    int cnt = 0, best_r = -1;
+    if (q_prom == q_prom) {  // query prominence known (not NaN)
+      for (int r = first; r < r1; ++r) {
+        if (rel_sense[r] != q_sense) continue;
+        const double p = rel_prom[r];
+        if (p != p) continue;
+        const double diff = fabs(p - q_prom);
+        sum += 4.0 / (1.0 + 2.0 * diff);
+        if (best_r < 0 || diff < best) {  // first minimum = stable sort of the reference
+          best = diff;
+          best_r = r;
+        }
+        ++cnt;
+      }
+    }
+    if (cnt > 0) {
+      score += sum / (double)cnt;
+      if (top != best_r && !chosen) top = best_r;
+    }
+    top -= r0;
+  }
+  score_out[e] = score;
+  top_out[e] = top;
+}
+
+__global__ void __launch_bounds__(256) text_diag_sim_kernel(const float* __restrict__ q, int Lq,
+                                                           const float* __restrict__ feats,
+                                                           const int64_t* __restrict__ feat_off,
+                                                           const int* __restrict__ cand, int dim,
+                                                           double* __restrict__ out) {
+  __shared__ double red[4];
+  const int c = cand[blockIdx.x];
+  const int64_t o0 = feat_off[c];
+  const int Ld = (int)(feat_off[c + 1] - o0);
+  const int n = Lq < Ld ? Lq : Ld;
+  const int d4 = dim >> 2;
+  const float4* qa = reinterpret_cast<const float4*>(q);
+  const float4* fa = reinterpret_cast<const float4*>(feats + o0 * dim);
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n * d4; i += 256) {
+    const float4 a = qa[i], b = fa[i];
+    acc += (double)(a.x * b.x) + (double)(a.y * b.y) + (double)(a.z * b.z) + (double)(a.w * b.w);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = n > 0 ? ((red[0] + red[1]) + (red[2] + red[3])) / (double)n : 0.0;
+}
+
+}  // namespace
+
+extern "C" int rg_discourse_scores(rg_handle* h, const int* spk, const int* rel_off, const int* rel_sense,
+                                   const int* rel_conn, const double* rel_prom, int n_entries, int q_sense,
+                                   int q_conn, int q_spk, double q_prom, double* score_out, int* top_out,
+                                   void* stream) {
+  RG_REQUIRE(h, spk && rel_off && rel_sense && rel_conn && rel_prom && score_out && top_out, "null pointer");
+  RG_REQUIRE(h, n_entries > 0, "empty database");
+  hipLaunchKernelGGL(discourse_scores_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, rg_stream(stream), spk,
+                     rel_off, rel_sense, rel_conn, rel_prom, n_entries, q_sense, q_conn, q_spk, q_prom, score_out,
+                     top_out);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_text_diag_sim(rg_handle* h, const float* q, int Lq, const float* feats, const int64_t* feat_off,
+                                const int* cand, int n_cand, int dim, double* out, void* stream) {
+  RG_REQUIRE(h, q && feats && feat_off && cand && out, "null pointer");
+  RG_REQUIRE(h, n_cand > 0 && Lq > 0 && dim % 4 == 0, "bad shape");
+  hipLaunchKernelGGL(text_diag_sim_kernel, dim3(n_cand), dim3(256), 0, rg_stream(stream), q, Lq, feats, feat_off,
+                     cand, dim, out);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}

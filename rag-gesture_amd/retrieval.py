@@ -1,0 +1,345 @@
+"""Motion-exemplar retrieval: replicated DB on the GPU, discourse scoring sweep + text-similarity
+tie-break as HIP reductions, exemplar placement and `re_dict` assembly.
+
+Mirrors (names, argument meaning, result schema):
+  mogen/models/transformers/raggesture.py:157-303 RetrievalDatabase.__init__ (DB dicts),
+      :313-477 retrieve (method dispatch, self-exclusion, num_retrieval), :479-884 forward
+      (exemplar fetch + VAE encode, placement, re_dict)
+  mogen/models/transformers/rag/discourse_retrieval.py:8-316, rag/utils.py:86-132, 171-228
+What runs where: string handling (connective cleaning, vocabulary coding, prominence matching) and
+the final tier walk are host integer/string logic exactly as in the reference; the O(N_db) score
+sweep (float64, reference operation order -> bit-identical scores) and the tie-break similarity
+reduction run on the GPU over an integer-coded CSR copy of the DB (`DiscourseIndex`).
+The LMDB-backed cache of the reference (6 LMDB dicts) is replaced by in-memory dicts handed in by
+the caller (`metadata=` or `dataset.retrieval_samples`); `lmdb` is not available in this image.
+"""
+import copy
+import ctypes
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _clean(s):
+    return "".join([c for c in str(s) if c.isalnum() or c.isspace()])
+
+
+def map_conns_to_prominence(conn_list, prominence_list):
+    """rag/utils.py:171-228: attach prominence values to connectives (multi-word = average)."""
+    relevant = {}
+    residual = copy.deepcopy(conn_list)
+    for dp in prominence_list:
+        dp_word = _clean(dp[0])
+        for si, sc in enumerate(conn_list):
+            if si not in relevant:
+                relevant[si] = []
+            if residual[si] is None:
+                continue
+            sc = _clean(sc)
+            if dp_word == sc or dp_word in sc.split():
+                relevant[si].append((sc, dp[3]))
+                if dp_word == sc or dp_word == sc.split()[-1]:
+                    residual[si] = None
+                break
+    for si, dps in relevant.items():
+        if len(dps) > 1:
+            if dps[0][0] != _clean(conn_list[si]):
+                raise ValueError("prominence words do not spell the connective %r" % (conn_list[si],))
+            relevant[si] = (conn_list[si], sum([d[1] for d in dps]) / len(dps))
+        else:
+            relevant[si] = dps[0] if len(dps) > 0 else None
+    if len(relevant) != len(conn_list):  # the reference drops into a debugger here
+        raise ValueError("prominence list does not cover the connective list (reference would trap)")
+    return relevant
+
+
+def build_db_dicts(samples):
+    """raggesture.py:255-276: DB dicts from per-sample records (sample_name, speaker_id, discourse,
+    prominence, text_feature), in iteration order."""
+    idx_2_text, idx_2_sense, idx_2_discbounds, idx_2_prominence = {}, {}, {}, {}
+    for smp in samples:
+        n, spk = smp["sample_name"], int(smp["speaker_id"])
+        idx_2_text[n] = (smp["text_feature"], spk)
+        idx_2_sense[n] = [spk] + [(d[1], d[0]) for d in smp["discourse"]]
+        idx_2_discbounds[n] = [(d[1], d[0], d[4], d[5], d[6], d[7]) for d in smp["discourse"]]
+        idx_2_prominence[n] = map_conns_to_prominence([d[0] for d in smp["discourse"]], smp["prominence"])
+    return dict(idx_2_text=idx_2_text, idx_2_sense=idx_2_sense, idx_2_discbounds=idx_2_discbounds,
+                idx_2_prominence=idx_2_prominence)
+
+
+class DiscourseIndex:
+    """Integer-coded, device-resident copy of the discourse DB (replicated per GPU)."""
+
+    def __init__(self, db, device="cuda"):
+        self.dev = torch.device(device)
+        self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        self.db = db
+        self.names = list(db["idx_2_sense"].keys())
+        self.name_to_idx = {n: i for i, n in enumerate(self.names)}
+        self.sense_code, self.conn_code = {}, {}
+        spk, off, rs, rc, rp = [], [0], [], [], []
+        for n in self.names:
+            rec = db["idx_2_sense"][n]
+            spk.append(int(rec[0]))
+            prom = db["idx_2_prominence"][n]
+            for k, (sense, conn) in enumerate(rec[1:]):
+                rs.append(self.sense_code.setdefault(sense, len(self.sense_code)))
+                rc.append(self.conn_code.setdefault(conn, len(self.conn_code)))
+                pv = prom.get(k)
+                rp.append(float("nan") if pv is None else float(pv[1]))
+            off.append(len(rs))
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=self.dev)
+        self.spk, self.rel_off, self.rel_sense, self.rel_conn = i32(spk), i32(off), i32(rs or [0]), i32(rc or [0])
+        self.rel_prom = torch.tensor(rp or [0.0], dtype=torch.float64, device=self.dev)
+        feats = [db["idx_2_text"][n][0].float() for n in self.names]
+        foff = np.zeros(len(feats) + 1, dtype=np.int64)
+        foff[1:] = np.cumsum([f.shape[0] for f in feats])
+        self.feat_off = torch.from_numpy(foff).to(self.dev)
+        self.feats = torch.cat(feats, dim=0).to(self.dev).contiguous()
+        self.dim = self.feats.shape[1]
+        self.n = len(self.names)
+        self._score = torch.empty(self.n, dtype=torch.float64, device=self.dev)
+        self._top = torch.empty(self.n, dtype=torch.int32, device=self.dev)
+
+    def scores(self, sense, conn, speaker_id, q_prom):
+        """HIP sweep for one query relation -> (scores float64 [N], top_rel int32 [N]) on the host."""
+        lib, vp = self.h.lib, ctypes.c_void_p
+        s = torch.cuda.current_stream().cuda_stream
+        rc = lib.rg_discourse_scores(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
+                                     vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
+                                     vp(self.rel_prom.data_ptr()), self.n, self.sense_code.get(sense, -2),
+                                     self.conn_code.get(conn, -1), int(speaker_id),
+                                     ctypes.c_double(float("nan") if q_prom is None else float(q_prom)),
+                                     vp(self._score.data_ptr()), vp(self._top.data_ptr()), vp(s))
+        if rc != 0:
+            raise capi.RgError("rg_discourse_scores failed: %s" % lib.rg_last_error(self.h._h).decode())
+        return self._score.cpu().numpy(), self._top.cpu().numpy()
+
+    def sims(self, q_feat_dev, cand):
+        """HIP tie-break reduction: mean diagonal similarity of the query to each candidate entry."""
+        lib, vp = self.h.lib, ctypes.c_void_p
+        c = torch.tensor(cand, dtype=torch.int32, device=self.dev)
+        out = torch.empty(len(cand), dtype=torch.float64, device=self.dev)
+        s = torch.cuda.current_stream().cuda_stream
+        rc = lib.rg_text_diag_sim(self.h._h, vp(q_feat_dev.data_ptr()), q_feat_dev.shape[0], vp(self.feats.data_ptr()),
+                                  vp(self.feat_off.data_ptr()), vp(c.data_ptr()), len(cand), self.dim,
+                                  vp(out.data_ptr()), vp(s))
+        if rc != 0:
+            raise capi.RgError("rg_text_diag_sim failed: %s" % lib.rg_last_error(self.h._h).decode())
+        return out.cpu().numpy()
+
+
+def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text):
+    """Same contract as rag/discourse_retrieval.py:8-316 (returns sample_indexes, d_bounds,
+    query_bounds) with the DB sweep on the GPU."""
+    d_bounds, sample_indexes, query_bounds = {}, {}, {}
+    if len(discourse) == 0:
+        return sample_indexes, d_bounds, query_bounds
+    senses = [d[1] for d in discourse]
+    conns = [d[0] for d in discourse]
+    query_bounds = {i: (d[0].lower(), d[1], d[6], d[7]) for i, d in enumerate(discourse)}
+    q_prom = map_conns_to_prominence(conns, prominence)
+    q_dev = encoded_text.to(index.dev).float().contiguous()
+    for qi, (q_sense, q_conn) in enumerate(zip(senses, conns)):
+        qp = q_prom[qi]
+        score, top = index.scores(q_sense, q_conn, speaker_id, None if qp is None else qp[1])
+        order = np.argsort(-score, kind="stable")  # == sorted(..., reverse=True): stable among equals
+        ranked, i = [], 0
+        while i < len(order) and len(ranked) < 10:
+            sc = score[order[i]]
+            if not sc > 0:
+                break
+            j = i
+            while j < len(order) and score[order[j]] == sc:
+                j += 1
+            tier = [int(e) for e in order[i:j]]
+            if len(tier) > 1:
+                sim = index.sims(q_dev, tier)
+                tier = [tier[k] for k in np.argsort(-sim, kind="stable")]
+            ranked += tier
+            i = j
+        ranked = ranked[:10]
+        sample_indexes[qi] = [index.names[e] for e in ranked]
+        d_bounds[qi] = {}
+        for e in ranked:
+            b = index.db["idx_2_discbounds"][index.names[e]][int(top[e])]
+            d_bounds[qi][index.names[e]] = (b[1], b[0], round(b[4], 3), round(b[5], 3))
+    return sample_indexes, d_bounds, query_bounds
+
+
+def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="discourse", fps=15, chunk=15,
+                    motion_len=150):
+    """Time -> latent-index placement of raggesture.py:542-760.  Returns a list of
+    (query_point, sample_name, placed) in visiting order, where placed is None (the exemplar was
+    fetched and VAE-encoded by the reference but then skipped) or
+    ((retr_lat_start, retr_lat_end), (start_lat, end_lat))."""
+    latent_len = motion_len // chunk
+    prev_end = -1
+    out = []
+    for qp, smp_idxs in retr_indexes.items():
+        if len(smp_idxs) == 0 or qp not in query_bounds:
+            continue
+        _, _, q_start, q_end = query_bounds[qp]
+        if q_start > q_end:
+            continue
+        for smp in smp_idxs:
+            _, _, r_start, r_end = retr_bounds[qp][smp]
+            q_start = max(0, q_start)
+            q_end = min(motion_len / fps, q_end)
+            q_start, q_end = int(q_start * fps), int(q_end * fps)
+            if not q_start // chunk < q_end // chunk + 1:
+                raise ValueError("empty query span")
+            if retrieval_method in ("gesture_type", "llm") and (r_end - r_start) > 0.9:
+                r_start, r_end = max(0, r_start - 0.2), min(motion_len / fps, r_end + 0.1)
+            else:
+                r_start, r_end = max(0, r_start - 0.666), min(motion_len / fps, r_end + 0.333)
+            r_start, r_end = int(r_start * fps), int(r_end * fps)
+            if r_start == r_end:
+                out.append((qp, smp, None))
+                continue
+            if r_end == motion_len:
+                r_end = motion_len - 1
+                r_start = max(0, r_start - 1)
+            r_lat_start, r_lat_end = r_start // chunk, r_end // chunk + 1
+            mid_lat = ((q_start + q_end) // 2) // chunk
+            n = r_lat_end - r_lat_start
+            side = n // 2
+            if n == 1:
+                s, e = mid_lat - side, mid_lat + side + 1
+            elif n == 2:
+                s, e = mid_lat, mid_lat + side + 1
+            elif n % 2 == 1:
+                s, e = mid_lat - side - 1, mid_lat + side
+            else:
+                s, e = mid_lat - side, mid_lat + side
+            if s < 0:
+                s, e = 0, n
+            if e > latent_len:
+                s -= e - latent_len
+                e = latent_len
+            if s < prev_end:
+                s = prev_end
+                e = s + n
+                if e > latent_len:
+                    e = latent_len
+                    n = e - s
+                    if n <= 0:
+                        out.append((qp, smp, None))
+                        continue
+                    r_lat_end = r_lat_start + n
+            prev_end = e
+            out.append((qp, smp, ((r_lat_start, r_lat_end), (s, e))))
+    return out
+
+
+class RetrievalDatabase:
+    """Drop-in for raggesture.py:157-884 `RetrievalDatabase` (inference, `discourse` method).
+
+    `dataset[name]` must return the per-sample dict the reference reads (motion, motion_upper/lower/
+    face/hands, facial, trans, contact, motion_mask, word, audio, speaker_id).  DB metadata comes
+    from `metadata` (dict of idx_2_text / idx_2_sense / idx_2_discbounds / idx_2_prominence) or from
+    `dataset.retrieval_samples` (raw records, see build_db_dicts)."""
+
+    def __init__(self, num_retrieval=None, topk=None, latent_dim=512, text_latent_dim=768, max_seq_len=150,
+                 motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", **_cfg):
+        if metadata is None:
+            samples = getattr(dataset, "retrieval_samples", None)
+            if samples is None:
+                raise capi.RgError("RetrievalDatabase needs `metadata=` or `dataset.retrieval_samples` "
+                                   "(the reference's LMDB caches cannot be read here: lmdb is not installed)")
+            metadata = build_db_dicts(samples)
+        self.dataset = dataset
+        self.num_retrieval, self.topk = num_retrieval or 1, topk
+        self.max_seq_len, self.motion_fps, self.motion_framechunksize = max_seq_len, motion_fps, motion_framechunksize
+        self.latent_dim, self.text_latent_dim = latent_dim, text_latent_dim
+        self.index = DiscourseIndex(metadata, device)
+        self.test_indexes, self.test_dbounds, self.test_qbounds = {}, {}, {}
+
+    def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None):
+        """raggesture.py:313-477 (eval branch, first-call behaviour; results cached per idx)."""
+        if retr_method != "discourse":
+            raise NotImplementedError("only the discourse retrieval method is built (llm / gesture_type: next)")
+        if idx is not None and idx in self.test_indexes and retr_method in self.test_indexes[idx]:
+            si, db_b, qb = (self.test_indexes[idx][retr_method], self.test_dbounds[idx][retr_method],
+                            self.test_qbounds[idx][retr_method])
+        else:
+            si, db_b, qb = discourse_retrieval(self.index, discourse, prominence, speaker_id, text_features)
+            self.test_indexes.setdefault(idx, {})[retr_method] = si
+            self.test_dbounds.setdefault(idx, {})[retr_method] = db_b
+            self.test_qbounds.setdefault(idx, {})[retr_method] = qb
+        data = {q: [s for s in idxs if s != idx][:self.num_retrieval] for q, idxs in si.items()}
+        return data, db_b, qb
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, conditions, lengths, device, idx=None, retrieval_method="gesture_type", gesture_rep_encoder=None,
+                noise=None):
+        """conditions: the model's kwargs dict (text_features, discourse, prominence, speaker_ids, ...)."""
+        gre = gesture_rep_encoder
+        dev = torch.device(device)
+        B = len(conditions["text_features"])
+        chunk, L = self.motion_framechunksize, self.max_seq_len // self.motion_framechunksize
+        T, D = 4 * L + 3, self.latent_dim
+        plans, ex = [], []
+        for b in range(B):
+            spk = int(conditions["speaker_ids"][b, 0].item())
+            ri, rb, qb = self.retrieve(retrieval_method, conditions["text_features"][b], conditions["discourse"][b],
+                                       conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None)
+            plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
+            plans.append((plan, rb, qb))
+            for qp, name, placed in plan:
+                ex.append((b, qp, name, placed))
+        # ---- fetch + VAE-encode every visited exemplar in one batch (noise in the reference's order)
+        recs = [self.dataset[name] for _, _, name, _ in ex]
+        lat = None
+        if ex:
+            E = len(ex)
+            stack = lambda k: torch.stack([r[k] for r in recs]).to(dev).float().contiguous()
+            draw = (lambda shape: noise.draw(shape)) if noise is not None else (lambda shape: torch.randn(*shape, device=dev))
+            eps = [[draw((L, 1, D)) for _ in range(4)] for _ in range(E)]
+            eps_list = [torch.cat([e[p].to(dev) for e in eps], dim=0) for p in range(4)]
+            lat, _ = gre.encode(stack("motion_upper"), stack("motion_lower"), stack("motion_face"), stack("motion_hands"),
+                                stack("trans"), stack("facial"), stack("contact"), stack("motion_mask"), eps_list)
+        retr_se, query_se, retr_lats, names_out, type2words = ([{} for _ in range(B)] for _ in range(5))
+        zero_motion = torch.zeros(B, T, D, device=dev)
+        tmpl = self.dataset[0] if self.dataset is not None else None
+        raw_motion = torch.zeros(B, self.max_seq_len, tmpl["motion"].shape[-1], device=dev)
+        raw_trans = torch.zeros(B, self.max_seq_len, tmpl["trans"].shape[-1], device=dev)
+        raw_facial = torch.zeros(B, self.max_seq_len, tmpl["facial"].shape[-1], device=dev)
+        for e, (b, qp, name, placed) in enumerate(ex):
+            if placed is None:
+                continue
+            (r0, r1), (s0, s1) = placed
+            rec, (plan, rb, qb) = recs[e], plans[b]
+            retr_se[b][qp], query_se[b][qp] = (r0, r1), (s0, s1)
+            retr_lats[b][qp] = dict(retr_motion_latent=lat[e:e + 1], retr_text=rec["word"].unsqueeze(0).to(dev),
+                                    retr_audio=rec["audio"].unsqueeze(0).to(dev),
+                                    retr_spkid=rec["speaker_id"].unsqueeze(0).to(dev),
+                                    retr_motion_mask=gre.latent_mask(rec["motion_mask"].unsqueeze(0)))
+            for part in range(4):
+                o = part * (L + 1)
+                zero_motion[b, o + s0:o + s1] = lat[e, o + r0:o + r1]
+            f0, f1, g0, g1 = s0 * chunk, s1 * chunk, r0 * chunk, r1 * chunk
+            raw_motion[b, f0:f1] = rec["motion"].to(dev)[g0:g1]
+            raw_trans[b, f0:f1] = rec["trans"].to(dev)[g0:g1]
+            raw_facial[b, f0:f1] = rec["facial"].to(dev)[g0:g1]
+            q_word, q_type = qb[qp][0], qb[qp][1]
+            r_word, r_type = rb[qp][name][0], rb[qp][name][1]
+            type2words[b][qp] = (q_word, q_type, r_word, r_type)
+            names_out[b][q_word] = name
+        src_mask = (zero_motion != 0).any(dim=-1).to(torch.int)
+        raw_latent_mask = src_mask.clone()
+        raw_motion_latents = zero_motion.clone()
+        fl = list(range(2 * L + 2, 3 * L + 2)) + list(range(3 * L + 3, T))
+        src_mask[:, fl] = 0
+        raw_motion_latents[:, fl, :] = 0
+        return dict(re_text=None, re_motion=None, re_mask=src_mask,
+                    raw_motion_latents=raw_motion_latents.view(B, self.num_retrieval, T, D),
+                    raw_motion=raw_motion.view(B, self.num_retrieval, self.max_seq_len, -1),
+                    raw_trans=raw_trans.view(B, self.num_retrieval, self.max_seq_len, -1),
+                    raw_facial=raw_facial.view(B, self.num_retrieval, self.max_seq_len, -1),
+                    raw_sample_names=names_out, raw_type2words=type2words, raw_latent_mask=raw_latent_mask,
+                    retr_startends=retr_se, query_startends=query_se, retr_uncropped_latents=retr_lats)

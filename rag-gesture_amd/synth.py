@@ -279,3 +279,82 @@ def reference_style_model_cfg(cfg=None, vae_cfgs=None, inference_type="ddim"):
                             classifier_free_guidance_scale=0),
         inference_type=inference_type,
     )
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic retrieval database (discourse relations, prominence, BERT-like token features)
+SENSES = ("Contingency.Cause", "Comparison.Contrast", "Expansion.Conjunction", "Temporal.Synchronous")
+_BASE_CONNS = ("and", "but", "because", "so", "when", "while", "then", "also", "however", "although",
+               "as well", "in fact", "for example", "after", "before", "since", "if", "or", "yet", "still")
+
+
+def connective_vocab(n=50):
+    out = list(_BASE_CONNS)
+    i = 0
+    while len(out) < n:
+        out.append("conn%02d" % i)
+        i += 1
+    return out[:n]
+
+
+def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, tie_groups=True):
+    """Raw per-sample records with the fields the reference's DB builder reads
+    (raggesture.py:244-293): sample_name, speaker_id, discourse (8-tuples
+    (conn, sense, arg1, arg2, start, end, conn_start, conn_end), beatx_dataset.py:1082-1093),
+    prominence ((word, start, end, value)), text_feature [L, feat_dim].  Returned sorted by
+    sample_name (the LMDB cursor order the reference iterates in)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    conns = connective_vocab()
+    recs = []
+    for i in range(n_entries):
+        spk = int(g.integers(0, n_speakers))
+        name = "%d_spk%02d_%d_%d/%d" % (spk, spk, int(g.integers(0, 3)), i, int(g.integers(0, 40)) * 15)
+        nrel = int(g.integers(0, 5))
+        disc, prom = [], []
+        if tie_groups and i % 5 == 0:           # forced ties: identical categorical signature, no prominence
+            nrel, spk = 1, 3
+        t = 0.2
+        for r in range(nrel):
+            conn = conns[int(g.integers(0, len(conns)))] if not (tie_groups and i % 5 == 0) else "because"
+            sense = SENSES[int(g.integers(0, len(SENSES)))] if not (tie_groups and i % 5 == 0) else SENSES[0]
+            cs = t + float(g.uniform(0.0, 1.5))
+            ce = cs + float(g.uniform(0.15, 0.6))
+            t = ce
+            disc.append((conn, sense, "arg1 text", "arg2 text", max(0.0, cs - 1.0), ce + 1.0, cs, ce))
+            if not (tie_groups and i % 5 == 0) and g.uniform() < 0.75:   # prominence known for most connectives
+                words = conn.split()
+                dur = (ce - cs) / len(words)
+                for wi, w in enumerate(words):
+                    prom.append((w, cs + wi * dur, cs + (wi + 1) * dur, float(g.uniform(0, 3))))
+        # some unrelated prominence words in between (at least one: the reference's
+        # map_conns_to_prominence traps on an empty prominence list)
+        for _ in range(int(g.integers(1, 3))):
+            prom.append(("filler%d" % int(g.integers(0, 9)), float(g.uniform(0, 9)), float(g.uniform(0, 9)), float(g.uniform(0, 3))))
+        prom.sort(key=lambda p: p[1])
+        L = int(g.integers(8, 49))
+        feat = torch.from_numpy(g.standard_normal((L, feat_dim)).astype(np.float32))
+        recs.append(dict(sample_name=name, speaker_id=spk, discourse=disc, prominence=prom, text_feature=feat))
+    recs.sort(key=lambda r: r["sample_name"])
+    return recs
+
+
+def synth_query(seed, n_rel=3, n_speakers=25, feat_dim=768):
+    g = np.random.Generator(np.random.PCG64(seed))
+    conns = connective_vocab()
+    disc, prom = [], []
+    t = 0.3
+    for r in range(n_rel):
+        conn = conns[int(g.integers(0, len(conns)))] if r else "because"
+        sense = SENSES[int(g.integers(0, len(SENSES)))] if r else SENSES[0]
+        cs = t + float(g.uniform(0.2, 2.0))
+        ce = cs + float(g.uniform(0.15, 0.6))
+        t = ce
+        disc.append((conn, sense, "a1", "a2", max(0.0, cs - 1.0), ce + 1.0, cs, ce))
+        if r != 1:
+            words = conn.split()
+            dur = (ce - cs) / len(words)
+            for wi, w in enumerate(words):
+                prom.append((w, cs + wi * dur, cs + (wi + 1) * dur, float(g.uniform(0, 3))))
+    L = int(g.integers(12, 49))
+    return dict(discourse=disc, prominence=prom, speaker_id=3 if seed % 2 == 0 else int(g.integers(0, n_speakers)),
+                text_features=torch.from_numpy(g.standard_normal((L, feat_dim)).astype(np.float32)))

@@ -165,7 +165,96 @@ def main():
             vkw = dict(num_layers=4, ff_size=512) if arch == "encoder_decoder" else {}
             vae_cfgs = synth.synth_vae_cfgs(decoder_arch=arch, **vkw)
             model, full = build_reference_model(ns, cfg, vae_cfgs, seed=0, tmpdir=os.path.join(tmp, tag))
-            run_model_goldens(ns, model, full, cfg, vae_cfgs, tag)
+            if "--retrieval-only" not in sys.argv:
+                run_model_goldens(ns, model, full, cfg, vae_cfgs, tag)
+            if tag == "L2_allenc":
+                run_retrieval_goldens(ns, model, tag)
+
+
+class _FakeDataset:
+    """dataset[name] -> the per-sample dict RetrievalDatabase.forward reads (raggesture.py:558-570)."""
+
+    def __init__(self, names):
+        self.names = list(names)
+
+    def __getitem__(self, key):
+        name = self.names[0] if isinstance(key, int) else key
+        import zlib
+        d = synth.synth_batch(1, seed=zlib.crc32(name.encode()) & 0x7FFFFFFF)
+        out = {k: d[k][0] for k in ("motion", "motion_upper", "motion_lower", "motion_face", "motion_hands", "facial",
+                                    "trans", "contact", "motion_mask", "word", "audio")}
+        out["speaker_id"] = d["speaker_ids"][0]
+        out["sample_name"] = name
+        return out
+
+
+def run_retrieval_goldens(ns, model, tag):
+    """Real reference: discourse_retrieval on a synthetic DB with forced ties, then the whole
+    RetrievalDatabase.forward (selection, exemplar VAE encode with taped noise, placement)."""
+    import json
+    from oracle import retrieval as oret
+    RD = ns.raggesture.RetrievalDatabase
+    samples = synth.synth_retrieval_samples(200, seed=2025)
+    names = [s["sample_name"] for s in samples]
+    # DB dicts built with the REFERENCE's own map_conns_to_prominence (raggesture.py:255-276)
+    db = dict(idx_2_text={}, idx_2_sense={}, idx_2_discbounds={}, idx_2_prominence={})
+    for smp in samples:
+        n, spk = smp["sample_name"], smp["speaker_id"]
+        db["idx_2_text"][n] = (smp["text_feature"], spk)
+        db["idx_2_sense"][n] = [spk] + [(d[1], d[0]) for d in smp["discourse"]]
+        db["idx_2_discbounds"][n] = [(d[1], d[0], d[4], d[5], d[6], d[7]) for d in smp["discourse"]]
+        db["idx_2_prominence"][n] = ns.rag_utils.map_conns_to_prominence([d[0] for d in smp["discourse"]], smp["prominence"])
+    mine = oret.build_db_dicts(samples)
+    assert mine["idx_2_prominence"] == db["idx_2_prominence"] and mine["idx_2_sense"] == db["idx_2_sense"]
+    gold = {"queries": []}
+    for qseed in (11, 12, 13, 14):
+        q = synth.synth_query(qseed)
+        si, db_b, qb = ns.discourse.discourse_retrieval(
+            text=None, discourse=q["discourse"], prominence=q["prominence"], speaker_id=q["speaker_id"],
+            db_idx_2_sense=db["idx_2_sense"], db_idx_2_discbounds=db["idx_2_discbounds"],
+            db_idx_2_prominence=db["idx_2_prominence"], encoded_text=q["text_features"], text_feat_cache=db["idx_2_text"])
+        osi, odb, oqb = oret.discourse_retrieval(q["discourse"], q["prominence"], q["speaker_id"], mine, q["text_features"])
+        assert osi == si and odb == db_b and oqb == qb, "oracle retrieval != reference"
+        gold["queries"].append(dict(seed=qseed, sample_indexes={str(k): v for k, v in si.items()},
+                                    d_bounds={str(k): {n: list(b) for n, b in v.items()} for k, v in db_b.items()},
+                                    query_bounds={str(k): list(v) for k, v in qb.items()}))
+    print(tag, "discourse_retrieval oracle == reference on 4 queries; tie sizes:",
+          [len(v) for v in gold["queries"][0]["sample_indexes"].values()])
+    # ---- whole RetrievalDatabase.forward
+    rdb = object.__new__(RD)
+    torch.nn.Module.__init__(rdb)
+    rdb.retrieval_method = {"discourse": ns.discourse.discourse_retrieval}
+    rdb.idx_2_text, rdb.idx_2_sense = db["idx_2_text"], db["idx_2_sense"]
+    rdb.idx_2_discbounds, rdb.idx_2_prominence = db["idx_2_discbounds"], db["idx_2_prominence"]
+    rdb.train_indexes, rdb.train_dbounds, rdb.train_qbounds = {}, {}, {}
+    rdb.test_indexes, rdb.test_dbounds, rdb.test_qbounds = {}, {}, {}
+    rdb.num_retrieval, rdb.topk, rdb.max_seq_len, rdb.motion_framechunksize, rdb.motion_fps = 1, 2, 150, 15, 15
+    rdb.latent_dim, rdb.text_latent_dim, rdb.dataset = 512, 768, _FakeDataset(names)
+    rdb.eval()
+    B = 2
+    qs = [synth.synth_query(21), synth.synth_query(22)]
+    data = synth.synth_batch(B, seed=99)
+    own = ["query_clip_a", names[7]]  # second query pretends to be DB sample 7 (self-exclusion path)
+    cond = dict(text=[None] * B, audio=[None] * B, text_enc=data["word"], text_features=[q["text_features"] for q in qs],
+                audio_enc=data["audio"], discourse=[q["discourse"] for q in qs], prominence=[q["prominence"] for q in qs],
+                speaker_ids=torch.tensor([[q["speaker_id"]] * 150 for q in qs]), gesture_labels=[[], []], text_times=[[], []])
+    with torch.no_grad(), taped_noise(synth.NoiseTape(4242)):
+        re = rdb(cond, [150] * B, "cpu", idx=own, retrieval_method="discourse", gesture_rep_encoder=model.model.gesture_rep_encoder)
+    gold["forward"] = []
+    lat = {}
+    for b in range(B):
+        ent = dict(own=own[b], retr_startends={str(k): list(v) for k, v in re["retr_startends"][b].items()},
+                   query_startends={str(k): list(v) for k, v in re["query_startends"][b].items()},
+                   names={str(k): v for k, v in re["raw_sample_names"][b].items()} if isinstance(re["raw_sample_names"][b], dict) else None)
+        gold["forward"].append(ent)
+        for k, v in re["retr_uncropped_latents"][b].items():
+            lat["lat_%d_%d" % (b, k)] = t2n(v["retr_motion_latent"])
+            lat["spk_%d_%d" % (b, k)] = t2n(v["retr_spkid"])
+    gold["test_indexes"] = {n: {m: {str(k): v for k, v in d.items()} for m, d in e.items()} for n, e in rdb.test_indexes.items()}
+    with open(os.path.join(HERE, "retrieval_%s.json" % tag), "w") as f:
+        json.dump(gold, f, indent=1)
+    np.savez(os.path.join(HERE, "retrieval_%s.npz" % tag), **lat)
+    print(tag, "RetrievalDatabase.forward golden:", [(e["retr_startends"], e["query_startends"]) for e in gold["forward"]])
 
 
 def run_model_goldens(ns, model, full, cfg, vae_cfgs, tag):

@@ -1,0 +1,148 @@
+"""Retrieval: the oracle against the real reference's golden results (CPU), and the HIP sweep +
+host tier walk against both (GPU).  Retrieval indices must match bit-exactly."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import retrieval as oret
+
+
+def _golden(golden_dir):
+    with open(os.path.join(golden_dir, "retrieval_L2_allenc.json")) as f:
+        return json.load(f)
+
+
+def _db(rg, n=200):
+    return rg.synth.synth_retrieval_samples(n, seed=2025)
+
+
+def _unpack(q):
+    si = {int(k): v for k, v in q["sample_indexes"].items()}
+    db = {int(k): {n: tuple(b) for n, b in v.items()} for k, v in q["d_bounds"].items()}
+    qb = {int(k): tuple(v) for k, v in q["query_bounds"].items()}
+    return si, db, qb
+
+
+def test_oracle_discourse_retrieval_matches_reference(rg, golden_dir):
+    g = _golden(golden_dir)
+    db = oret.build_db_dicts(_db(rg))
+    for q in g["queries"]:
+        qq = rg.synth.synth_query(q["seed"])
+        si, dbb, qb = oret.discourse_retrieval(qq["discourse"], qq["prominence"], qq["speaker_id"], db, qq["text_features"])
+        gsi, gdb, gqb = _unpack(q)
+        assert si == gsi and dbb == gdb and qb == gqb
+    assert any(len(set(v)) == 10 for v in _unpack(g["queries"][0])[0].values())
+
+
+def test_product_host_logic_matches_oracle(rg):
+    """map_conns_to_prominence / build_db_dicts / place_exemplars of the product == the oracle's."""
+    smp = _db(rg, 120)
+    a, b = oret.build_db_dicts(smp), rg.retrieval.build_db_dicts(smp)
+    assert a["idx_2_prominence"] == b["idx_2_prominence"] and a["idx_2_sense"] == b["idx_2_sense"]
+    assert a["idx_2_discbounds"] == b["idx_2_discbounds"]
+    g = np.random.Generator(np.random.PCG64(5))
+    for _ in range(300):
+        ri, rb, qb = {}, {}, {}
+        for qp in range(int(g.integers(1, 5))):
+            qs = float(g.uniform(0.3, 9.9))
+            qe = qs + float(g.uniform(-0.2, 2.0))
+            rs = float(g.uniform(0, 10))
+            re = rs + float(g.uniform(0.0, 3.0))
+            ri[qp] = ["s%d" % qp] if g.uniform() > 0.1 else []
+            qb[qp] = ("w", "t", qs, qe)
+            rb[qp] = {"s%d" % qp: ("w", "t", round(rs, 3), round(min(re, 10.0), 3))}
+        for method in ("discourse", "llm"):
+            want = oret.place_exemplars(ri, rb, qb, method)
+            got = {qp: (n, p[0], p[1]) for qp, n, p in rg.retrieval.place_exemplars(ri, rb, qb, method) if p is not None}
+            assert want == got
+
+
+def test_oracle_placement_matches_reference_forward(rg, golden_dir):
+    g = _golden(golden_dir)
+    for b, ent in enumerate(g["forward"]):
+        own = ent["own"]
+        t = g["test_indexes"][own]["discourse"]
+        qq = rg.synth.synth_query(21 + b)
+        db = oret.build_db_dicts(_db(rg))
+        si, dbb, qb = oret.discourse_retrieval(qq["discourse"], qq["prominence"], qq["speaker_id"], db, qq["text_features"])
+        assert {str(k): v for k, v in si.items()} == t
+        sel = oret.select_retrieved(si, own, 1)
+        placed = oret.place_exemplars(sel, dbb, qb, "discourse")
+        assert {str(k): list(v[1]) for k, v in placed.items()} == ent["retr_startends"]
+        assert {str(k): list(v[2]) for k, v in placed.items()} == ent["query_startends"]
+
+
+class _FakeDataset:
+    def __init__(self, rg, samples):
+        self.rg, self.names, self.retrieval_samples = rg, [s["sample_name"] for s in samples], samples
+
+    def __getitem__(self, key):
+        name = self.names[0] if isinstance(key, int) else key
+        d = self.rg.synth.synth_batch(1, seed=zlib.crc32(name.encode()) & 0x7FFFFFFF)
+        out = {k: d[k][0] for k in ("motion", "motion_upper", "motion_lower", "motion_face", "motion_hands", "facial",
+                                    "trans", "contact", "motion_mask", "word", "audio")}
+        out["speaker_id"] = d["speaker_ids"][0]
+        out["sample_name"] = name
+        return out
+
+
+@pytest.mark.gpu
+def test_hip_sweep_matches_reference_golden(rg, golden_dir):
+    g = _golden(golden_dir)
+    index = rg.retrieval.DiscourseIndex(rg.retrieval.build_db_dicts(_db(rg)), "cuda")
+    for q in g["queries"]:
+        qq = rg.synth.synth_query(q["seed"])
+        si, dbb, qb = rg.retrieval.discourse_retrieval(index, qq["discourse"], qq["prominence"], qq["speaker_id"],
+                                                       qq["text_features"])
+        gsi, gdb, gqb = _unpack(q)
+        assert si == gsi, "retrieval indices differ from the reference"
+        assert dbb == gdb and qb == gqb
+
+
+@pytest.mark.gpu
+def test_hip_sweep_matches_oracle_large_db(rg):
+    """4096-entry DB, 12 queries: scores are bit-identical float64, indices exact."""
+    smp = rg.synth.synth_retrieval_samples(4096, seed=7)
+    db = oret.build_db_dicts(smp)
+    index = rg.retrieval.DiscourseIndex(rg.retrieval.build_db_dicts(smp), "cuda")
+    for seed in range(100, 112):
+        qq = rg.synth.synth_query(seed)
+        want = oret.discourse_retrieval(qq["discourse"], qq["prominence"], qq["speaker_id"], db, qq["text_features"])
+        got = rg.retrieval.discourse_retrieval(index, qq["discourse"], qq["prominence"], qq["speaker_id"], qq["text_features"])
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+
+
+@pytest.mark.gpu
+def test_retrieval_database_forward_vs_reference(rg, golden_dir):
+    g = _golden(golden_dir)
+    lat = np.load(os.path.join(golden_dir, "retrieval_L2_allenc.npz"))
+    samples = _db(rg)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    P = {}
+    for i, part in enumerate(rg.synth.PARTS):
+        P.update(rg.synth.synth_vae_state(101 + i, vae_cfgs[part], prefix="gesture_rep_encoder.%s_vae." % part))
+    gre = rg.vae.GestureRepEncoder(P, vae_cfgs, "cuda", "fp32")
+    rdb = rg.retrieval.RetrievalDatabase(num_retrieval=1, dataset=_FakeDataset(rg, samples), device="cuda")
+    qs = [rg.synth.synth_query(21), rg.synth.synth_query(22)]
+    own = [e["own"] for e in g["forward"]]
+    cond = dict(text_features=[q["text_features"] for q in qs], discourse=[q["discourse"] for q in qs],
+                prominence=[q["prominence"] for q in qs],
+                speaker_ids=torch.tensor([[q["speaker_id"]] * 150 for q in qs]))
+    re = rdb(cond, [150, 150], "cuda", idx=own, retrieval_method="discourse", gesture_rep_encoder=gre,
+             noise=rg.synth.NoiseTape(4242))
+    for b, ent in enumerate(g["forward"]):
+        assert {str(k): list(v) for k, v in re["retr_startends"][b].items()} == ent["retr_startends"]
+        assert {str(k): list(v) for k, v in re["query_startends"][b].items()} == ent["query_startends"]
+        assert re["raw_sample_names"][b] == ent["names"]
+        for k, v in re["retr_uncropped_latents"][b].items():
+            ref = torch.from_numpy(lat["lat_%d_%d" % (b, k)])
+            err = ((v["retr_motion_latent"].cpu() - ref).norm() / ref.norm()).item()
+            assert err <= 1e-3, "exemplar latent (VAE encode with taped noise) differs: %g" % err
+            assert torch.equal(v["retr_spkid"].cpu(), torch.from_numpy(lat["spk_%d_%d" % (b, k)]))
+    # the raw_motion_latents template carries upper+hands rows only (raggesture.py:856-857)
+    rml = re["raw_motion_latents"]
+    assert rml.shape == (2, 1, 43, 512) and rml[:, :, 22:].abs().max() == 0
