@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--workload", choices=["guided", "base"], default="guided")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 16 guided, 32 base)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--db-size", type=int, default=32768, help="retrieval DB entries (guided workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,20 +86,29 @@ def main():
     B = args.batch or (16 if args.workload == "guided" else 32)
     cfg = rg.synth.default_model_cfg(num_layers=8)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
-    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs), database=None, device=dev)
+    guided = args.workload == "guided"
+    # guided: the retrieval DB (discourse metadata + token features) is replicated on every GPU
+    database = rg.synth.SyntheticDataset(args.db_size, seed=2025, device=dev, feat_device=dev) if guided else None
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=guided),
+                                  database=database, device=dev)
     model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
     model.eval()
 
     data = rg.synth.synth_batch(B, seed=1234 + rank, device=dev)
-    re_dict = make_re_dict(B, 77 + rank, dev) if args.workload == "guided" else None
+    if guided:  # per-clip discourse relations / prominence / BERT token features (3 relations per query)
+        qs = [rg.synth.synth_query(1000 * rank + i) for i in range(B)]
+        data["discourse"] = [q["discourse"] for q in qs]
+        data["prominence"] = [q["prominence"] for q in qs]
+        data["text_features"] = [q["text_features"].to(dev) for q in qs]
+        data["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
     trans0 = data["trans"].clone()
 
     def one_step():
         d = dict(data)
         d["trans"] = trans0.clone()  # forward re-zeroes trans in place like the reference
         ikw = {}
-        if args.workload == "guided":
-            d["re_dict"] = re_dict
+        if guided:
+            model.model.database.test_indexes.clear()  # no cross-step caching of retrieval results
             ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
         out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
         packed = torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
@@ -153,7 +163,7 @@ def main():
     # ---- CPU baseline: the oracle (faithful port of the reference) on a bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pipeline as opipe, diffusion as odf
+        from oracle import pipeline as opipe, diffusion as odf, retrieval as oret
         try:
             cores = len(os.sched_getaffinity(0))
         except AttributeError:
@@ -163,13 +173,21 @@ def main():
         P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
         cdata = rg.synth.synth_batch(1, seed=1234)
         ckw, cre = {}, None
-        if args.workload == "guided":
-            cre = opipe.synthetic_re_dict(1, seed=77)
+        tape = rg.synth.NoiseTape(1)
+        if guided:
+            cpu_db = oret.build_db_dicts([dict(r, text_feature=r["text_feature"].cpu()) for r in database.retrieval_samples])
+            cpu_ds = rg.synth.SyntheticDataset(0)
+            q0 = rg.synth.synth_query(0)
+            ccond = dict(text_features=[q0["text_features"]], discourse=[q0["discourse"]], prominence=[q0["prominence"]],
+                         speaker_ids=torch.tensor([[q0["speaker_id"]] * 150]))
             ckw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
         tc = time.perf_counter()
         with torch.no_grad():
-            opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, rg.synth.NoiseTape(1),
-                                           re_dict=cre, **ckw)
+            if guided:  # sweep over the same DB + exemplar encode + placement, as the reference does per clip
+                cre = lambda tp: oret.database_forward(P, vae_cfgs, cpu_db, cpu_ds, ccond, ["bench_query"], tp)
+                opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, tape, re_dict=cre, **ckw)
+            else:
+                opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, tape, re_dict=None)
         tc = time.perf_counter() - tc
         cpu = {"value": round(150.0 / tc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
                "sample": "1 clip (150 frames), same workload (%s), torch fp32 on %d host threads, %.1f s"
@@ -181,8 +199,9 @@ def main():
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("guided discourse-style config: use_inversion + insertion_guidance "
-                                    "decreasing_till_25, 2 exemplars/clip, len150 DDIM-50"
+            "config": {"workload": ("guided discourse config: discourse retrieval over a replicated %d-entry DB, "
+                                    "use_inversion + insertion_guidance decreasing_till_25, <=3 exemplars/clip, "
+                                    "len150 DDIM-50" % args.db_size
                                     if args.workload == "guided" else "base diffusion len150 DDIM-50 (no guidance)"),
                        "clips_per_gpu": B, "global_batch": world * B, "frames_per_clip": 150, "ddim_steps": 50,
                        "denoiser": "8 layers x 512, CFG x2 rows", "vae": "all_encoder, 8 layers, synthetic hparams",

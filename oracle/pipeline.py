@@ -37,6 +37,8 @@ def motion_diffusion_forward(P, cfg, vae_cfgs, sch, data, tape, re_dict=None, us
     up_i, ha_i, fa_i, lt_i = part_indices(T)
     qm = od.make_query_masks(motion_mask)
     xf = od.encode_conditions(P, data["word"], data["audio"], data["speaker_ids"], cfg["num_speakers"])
+    if callable(re_dict):  # RetrievalDatabase.forward runs here in the reference (its rsample draws come now)
+        re_dict = re_dict(tape)
 
     def model_fn(xf_, qm_, mm_):
         return lambda x, t: od.denoiser_forward(P, cfg, x, t, mm_, xf_, qm_)

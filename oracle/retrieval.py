@@ -206,3 +206,38 @@ def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="d
             prev_end = e
             out[qp] = (smp, (r_lat_start, r_lat_end), (s, e))
     return out
+
+
+def database_forward(P, vae_cfgs, db, dataset, conditions, own_names, tape, retrieval_method="discourse"):
+    """reference: RetrievalDatabase.forward (raggesture.py:479-884), the parts the sampler consumes:
+    per clip retrieve -> select -> fetch + VAE-encode each visited exemplar (4 rsample draws each, in
+    visiting order, even when the exemplar is skipped afterwards) -> placement -> re_dict."""
+    from . import vae as ovae
+    B = len(conditions["text_features"])
+    retr_se, query_se, lats = [], [], []
+    for b in range(B):
+        spk = int(conditions["speaker_ids"][b, 0].item())
+        si, dbb, qb = discourse_retrieval(conditions["discourse"][b], conditions["prominence"][b], spk, db,
+                                          conditions["text_features"][b])
+        sel = select_retrieved(si, own_names[b], 1)
+        rs, qs, ls = {}, {}, {}
+        # visiting order and skip rules as in place_exemplars, but the encode happens before the skips
+        visited = []
+        for qp, smp_idxs in sel.items():
+            if len(smp_idxs) == 0 or qp not in qb or qb[qp][2] > qb[qp][3]:
+                continue
+            visited.append((qp, smp_idxs[0]))
+        placed = place_exemplars(sel, dbb, qb, retrieval_method)
+        for qp, name in visited:
+            rec = dataset[name]
+            data = {k: rec[k].unsqueeze(0).clone() for k in ("motion_upper", "motion_lower", "motion_face", "motion_hands",
+                                                             "facial", "trans", "contact", "motion_mask")}
+            eps = [tape.draw((10, 1, 512)) for _ in range(4)]
+            lat, mask = ovae.gesture_encode(P, vae_cfgs, data, eps)
+            if qp in placed:
+                _, r, q = placed[qp]
+                rs[qp], qs[qp] = r, q
+                ls[qp] = dict(retr_motion_latent=lat, retr_text=rec["word"].unsqueeze(0), retr_audio=rec["audio"].unsqueeze(0),
+                              retr_spkid=rec["speaker_id"].unsqueeze(0), retr_motion_mask=mask)
+        retr_se.append(rs), query_se.append(qs), lats.append(ls)
+    return dict(retr_startends=retr_se, query_startends=query_se, retr_uncropped_latents=lats)

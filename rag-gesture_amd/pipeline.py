@@ -60,7 +60,8 @@ class ReGestureTransformer:
                  use_retrieval_for_test=False, input_feats=None, max_seq_len=240, frame_chunk_size=16,
                  latent_dim=512, time_embed_dim=2048, num_layers=8, sa_block_cfg=None, ca_block_cfg=None,
                  vae_cfg=None, ffn_cfg=None, text_encoder=None, audio_encoder=None, speaker_embedding=None,
-                 use_cache_for_text=False, init_cfg=None, body_part_cat_axis="time", database=None, **_unused):
+                 use_cache_for_text=False, init_cfg=None, body_part_cat_axis="time", database=None, device="cuda",
+                 **_unused):
         assert not retrieval_train
         assert body_part_cat_axis == "time", "Only time axis is supported for body part categorization"
         for enc in (text_encoder, audio_encoder):
@@ -81,7 +82,7 @@ class ReGestureTransformer:
         self.database = None
         if retrieval_cfg is not None and use_retrieval_for_test:
             from . import retrieval
-            self.database = retrieval.RetrievalDatabase(**retrieval_cfg, dataset=database)
+            self.database = retrieval.RetrievalDatabase(**retrieval_cfg, dataset=database, device=device)
         self.weights = self.gesture_rep_encoder = None
 
     @staticmethod
@@ -109,7 +110,7 @@ class MotionDiffusion:
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", **kwargs):
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
-        self.model = build_submodule(model, **kwargs)
+        self.model = build_submodule(model, device=device, **kwargs)
         dt = dict(diffusion_test)
         self.schedule = sched_mod.Schedule(beta_scheduler=dt["beta_scheduler"], diffusion_steps=dt["diffusion_steps"],
                                            respace=dt.get("respace"))

@@ -145,7 +145,14 @@ def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text):
     for qi, (q_sense, q_conn) in enumerate(zip(senses, conns)):
         qp = q_prom[qi]
         score, top = index.scores(q_sense, q_conn, speaker_id, None if qp is None else qp[1])
-        order = np.argsort(-score, kind="stable")  # == sorted(..., reverse=True): stable among equals
+        # Only the top tiers are ever visited (the walk stops at 10 entries): keep the entries whose score
+        # reaches the 10th largest one, then order them like sorted(..., reverse=True) (stable among equals).
+        if score.shape[0] > 64:
+            kth = np.partition(score, score.shape[0] - 10)[score.shape[0] - 10]
+            keep = np.flatnonzero((score >= kth) & (score > 0))
+        else:
+            keep = np.arange(score.shape[0])
+        order = keep[np.argsort(-score[keep], kind="stable")]
         ranked, i = [], 0
         while i < len(order) and len(ranked) < 10:
             sc = score[order[i]]

@@ -244,7 +244,7 @@ def synth_batch(batch, seed=1234, device="cpu"):
     return d
 
 
-def reference_style_model_cfg(cfg=None, vae_cfgs=None, inference_type="ddim"):
+def reference_style_model_cfg(cfg=None, vae_cfgs=None, inference_type="ddim", with_retrieval=False):
     """`cfg.model` in the layout of configs/raggesture_beatx/basegesture_len150_beat.py:45-160, with the
     VAE YAML paths replaced by the hyper-parameter dicts themselves and `per_joint_scale` supplied
     (SURVEY F6)."""
@@ -267,7 +267,12 @@ def reference_style_model_cfg(cfg=None, vae_cfgs=None, inference_type="ddim"):
                               ff_size=2048, dropout=0, use_text_proj=False),
             audio_encoder=dict(pretrained_model=None, latent_dim=cfg["text_latent_dim"], num_layers=0, dropout=0.1),
             speaker_embedding=dict(num_speakers=cfg["num_speakers"]),
-            retrieval_train=False, retrieval_cfg=None,
+            retrieval_train=False,
+            retrieval_cfg=(dict(motion_feat_dim=189, num_retrieval=1, topk=2, latent_dim=d, text_latent_dim=cfg["text_latent_dim"],
+                                max_seq_len=cfg["max_seq_len"], motion_fps=15, motion_framechunksize=cfg["frame_chunk_size"],
+                                lmdb_paths="experiments/retrieval_cache_stratified/", new_lmdb_cache=False)
+                           if with_retrieval else None),
+            use_retrieval_for_test=with_retrieval,
             scale_func_cfg=dict(cfg["scale_func_cfg"]), per_joint_scale=dict(cfg["per_joint_scale"]),
         ),
         loss_recon=dict(type="MSELoss", loss_weight=1, reduction="none"),
@@ -297,7 +302,7 @@ def connective_vocab(n=50):
     return out[:n]
 
 
-def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, tie_groups=True):
+def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, tie_groups=True, feat_device=None):
     """Raw per-sample records with the fields the reference's DB builder reads
     (raggesture.py:244-293): sample_name, speaker_id, discourse (8-tuples
     (conn, sense, arg1, arg2, start, end, conn_start, conn_end), beatx_dataset.py:1082-1093),
@@ -332,10 +337,46 @@ def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, t
             prom.append(("filler%d" % int(g.integers(0, 9)), float(g.uniform(0, 9)), float(g.uniform(0, 9)), float(g.uniform(0, 3))))
         prom.sort(key=lambda p: p[1])
         L = int(g.integers(8, 49))
-        feat = torch.from_numpy(g.standard_normal((L, feat_dim)).astype(np.float32))
+        feat = L if feat_device is not None else torch.from_numpy(g.standard_normal((L, feat_dim)).astype(np.float32))
         recs.append(dict(sample_name=name, speaker_id=spk, discourse=disc, prominence=prom, text_feature=feat))
+    if feat_device is not None:
+        # benchmark-sized DBs: draw all token features with one device-side generator call
+        tot = sum(r["text_feature"] for r in recs)
+        gen = torch.Generator(device=feat_device).manual_seed(seed)
+        big = torch.randn(tot, feat_dim, device=feat_device, generator=gen)
+        o = 0
+        for r in recs:
+            L = r["text_feature"]
+            r["text_feature"] = big[o:o + L]
+            o += L
     recs.sort(key=lambda r: r["sample_name"])
     return recs
+
+
+class SyntheticDataset:
+    """Stand-in for the BEAT-X train set handed to `build_architecture(cfg.model, database=...)`:
+    `dataset[name]` returns the per-sample dict RetrievalDatabase.forward reads (raggesture.py:558-570),
+    `retrieval_samples` are the raw DB records.  Samples are generated from crc32(name) and cached."""
+
+    def __init__(self, n_entries, seed=2025, device="cpu", feat_device=None):
+        self.device = device
+        self.retrieval_samples = synth_retrieval_samples(n_entries, seed, feat_device=feat_device)
+        self.names = [r["sample_name"] for r in self.retrieval_samples]
+        self._cache = {}
+
+    def __len__(self):
+        return len(self.names)
+
+    def __getitem__(self, key):
+        name = self.names[0] if isinstance(key, int) else key
+        if name not in self._cache:
+            d = synth_batch(1, seed=zlib.crc32(name.encode()) & 0x7FFFFFFF, device=self.device)
+            out = {k: d[k][0] for k in ("motion", "motion_upper", "motion_lower", "motion_face", "motion_hands", "facial",
+                                        "trans", "contact", "motion_mask", "word", "audio")}
+            out["speaker_id"] = d["speaker_ids"][0]
+            out["sample_name"] = name
+            self._cache[name] = out
+        return self._cache[name]
 
 
 def synth_query(seed, n_rel=3, n_speakers=25, feat_dim=768):

@@ -1,0 +1,69 @@
+"""CPU: the N > 1 path (clip sharding + final result gather) with 2 gloo processes."""
+import importlib
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WIDTHS = dict(pred_upper=39, pred_lower=27, pred_facepose=3, pred_hands=90, pred_transl=3, pred_exps=100)
+
+
+def _fake_results(lo, hi):
+    """Deterministic per-clip 'results': clip c, key k -> c + 0.01 * column index."""
+    out = {}
+    for k, w in WIDTHS.items():
+        c = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1)
+        out[k] = (c + 0.01 * torch.arange(w, dtype=torch.float32).view(1, 1, -1)).expand(-1, 150, -1).contiguous()
+    return out
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = importlib.import_module("rag-gesture_amd.dist")
+    data = dict(motion_upper=torch.zeros(n_total, 150, 39), sample_name=["c%d" % i for i in range(n_total)], flag=7)
+    shard = d.shard_batch(data, rank, world)
+    lo, hi = d.shard_range(n_total, rank, world)
+    assert shard["motion_upper"].shape[0] == hi - lo and shard["sample_name"] == ["c%d" % i for i in range(lo, hi)]
+    assert shard["flag"] == 7
+    full = d.gather_results(_fake_results(lo, hi), n_total=n_total)
+    want = _fake_results(0, n_total)
+    ok = all(torch.equal(full[k], want[k]) for k in WIDTHS)
+    full2 = d.gather_results(_fake_results(lo, hi))  # sizes exchanged instead of given
+    ok = ok and all(torch.equal(full2[k], want[k]) for k in WIDTHS)
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def _run(n_total, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_shard_and_gather_even():
+    _run(8, 29611)
+
+
+def test_shard_and_gather_ragged():
+    _run(5, 29612)
+
+
+def test_shard_range_covers_everything():
+    d = importlib.import_module("rag-gesture_amd.dist")
+    for n in (1, 7, 10, 128):
+        for w in (1, 2, 4, 8):
+            spans = [d.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

@@ -114,3 +114,45 @@ def test_end_to_end_vs_reference_golden(rg, models, golden_dir, rtag, ikw, need_
         print("   ", k, "rel err %.3e" % ek)
         assert out[k].shape == r.shape
         assert ek <= (3e-2 if precision == "fp32" else 8e-2), k
+
+
+def test_end_to_end_with_retrieval_database_vs_oracle(rg):
+    """build_architecture(cfg.model, database=train_dataset) with use_retrieval_for_test: discourse
+    retrieval over the replicated DB (HIP sweep), exemplar encode, batched inversion, guided sampling --
+    against the oracle run of the same chain (retrieval indices/placement exact, latents close)."""
+    from oracle import retrieval as oret, diffusion as odf
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder", num_layers=2)
+    ds = rg.synth.SyntheticDataset(300, seed=31)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds,
+                                  precision="fp32")
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    model.load_state_dict(P).eval()
+    B = 2
+    qs = [rg.synth.synth_query(41), rg.synth.synth_query(42)]
+
+    def make_data():
+        d = rg.synth.synth_batch(B, seed=8)
+        d["discourse"], d["prominence"] = [q["discourse"] for q in qs], [q["prominence"] for q in qs]
+        d["text_features"] = [q["text_features"] for q in qs]
+        d["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs])
+        d["sample_name"] = ["query_a", ds.names[3]]
+        return d
+
+    ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    out = model(**dict(make_data(), retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=rg.synth.NoiseTape(77))))
+    torch.cuda.synchronize()
+    db = oret.build_db_dicts(ds.retrieval_samples)
+    d2 = make_data()
+    cond = dict(text_features=d2["text_features"], discourse=d2["discourse"], prominence=d2["prominence"],
+                speaker_ids=d2["speaker_ids"])
+    with torch.no_grad():
+        ref = opipe.motion_diffusion_forward(
+            P, cfg, vae_cfgs, odf.SpacedSchedule(), d2, rg.synth.NoiseTape(77),
+            re_dict=lambda tp: oret.database_forward(P, vae_cfgs, db, ds, cond, d2["sample_name"], tp), **ikw)
+    rd = out["retrieval_dict"]
+    assert sum(len(x) for x in rd["retr_startends"]) >= 2, "the synthetic queries should retrieve exemplars"
+    lat, r = out["prev_latentout"].cpu(), ref["prev_latentout"]
+    e = relerr(lat[:, KEEP], r[:, KEEP])
+    print("e2e with retrieval DB (fp32 mode): final latent rel err %.3e" % e)
+    assert e <= 1e-2
