@@ -144,6 +144,13 @@ typedef struct rg_gemm_desc {
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
 
+/* The A-operand prologue of rg_gemm as a standalone pass: out[row, s*seg_len + k] =
+ * bf16(f_s(src_s[row,k])) for nseg fp32 segments (identity / LayerNorm / stylization front half,
+ * same rg_a_segment descriptors, HOST array).  Used in front of the K = 4*512 ca_mix GEMM so the
+ * SiLU prologue runs once per element instead of once per column tile. */
+int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16, int ldo,
+               void* stream);
+
 /* Kernel selection hook for tests: force_generic = 1 routes every rg_gemm through the generic
  * register-staged kernel; 0 (default) lets aligned shapes use the LDS-DMA kernel. */
 int rg_set_gemm_path(rg_handle* h, int force_generic);

@@ -88,7 +88,7 @@ __device__ __forceinline__ void qa_and_store(const float* sq, const float (&Areg
   }
 }
 
-__global__ void __launch_bounds__(256) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
+__global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
                                                           const float* __restrict__ src_mask, float* __restrict__ y,
                                                           int ldy, float* __restrict__ stats, int T) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -99,10 +99,10 @@ __global__ void __launch_bounds__(256) sa_attention_kernel(const float* __restri
   const int Tp = (T + 3) & ~3;
   float* sstat = sm;                       // [WAVES][Tp][2]
   float* smask = sm + WAVES * 2 * Tp;      // [Tp]  (token mask staged once: no global loads in the loops)
-  float* sq = smask + Tp + wave * (3 * Tp * HD + HD * HD);
+  float* sq = smask + Tp + wave * (3 * Tp * HD);
   float* sk = sq + Tp * HD;
   float* sv = sk + Tp * HD;
-  float* sA = sv + Tp * HD;                // [32][32]
+  float* sA = sk;                          // [32][32] reuses the P tile once A is in registers (Tp >= 32)
   const float* base = qkv + (size_t)b * T * ldqkv + h * HD;
   {
     float* const dsts[3] = {sq, sk, sv};
@@ -151,6 +151,8 @@ __global__ void __launch_bounds__(256) sa_attention_kernel(const float* __restri
         acc[j4 + 3] = fmaf(pn, vv.w, acc[j4 + 3]);
       }
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane's reads of P are done before A overwrites it
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 16; ++j) sA[d * HD + l0 + j] = acc[j];
   }
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256) sa_attention_kernel(const float* __restri
 
 // grid = R * ncond * (D/128); Apre layout [cond][R][H][32][32]; q3/y3 layout [M][ncond*D];
 // stats layout [cond][M][D/128][2]; qmask layout [cond][R][T].
-__global__ void __launch_bounds__(256) ca_attention_kernel(const float* __restrict__ q3, const float* __restrict__ Apre,
+__global__ void __launch_bounds__(256, 2) ca_attention_kernel(const float* __restrict__ q3, const float* __restrict__ Apre,
                                                           const float* __restrict__ qmask, float* __restrict__ y3,
                                                           float* __restrict__ stats, int R, int T, int D, int ncond,
                                                           int Rc, const float* __restrict__ Aunc) {
@@ -310,7 +312,92 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const float* __restrict_
   }
 }
 
+// out[row, s*seg_len + k] = bf16( f_s(src_s[row, k]) ), f_s = identity / LayerNorm / LN*(1+scale)+shift->SiLU.
+// The same transforms rg_gemm applies in its A prologue, done ONCE per element: used where a GEMM
+// would otherwise redo an expensive prologue in every column tile (the K = 4*512 ca_mix GEMM).
+// One wave per (row, segment), 8 elements per lane per 512 columns; HBM-bound.
+struct StylizeArgs {
+  rg_a_segment seg[RG_MAX_SEG];
+  int nseg, seg_len, M, ldo;
+  unsigned short* out;
+};
+
+__global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
+  typedef __attribute__((ext_vector_type(4))) float v4;
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= a.M * a.nseg) return;
+  const int row = wave / a.nseg, s = wave % a.nseg;
+  rg_a_segment sg = a.seg[0];
+  if (s == 1) sg = a.seg[1];
+  if (s == 2) sg = a.seg[2];
+  if (s == 3) sg = a.seg[3];
+  float mu = 0.f, rs = 1.f;
+  if (sg.mode != RG_A_IDENT) {
+    const float* sp = sg.stats + (size_t)row * sg.nparts * 2;
+    float su = 0.f, sq = 0.f;
+    for (int q = 0; q < sg.nparts; ++q) {
+      su += sp[2 * q];
+      sq += sp[2 * q + 1];
+    }
+    const float inv = 1.0f / (float)a.seg_len;
+    mu = su * inv;
+    float var = sq * inv - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    rs = rsqrtf(var + 1e-5f);
+  }
+  const float* src = sg.src + (size_t)row * sg.ld;
+  unsigned short* dst = a.out + (size_t)row * a.ldo + s * a.seg_len;
+  for (int k = lane * 8; k < a.seg_len; k += 512) {
+    const v4 x0 = *reinterpret_cast<const v4*>(src + k), x1 = *reinterpret_cast<const v4*>(src + k + 4);
+    float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    if (sg.mode != RG_A_IDENT) {
+      const v4 g0 = *reinterpret_cast<const v4*>(sg.gamma + k), g1 = *reinterpret_cast<const v4*>(sg.gamma + k + 4);
+      const v4 b0 = *reinterpret_cast<const v4*>(sg.beta + k), b1 = *reinterpret_cast<const v4*>(sg.beta + k + 4);
+      const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      const float be[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu) * rs * g[e] + be[e];
+      if (sg.mode == RG_A_STYL) {
+        const float* sc = sg.scale_shift + k;
+        const float* sh = sg.scale_shift + a.seg_len + k;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = v[e] * (1.0f + sc[e]) + sh[e];
+          v[e] = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.44269504088896340736f));
+        }
+      }
+    }
+    u4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
+      o[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+    *reinterpret_cast<u4*>(dst + k) = o;
+  }
+}
+
 }  // namespace
+
+extern "C" int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16,
+                          int ldo, void* stream) {
+  RG_REQUIRE(h, segs_host && out_bf16, "null pointer");
+  RG_REQUIRE(h, nseg >= 1 && nseg <= RG_MAX_SEG && seg_len % 8 == 0 && M > 0 && ldo % 8 == 0, "bad shape");
+  StylizeArgs a;
+  for (int s = 0; s < RG_MAX_SEG; ++s) a.seg[s] = segs_host[s < nseg ? s : 0];
+  for (int s = 0; s < nseg; ++s) {
+    RG_REQUIRE(h, a.seg[s].src && (a.seg[s].ld % 4) == 0, "segment source must be 16-B aligned rows");
+    if (a.seg[s].mode != RG_A_IDENT) RG_REQUIRE(h, a.seg[s].stats && a.seg[s].gamma && a.seg[s].beta, "LN/STYL needs stats");
+    if (a.seg[s].mode == RG_A_STYL) RG_REQUIRE(h, a.seg[s].scale_shift, "STYL needs scale_shift");
+  }
+  a.nseg = nseg; a.seg_len = seg_len; a.M = M; a.ldo = ldo;
+  a.out = reinterpret_cast<unsigned short*>(out_bf16);
+  const int64_t waves = (int64_t)M * nseg;
+  hipLaunchKernelGGL(stylize_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, rg_stream(stream), a);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
 
 extern "C" int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows, int dim, void* stream) {
   RG_REQUIRE(h, x && stats, "null pointer");
@@ -325,9 +412,9 @@ extern "C" int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows
 extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
                                float* stats, int R, int T, int D, void* stream) {
   RG_REQUIRE(h, qkv && src_mask && y && stats, "null pointer");
-  RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape");
+  RG_REQUIRE(h, T >= 32 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape (32 <= T <= 64)");
   const int Tp = (T + 3) & ~3;
-  const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * (3 * Tp * HD + HD * HD)) * sizeof(float);
+  const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * (3 * Tp * HD)) * sizeof(float);
   hipLaunchKernelGGL(sa_attention_kernel, dim3(R * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream), qkv,
                      ldqkv, D, src_mask, y, ldy, stats, T);
   RG_CHECK_LAUNCH(h);

@@ -120,3 +120,22 @@ def launch(h, desc, stream=None):
 
 def gemm(h, stream=None, **kw):
     launch(h, make_desc(**kw), stream)
+
+
+def stylize(h, segs, seg_len, M, out, stream=None):
+    """rg_stylize: materialise the fp32->bf16 A prologue of `segs` once into out [M, nseg*seg_len] bf16."""
+    arr = (ASegment * MAX_SEG)()
+    for i, sg in enumerate(segs):
+        e = arr[i]
+        e.src = _p(sg.src, torch.float32) + 4 * sg.col_offset
+        e.ld, e.mode = sg.ld, sg.mode
+        if sg.mode != A_IDENT:
+            e.stats, e.nparts = _p(sg.stats, torch.float32), sg.stats.shape[-2]
+            e.gamma, e.beta = _p(sg.gamma, torch.float32), _p(sg.beta, torch.float32)
+        if sg.mode == A_STYL:
+            e.scale_shift = _p(sg.ss, torch.float32)
+    s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    rc = h.lib.rg_stylize(h._h, arr, len(segs), seg_len, M, ctypes.c_void_p(_p(out, torch.bfloat16)), out.stride(-2),
+                          ctypes.c_void_p(s))
+    if rc != 0:
+        raise capi.RgError("rg_stylize failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
