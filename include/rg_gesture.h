@@ -147,9 +147,14 @@ int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
 /* The A-operand prologue of rg_gemm as a standalone pass: out[row, s*seg_len + k] =
  * bf16(f_s(src_s[row,k])) for nseg fp32 segments (identity / LayerNorm / stylization front half,
  * same rg_a_segment descriptors, HOST array).  Used in front of the K = 4*512 ca_mix GEMM so the
- * SiLU prologue runs once per element instead of once per column tile. */
+ * SiLU prologue runs once per element instead of once per column tile.
+ * Rows [m_cond, M) are the classifier-free rows: for the first unc_nseg segments they copy
+ * unc_tab[flag][s*seg_len + k] (bf16; flag = 1 where qmask[s][row] == 0) instead of reading the source:
+ * with cond_type 0 the cross-attention output is the value bias for every token
+ * (efficient_attention.py:83-90), so its stylized form depends on the weights and the
+ * timestep only and is tabulated at load time.  m_cond = M disables this. */
 int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16, int ldo,
-               void* stream);
+               int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask, void* stream);
 
 /* Kernel selection hook for tests: force_generic = 1 routes every rg_gemm through the generic
  * register-staged kernel; 0 (default) lets aligned shapes use the LDS-DMA kernel. */

@@ -320,6 +320,12 @@ struct StylizeArgs {
   rg_a_segment seg[RG_MAX_SEG];
   int nseg, seg_len, M, ldo;
   unsigned short* out;
+  // classifier-free rows [m_cond, M): the first unc_nseg segments do not read their source but copy a
+  // precomputed bf16 row (cross-attention output is a weights-only constant there):
+  // unc_tab[flag][s*seg_len + k], flag = 1 on masked-query rows (qmask[s][row] == 0)
+  int m_cond, unc_nseg;
+  const unsigned short* unc_tab;
+  const float* qmask;   // [nseg][M] or null
 };
 
 __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
@@ -333,7 +339,7 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
   if (s == 2) sg = a.seg[2];
   if (s == 3) sg = a.seg[3];
   float mu = 0.f, rs = 1.f;
-  if (sg.mode != RG_A_IDENT) {
+  if (sg.mode != RG_A_IDENT && !(row >= a.m_cond && s < a.unc_nseg)) {
     const float* sp = sg.stats + (size_t)row * sg.nparts * 2;
     float su = 0.f, sq = 0.f;
     for (int q = 0; q < sg.nparts; ++q) {
@@ -346,8 +352,14 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
     var = var < 0.f ? 0.f : var;
     rs = rsqrtf(var + 1e-5f);
   }
-  const float* src = sg.src + (size_t)row * sg.ld;
   unsigned short* dst = a.out + (size_t)row * a.ldo + s * a.seg_len;
+  if (row >= a.m_cond && s < a.unc_nseg) {
+    const int flag = (a.qmask && a.qmask[(size_t)s * a.M + row] == 0.f) ? 1 : 0;
+    const unsigned short* tab = a.unc_tab + (size_t)flag * a.unc_nseg * a.seg_len + s * a.seg_len;
+    for (int k = lane * 8; k < a.seg_len; k += 512) *reinterpret_cast<u4*>(dst + k) = *reinterpret_cast<const u4*>(tab + k);
+    return;
+  }
+  const float* src = sg.src + (size_t)row * sg.ld;
   for (int k = lane * 8; k < a.seg_len; k += 512) {
     const v4 x0 = *reinterpret_cast<const v4*>(src + k), x1 = *reinterpret_cast<const v4*>(src + k + 4);
     float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
@@ -381,8 +393,11 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
 }  // namespace
 
 extern "C" int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16,
-                          int ldo, void* stream) {
+                          int ldo, int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask,
+                          void* stream) {
   RG_REQUIRE(h, segs_host && out_bf16, "null pointer");
+  RG_REQUIRE(h, m_cond >= 0 && m_cond <= M && unc_nseg >= 0 && unc_nseg <= nseg && (m_cond == M || unc_nseg == 0 || unc_tab_bf16),
+             "classifier-free rows need unc_tab");
   RG_REQUIRE(h, nseg >= 1 && nseg <= RG_MAX_SEG && seg_len % 8 == 0 && M > 0 && ldo % 8 == 0, "bad shape");
   StylizeArgs a;
   for (int s = 0; s < RG_MAX_SEG; ++s) a.seg[s] = segs_host[s < nseg ? s : 0];
@@ -393,6 +408,9 @@ extern "C" int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg,
   }
   a.nseg = nseg; a.seg_len = seg_len; a.M = M; a.ldo = ldo;
   a.out = reinterpret_cast<unsigned short*>(out_bf16);
+  a.m_cond = m_cond; a.unc_nseg = unc_nseg;
+  a.unc_tab = reinterpret_cast<const unsigned short*>(unc_tab_bf16);
+  a.qmask = qmask;
   const int64_t waves = (int64_t)M * nseg;
   hipLaunchKernelGGL(stylize_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);

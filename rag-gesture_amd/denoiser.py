@@ -123,6 +123,24 @@ class DenoiserWeights:
                 q = "temporal_decoder_blocks.%d.%s.proj_out.emb_layers.1." % (l, blk)
                 self.h.call("linear_f32", emb, f32(g(q + "weight")), f32(g(q + "bias")), tmp, S, 2 * D, self.TE, 1, 0)
                 self.ss[:, l, bi].copy_(tmp)
+        # --- classifier-free rows (bf16 path): cross-attention output == value bias for every token
+        # (cond_type 0), so its stylized bf16 form is a (step, layer, cond, masked?) table
+        if precision == "bf16":
+            for l, lw in enumerate(self.layers):
+                cq = ["temporal_decoder_blocks.%d.ca_blocks.%s." % (l, c) for c in CONDS]
+                bv = torch.stack([g(q + "value.bias") for q in cq])                      # [3, D]
+                bq = (bv + torch.tensor(-1000000.0)) + torch.tensor(1000000.0)           # fp32 rounding of y - 1e6
+                yu = f32(torch.stack([bv.reshape(-1), bq.reshape(-1)]))                  # [2, 3D]
+                st = torch.empty(2 * 3, D // 64, 2, device=self.dev)
+                self.h.call("row_stats", yu.view(6, D), st, 6, D)
+                st = st.view(2, 3, D // 64, 2)
+                tab = torch.empty(S, 2, 3 * D, device=self.dev, dtype=torch.bfloat16)
+                stc = [st[:, c].contiguous() for c in range(3)]
+                for si in range(S):
+                    segs = [G.Seg(yu, ld=3 * D, mode=G.A_STYL, stats=stc[c], gamma=lw["ca_sg"][c], beta=lw["ca_sb"][c],
+                                  scale_shift=self.ss[si, l, 1 + c], col_offset=c * D) for c in range(3)]
+                    G.stylize(self.h, segs, D, 2, tab[si])
+                lw["unc_tab"] = tab
         torch.cuda.synchronize(self.dev)
         # per-joint CFG scale (raggesture.py:909-922), default all ones
         pjs = cfg.get("per_joint_scale") or dict(upper=1.0, hands=1.0, face=1.0, lowertransl=1.0)
@@ -153,6 +171,8 @@ class DenoiserSession:
         self.yf, self.st_f = f(M, D), f(M, D // G.STATS_COLS, 2)
         self.head = f(M, D)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
+        self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
+        self.qmask_c = torch.ones(3, B, T, device=dev)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
         self.src_mask = torch.ones(self.R, T, device=dev)
         self.qmask = torch.ones(3, self.R, T, device=dev)
@@ -170,6 +190,7 @@ class DenoiserSession:
         else:
             for ci, c in enumerate(CONDS):
                 self.qmask[ci].copy_(query_masks[c].to(dev).float().repeat(2, 1))
+        self.qmask_c.copy_(self.qmask[:, :B])
         srcs = []
         for name, x, wt, bt in (("xf_text", word, w.w_text, w.b_text), ("xf_audio", audio, w.w_audio, w.b_audio)):
             x = x.to(dev).float().contiguous()
@@ -224,18 +245,28 @@ class DenoiserSession:
                    segs=[G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"],
                                scale_shift=ss[0])], seg_len=D, bias=lw["b_sao"], residual=xa, stats_out=sb_)
             # --- three parallel cross attentions on the same input
-            G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
-                   segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
-                   bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
-            h.call("ca_attention", self.q3, self.a_pre[l], lw["a_unc"], self.qmask, self.y3, self.st3, R, B, T, D, 3)
-            segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3[c], gamma=lw["ca_sg"][c],
-                          beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
-            segs.append(G.Seg(xb))
             if self.hcat is not None:
+                # production path: query projection + cross attention on the conditional rows only; the
+                # classifier-free rows take their (constant) stylized cross-attention rows from the table
+                Mc = B * T
+                G.gemm(h, M=Mc, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
+                       segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
+                       bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
+                h.call("ca_attention", self.q3, self.a_pre[l], None, self.qmask_c, self.y3, self.st3c, B, B, T, D, 3)
+                segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3c[c], gamma=lw["ca_sg"][c],
+                              beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
+                segs.append(G.Seg(xb))
                 # the SiLU prologue of the K = 2048 GEMM once per element instead of once per column tile
-                G.stylize(h, segs, D, M, self.hcat)
+                G.stylize(h, segs, D, M, self.hcat, m_cond=Mc, unc_nseg=3, unc_tab=lw["unc_tab"][step], qmask=self.qmask)
                 G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"])
             else:
+                G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
+                       segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
+                       bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
+                h.call("ca_attention", self.q3, self.a_pre[l], lw["a_unc"], self.qmask, self.y3, self.st3, R, B, T, D, 3)
+                segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3[c], gamma=lw["ca_sg"][c],
+                              beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
+                segs.append(G.Seg(xb))
                 G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, segs=segs, seg_len=D, bias=lw["b_mix"])
             # --- FFN
             G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, segs=[G.Seg(xc)], seg_len=D, bias=lw["b_ff1"], act=1)

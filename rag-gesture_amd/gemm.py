@@ -122,7 +122,7 @@ def gemm(h, stream=None, **kw):
     launch(h, make_desc(**kw), stream)
 
 
-def stylize(h, segs, seg_len, M, out, stream=None):
+def stylize(h, segs, seg_len, M, out, stream=None, m_cond=None, unc_nseg=0, unc_tab=None, qmask=None):
     """rg_stylize: materialise the fp32->bf16 A prologue of `segs` once into out [M, nseg*seg_len] bf16."""
     arr = (ASegment * MAX_SEG)()
     for i, sg in enumerate(segs):
@@ -136,6 +136,8 @@ def stylize(h, segs, seg_len, M, out, stream=None):
             e.scale_shift = _p(sg.ss, torch.float32)
     s = torch.cuda.current_stream().cuda_stream if stream is None else stream
     rc = h.lib.rg_stylize(h._h, arr, len(segs), seg_len, M, ctypes.c_void_p(_p(out, torch.bfloat16)), out.stride(-2),
-                          ctypes.c_void_p(s))
+                          M if m_cond is None else m_cond, unc_nseg,
+                          ctypes.c_void_p(_p(unc_tab, torch.bfloat16) if unc_tab is not None else None),
+                          ctypes.c_void_p(_p(qmask, torch.float32) if qmask is not None else None), ctypes.c_void_p(s))
     if rc != 0:
         raise capi.RgError("rg_stylize failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
