@@ -156,9 +156,11 @@ int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
 int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16, int ldo,
                int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask, void* stream);
 
-/* Kernel selection hook for tests: force_generic = 1 routes every rg_gemm through the generic
- * register-staged kernel; 0 (default) lets aligned shapes use the LDS-DMA kernel. */
-int rg_set_gemm_path(rg_handle* h, int force_generic);
+/* Kernel selection hook for tests / tuning: 0 = auto, 1 = generic register-staged kernel only (any
+ * shape), 2 = prefer the LDS-DMA ring kernel, 3 = prefer the depth-4 register-staged kernel. */
+int rg_set_gemm_path(rg_handle* h, int path);
+/* Tuning knob: waves per workgroup of the LDS-DMA GEMM kernel (0 = auto by shape, 4 or 8; process-wide, default 0). */
+int rg_set_gemm_waves(int waves);
 
 /* Measurement aid (bench.py roofline): between begin and end every rg_gemm launch is bracketed by
  * HIP events on its stream; end synchronises and returns launch count, summed kernel time and summed
@@ -177,9 +179,11 @@ int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* 
  * of T tokens: qkv is [R*T, ldqkv] fp32 with q (already softmaxed over head_dim by the GEMM
  * epilogue) in columns [0,D), k in [D,2D), v in [2D,3D); src_mask [R,T] (0 = masked token:
  * `key + (1-mask)*-1e6` and `value*mask`).  Writes y [R*T, ldy] fp32 and per-row partial
- * LayerNorm statistics stats[R*T][D/128][2] (sum, sumsq over each 128-column head group). */
+ * LayerNorm statistics stats[R*T][D/128][2] (sum, sumsq over each 128-column head group).
+ * perm (device, nperm ints, or NULL): launch order -> work item (row * D/128 + head group, -1 = idle
+ * block); lets the caller place a row group on the XCD whose L2 already holds its rows. */
 int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
-                    float* stats, int R, int T, int D, void* stream);
+                    float* stats, int R, int T, int D, const int* perm, int nperm, void* stream);
 
 /* Cross-attention core of EfficientCrossAttention for ncond parallel conditions
  * (efficient_attention.py:90-98; diffusion_transformer.py:105-118): y3[:, c*D:(c+1)*D] = Q_c A_c
@@ -188,9 +192,11 @@ int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_
  * A[d][l] = b_v[l]; efficient_attention.py:83-90).
  * qmask [ncond][R][T] or NULL: where 0, y is rounded exactly as the reference's fp32
  * `y + (1-query_mask)*-1e6` rounds it (grid 1/16) so that the following LayerNorm sees the
- * same values up to the shift.  stats layout [ncond][R*T][D/128][2]. */
+ * same values up to the shift.  stats layout [ncond][R*T][D/128][2].
+ * perm as for rg_sa_attention; work item = (row * ncond + cond) * D/128 + head group. */
 int rg_ca_attention(rg_handle* h, const float* q3, const float* Apre, const float* Aunc, const float* qmask,
-                    float* y3, float* stats, int R, int Rc, int T, int D, int ncond, void* stream);
+                    float* y3, float* stats, int R, int Rc, int T, int D, int ncond, const int* perm, int nperm,
+                    void* stream);
 
 /* A[b][h] = softmax_over_tokens(K[b,:,h,:])^T V[b,:,h,:]  (efficient_attention.py:82-90) for B rows
  * of N conditioning tokens; kv is [B*N, ldkv] fp32 with k in columns [0,D) and v in [D,2D).

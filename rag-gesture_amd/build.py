@@ -11,8 +11,9 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "librg_gesture.so")
-OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj")
+DIAG = os.environ.get("RG_DIAG") == "1"   # diagnostic build with in-kernel phase stamps (never the product)
+LIB_PATH = os.path.join(PKG_DIR, "librg_gesture_diag.so" if DIAG else "librg_gesture.so")
+OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj_diag" if DIAG else "_obj")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
          "-mllvm", "-amdgpu-early-inline-all=true"]
@@ -40,7 +41,7 @@ def _compile(src, hdr_mtime, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= hdr_mtime):
         return obj
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + (["-DRG_STAMPS"] if DIAG else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

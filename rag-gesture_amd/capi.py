@@ -10,7 +10,7 @@ import re
 import torch
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "librg_gesture.so")
+LIB_PATH = os.path.join(PKG_DIR, "librg_gesture_diag.so" if os.environ.get("RG_DIAG") == "1" else "librg_gesture.so")
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "rg_gesture.h")
 
 _lib = None

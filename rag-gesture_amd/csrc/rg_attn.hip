@@ -27,52 +27,28 @@ __device__ __forceinline__ float wave_sum32(float v) {  // sum over the 32 lanes
   return v;
 }
 
-// Load NT_ [T][32] fp32 tiles (row stride ld floats, column offsets coff[i]) into LDS [T][32] each;
-// 8 rows per wave-instruction.  All global loads are issued before the first LDS store so the
-// tile costs one memory latency, not one per row group.
-template <int NT_>
-__device__ __forceinline__ void load_tiles32(float* const (&dst)[NT_], const float* src, const int (&coff)[NT_],
-                                             int ld, int T, int lane) {
-  typedef __attribute__((ext_vector_type(4))) float v4;
-  constexpr int NIT = TMAX / 8;
-  const int c4 = (lane & 7) * 4;
-  v4 reg[NT_][NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int r = (lane >> 3) + 8 * it;
-    if (r < T) {
-#pragma unroll
-      for (int i = 0; i < NT_; ++i) reg[i][it] = *reinterpret_cast<const v4*>(src + (size_t)r * ld + coff[i] + c4);
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int r = (lane >> 3) + 8 * it;
-    if (r < T) {
-#pragma unroll
-      for (int i = 0; i < NT_; ++i) *reinterpret_cast<v4*>(dst[i] + r * HD + c4) = reg[i][it];
-    }
-  }
-}
-
 // y[n][l] = sum_d q[n][d] * A[d][l] for the T tokens of one head; lane -> (l = lane&31, half).
 // Areg = column l of A.  Writes y (optionally quantised like the reference's "-1e6 + y" on
-// masked query rows) and writes this wave's per-token partial sums to sstat[T][2] (its own LDS
-// slice: no atomics, so results are bitwise reproducible run to run).
-__device__ __forceinline__ void qa_and_store(const float* sq, const float (&Areg)[HD], float* yout, int ldy,
+// masked query rows) to global memory and, in place of the consumed q row, to LDS; the per-token
+// (sum, sumsq) over the head's 32 columns is then one lane per token reading its row with a
+// rotated column order (bank-conflict free) -- no cross-lane shuffles, fixed summation order, so
+// results are bitwise reproducible run to run.  sstat[T][2] is this wave's own LDS slice.
+__device__ __forceinline__ void qa_and_store(float* sq, const float (&Areg)[HD], float* yout, int ldy,
                                              int T, int lane, const float* qmask, float* sstat) {
   const int l = lane & 31, half = lane >> 5;
+#pragma unroll 2
   for (int n = half; n < T; n += 2) {
     const float* qr = sq + n * HD;
-    float acc = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int d4 = 0; d4 < HD; d4 += 4) {
       float4 q = *reinterpret_cast<const float4*>(qr + d4);
-      acc = fmaf(q.x, Areg[d4], acc);
-      acc = fmaf(q.y, Areg[d4 + 1], acc);
-      acc = fmaf(q.z, Areg[d4 + 2], acc);
-      acc = fmaf(q.w, Areg[d4 + 3], acc);
+      a0 = fmaf(q.x, Areg[d4], a0);
+      a1 = fmaf(q.y, Areg[d4 + 1], a1);
+      a2 = fmaf(q.z, Areg[d4 + 2], a2);
+      a3 = fmaf(q.w, Areg[d4 + 3], a3);
     }
+    float acc = (a0 + a1) + (a2 + a3);
     if (qmask && qmask[n] == 0.f) {
       // reference: y + (1 - query_mask) * -1e6 in fp32, then LayerNorm (shift invariant).
       // z is y rounded onto the fp32 grid near -1e6 (spacing 1/16); z + 1e6 is exact.
@@ -80,56 +56,93 @@ __device__ __forceinline__ void qa_and_store(const float* sq, const float (&Areg
       acc = z + 1000000.0f;
     }
     yout[(size_t)n * ldy + l] = acc;
-    float s = wave_sum32(acc), ss = wave_sum32(acc * acc);
-    if (l == 0) {
-      sstat[2 * n] = s;
-      sstat[2 * n + 1] = ss;
+    sq[n * HD + l] = acc;   // row n is read by this half-wave only, and all its reads fed acc
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+  __builtin_amdgcn_wave_barrier();
+  if (lane < T) {
+    const float* yr = sq + lane * HD;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < HD; j += 2) {
+      const float v0 = yr[(j + lane) & 31], v1 = yr[(j + 1 + lane) & 31];
+      s0 += v0;
+      s1 += v1;
+      q0 = fmaf(v0, v0, q0);
+      q1 = fmaf(v1, v1, q1);
     }
+    sstat[2 * lane] = s0 + s1;
+    sstat[2 * lane + 1] = q0 + q1;
   }
 }
 
 __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
                                                           const float* __restrict__ src_mask, float* __restrict__ y,
-                                                          int ldy, float* __restrict__ stats, int T) {
+                                                          int ldy, float* __restrict__ stats, int T,
+                                                          const int* __restrict__ perm) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x / (D / (HD * WAVES));
-  const int hg = blockIdx.x % (D / (HD * WAVES));
+  // perm: block -> work item, so that a row group is processed on the XCD whose L2 holds its rows
+  // (the GEMMs put M-tile t on XCD t % 8); -1 = padding block
+  const int item = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+  if (item < 0) return;
+  const int b = item / (D / (HD * WAVES));
+  const int hg = item % (D / (HD * WAVES));
   const int h = hg * WAVES + wave;
-  const int Tp = (T + 3) & ~3;
+  const int Tp = (T + 7) & ~7;
   float* sstat = sm;                       // [WAVES][Tp][2]
   float* smask = sm + WAVES * 2 * Tp;      // [Tp]  (token mask staged once: no global loads in the loops)
   float* sq = smask + Tp + wave * (3 * Tp * HD);
   float* sk = sq + Tp * HD;
   float* sv = sk + Tp * HD;
-  float* sA = sk;                          // [32][32] reuses the P tile once A is in registers (Tp >= 32)
-  const float* base = qkv + (size_t)b * T * ldqkv + h * HD;
+  constexpr int AS = HD + 1;
+  float* sA = sk;                          // [32][33] reuses the P tile once A is in registers (Tp*32 >= 32*33)
+  // q, k, v tiles [T][32] straight into LDS: one 1-KiB LDS-DMA per 8 rows and tile
   {
-    float* const dsts[3] = {sq, sk, sv};
-    const int coffs[3] = {0, D, 2 * D};
-    load_tiles32<3>(dsts, base, coffs, ldqkv, T, lane);
+    typedef __attribute__((address_space(3))) void lds_void;
+    const float* src = qkv + (size_t)b * T * ldqkv + h * HD + (lane & 7) * 4;
+    for (int r0 = 0; r0 < Tp; r0 += 8) {
+      int r = r0 + (lane >> 3);
+      r = r < T ? r : T - 1;   // pad rows duplicate the last token (never read back)
+      const float* rp = src + (size_t)r * ldqkv;
+      __builtin_amdgcn_global_load_lds((const void*)(rp + D), (lds_void*)(sk + r0 * HD), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)(rp + 2 * D), (lds_void*)(sv + r0 * HD), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const void*)rp, (lds_void*)(sq + r0 * HD), 16, 0, 0);
+    }
   }
   for (int n = threadIdx.x; n < T; n += 256) smask[n] = src_mask[(size_t)b * T + n];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float* mrow = smask;
 
-  // softmax over tokens for column d = lane&31; the two half-waves split the tokens
+  // softmax over tokens for column d = lane&31; the two half-waves split the tokens.  The column
+  // lives in registers (one batch of independent LDS reads instead of three dependent sweeps)
   {
     const int d = lane & 31, half = lane >> 5;
+    constexpr int NH = TMAX / 2;
+    float kr[NH];
     float mx = -INFINITY;
-    for (int n = half; n < T; n += 2)
-      if (mrow[n] != 0.f) mx = fmaxf(mx, sk[n * HD + d]);
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int n = half + 2 * i;
+      // key + (1-mask)*-1e6: a masked token's weight underflows to exactly 0 in fp32
+      kr[i] = (n < T && mrow[n] != 0.f) ? sk[n * HD + d] : -INFINITY;
+      mx = fmaxf(mx, kr[i]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
-    for (int n = half; n < T; n += 2) {
-      // key + (1-mask)*-1e6: a masked token's weight underflows to exactly 0 in fp32
-      float e = (mrow[n] != 0.f) ? expf(sk[n * HD + d] - mx) : 0.f;
-      sk[n * HD + d] = e;
-      sum += e;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      kr[i] = (kr[i] == -INFINITY) ? 0.f : expf(kr[i] - mx);
+      sum += kr[i];
     }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
-    for (int n = half; n < T; n += 2) sk[n * HD + d] *= inv;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int n = half + 2 * i;
+      if (n < T) sk[n * HD + d] = kr[i] * inv;
+    }
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
   __builtin_amdgcn_wave_barrier();
@@ -139,6 +152,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll 4
     for (int n = 0; n < T; ++n) {
       const float pn = sk[n * HD + d];
       const float* vr = sv + n * HD + l0;
@@ -154,14 +168,14 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
     __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane's reads of P are done before A overwrites it
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) sA[d * HD + l0 + j] = acc[j];
+    for (int j = 0; j < 16; ++j) sA[d * AS + l0 + j] = acc[j];   // row stride 33: conflict-free transposed write
   }
   // (same wave wrote sA: a wave-level LDS fence is enough)
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
   float Areg[HD];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) Areg[d] = sA[d * HD + (lane & 31)];
+  for (int d = 0; d < HD; ++d) Areg[d] = sA[d * AS + (lane & 31)];
   qa_and_store(sq, Areg, y + (size_t)b * T * ldy + h * HD, ldy, T, lane, nullptr, sstat + wave * 2 * Tp);
   __syncthreads();
   const int ngroups = D / (HD * WAVES);
@@ -174,29 +188,37 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
 
 // grid = R * ncond * (D/128); Apre layout [cond][R][H][32][32]; q3/y3 layout [M][ncond*D];
 // stats layout [cond][M][D/128][2]; qmask layout [cond][R][T].
-__global__ void __launch_bounds__(256, 2) ca_attention_kernel(const float* __restrict__ q3, const float* __restrict__ Apre,
+__global__ void __launch_bounds__(256, 4) ca_attention_kernel(const float* __restrict__ q3, const float* __restrict__ Apre,
                                                           const float* __restrict__ qmask, float* __restrict__ y3,
                                                           float* __restrict__ stats, int R, int T, int D, int ncond,
-                                                          int Rc, const float* __restrict__ Aunc) {
+                                                          int Rc, const float* __restrict__ Aunc,
+                                                          const int* __restrict__ perm) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ngroups = D / (HD * WAVES);
   const int H = D / HD;
-  int bid = blockIdx.x;
+  int bid = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+  if (bid < 0) return;
   const int hg = bid % ngroups;
   bid /= ngroups;
   const int c = bid % ncond;
   const int b = bid / ncond;
   const int h = hg * WAVES + wave;
-  const int Tp = (T + 3) & ~3;
+  const int Tp = (T + 7) & ~7;
   float* sstat = sm;  // [WAVES][Tp][2]
   float* smask = sm + WAVES * 2 * Tp;  // [Tp]
   float* sq = smask + Tp + wave * (Tp * HD);
   const int ld = ncond * D;
+  // q tile [T][32] straight into LDS: one 1-KiB LDS-DMA per 8 rows (8 lanes x 16 B per row), no
+  // staging registers, so 4 workgroups fit a CU and the grid runs in one round
   {
-    float* const dsts[1] = {sq};
-    const int coffs[1] = {0};
-    load_tiles32<1>(dsts, q3 + (size_t)b * T * ld + c * D + h * HD, coffs, ld, T, lane);
+    typedef __attribute__((address_space(3))) void lds_void;
+    const float* src = q3 + (size_t)b * T * ld + c * D + h * HD + (lane & 7) * 4;
+    for (int r0 = 0; r0 < Tp; r0 += 8) {
+      int r = r0 + (lane >> 3);
+      r = r < T ? r : T - 1;   // pad rows duplicate the last token (never read back)
+      __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)r * ld), (lds_void*)(sq + r0 * HD), 16, 0, 0);
+    }
   }
   // rows [0,Rc) carry per-row conditioning; rows [Rc,R) are the classifier-free "no condition"
   // branch whose A depends only on the weights (Aunc[cond][H][32][32])
@@ -207,6 +229,7 @@ __global__ void __launch_bounds__(256, 2) ca_attention_kernel(const float* __res
   for (int d = 0; d < HD; ++d) Areg[d] = Ap[d * HD + (lane & 31)];
   if (qmask)
     for (int n = threadIdx.x; n < T; n += 256) smask[n] = qmask[((size_t)c * R + b) * T + n];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float* qm = qmask ? smask : nullptr;
   qa_and_store(sq, Areg, y3 + (size_t)b * T * ld + c * D + h * HD, ld, T, lane, qm, sstat + wave * 2 * Tp);
@@ -428,27 +451,29 @@ extern "C" int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows
 }
 
 extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
-                               float* stats, int R, int T, int D, void* stream) {
+                               float* stats, int R, int T, int D, const int* perm, int nperm, void* stream) {
   RG_REQUIRE(h, qkv && src_mask && y && stats, "null pointer");
-  RG_REQUIRE(h, T >= 32 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape (32 <= T <= 64)");
-  const int Tp = (T + 3) & ~3;
+  RG_REQUIRE(h, T >= 33 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape (33 <= T <= 64)");
+  const int Tp = (T + 7) & ~7;
   const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * (3 * Tp * HD)) * sizeof(float);
-  hipLaunchKernelGGL(sa_attention_kernel, dim3(R * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream), qkv,
-                     ldqkv, D, src_mask, y, ldy, stats, T);
+  RG_REQUIRE(h, !perm || nperm >= R * (D / (HD * WAVES)), "perm shorter than the work list");
+  hipLaunchKernelGGL(sa_attention_kernel, dim3(perm ? nperm : R * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream),
+                     qkv, ldqkv, D, src_mask, y, ldy, stats, T, perm);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }
 
 extern "C" int rg_ca_attention(rg_handle* h, const float* q3, const float* Apre, const float* Aunc,
                                const float* qmask, float* y3, float* stats, int R, int Rc, int T, int D, int ncond,
-                               void* stream) {
+                               const int* perm, int nperm, void* stream) {
   RG_REQUIRE(h, q3 && Apre && y3 && stats, "null pointer");
   RG_REQUIRE(h, Rc >= 0 && Rc <= R && (Rc == R || Aunc), "rows beyond Rc need Aunc");
   RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * WAVES) == 0 && R > 0 && ncond > 0, "bad shape");
-  const int Tp = (T + 3) & ~3;
+  const int Tp = (T + 7) & ~7;
   const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * Tp * HD) * sizeof(float);
-  hipLaunchKernelGGL(ca_attention_kernel, dim3(R * ncond * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream),
-                     q3, Apre, qmask, y3, stats, R, T, D, ncond, Rc, Aunc);
+  RG_REQUIRE(h, !perm || nperm >= R * ncond * (D / (HD * WAVES)), "perm shorter than the work list");
+  hipLaunchKernelGGL(ca_attention_kernel, dim3(perm ? nperm : R * ncond * (D / (HD * WAVES))), dim3(256), lds,
+                     rg_stream(stream), q3, Apre, qmask, y3, stats, R, T, D, ncond, Rc, Aunc, perm);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

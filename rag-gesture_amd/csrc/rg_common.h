@@ -19,7 +19,7 @@ struct rg_handle {
   int device = 0;
   int num_cus = 256;
   std::string err;
-  bool force_generic_gemm = false; // rg_set_gemm_path
+  int gemm_path = 0;               // rg_set_gemm_path
   bool profiling = false;          // rg_profile_begin/end: HIP events around every rg_gemm launch
   std::vector<rg_prof_rec> prof;
   std::vector<hipEvent_t> ev_pool;

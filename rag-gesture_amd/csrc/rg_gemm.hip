@@ -32,6 +32,17 @@
 namespace {
 using namespace rg_gemm_detail;
 
+#ifdef RG_STAMPS
+__device__ unsigned long long* g_stamp_buf2 = nullptr;
+#define RG_STAMP2(slot)                                                                        \
+  do {                                                                                         \
+    if (g_stamp_buf2 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))  \
+      g_stamp_buf2[(blockIdx.x == 0 ? 0 : 64) + (slot)] = __builtin_amdgcn_s_memrealtime();    \
+  } while (0)
+#else
+#define RG_STAMP2(slot)
+#endif
+
 template <bool A_BF16, bool SPLIT>
 struct Stage {                 // one K-tile in flight in registers
   u32x4 w[4];
@@ -40,7 +51,12 @@ struct Stage {                 // one K-tile in flight in registers
   f32x4 af[A_BF16 ? 1 : 2][2];
 };
 
-template <bool A_BF16, bool SPLIT>
+// FAST: K % 256 == 0 and 16-B aligned rows.  Loads are unconditional (rows beyond M are clamped, their
+// results discarded by the epilogue) and the K loop is peeled so that no global load sits under a
+// branch: hipcc's waitcnt insertion then emits counted vmcnt(N) waits; with predicated or conditional
+// loads it falls back to vmcnt(0) at the LDS store and the software pipeline degenerates into one
+// exposed memory latency per K-tile (measured ~1 us per tile).
+template <bool A_BF16, bool SPLIT, bool FAST>
 __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPL = SPLIT ? 2 : 1;                       // hi (+ lo) planes
@@ -136,7 +152,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
       const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        if (arow_ok[j] && k0 + 8 <= p.K)
+        if (FAST || (arow_ok[j] && k0 + 8 <= p.K))
           st.abf[j] = *reinterpret_cast<const u32x4*>(Ab + (size_t)arow[j] * p.lda + k0);
         else
           st.abf[j] = u32x4{0u, 0u, 0u, 0u};
@@ -145,7 +161,7 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
       const int sidx = (kt * BK) / p.seg_len;
       const SegInfo sg = sSeg[sidx];
       const int ks = k0 - sidx * p.seg_len;
-      const bool fast = ((sg.ld & 3) == 0) && (k0 + 8 <= p.K);
+      const bool fast = FAST || (((sg.ld & 3) == 0) && (k0 + 8 <= p.K));
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float* src = sg.src + (size_t)arow[j] * sg.ld + ks;
@@ -276,24 +292,64 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
     }
   };
 
+  RG_STAMP2(0);
+  if constexpr (FAST) {
+    // ---- prefetch distance 4, four statically named register sets, K loop in quads (nk % 4 == 0);
+    //      the last quad is peeled (nothing left to prefetch), so every load is unconditional
+    St s0, s1, s2, s3;
+    load_tile(s0, 0); load_tile(s1, 1); load_tile(s2, 2); load_tile(s3, 3);
+    store_tile(s0, 0, 0);
+    __syncthreads();
+    RG_STAMP2(1);
+#define RG_STEP(FREE, NEXT, T)              \
+    load_tile(FREE, (T) + 4);               \
+    compute((T) & 1);                       \
+    store_tile(NEXT, (T) + 1, ((T) + 1) & 1); \
+    __syncthreads();
+#define RG_TAIL(NEXT, T)                    \
+    compute((T) & 1);                       \
+    store_tile(NEXT, (T) + 1, ((T) + 1) & 1); \
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 4) {
+      if (kt < 40) RG_STAMP2(2 + kt);
+      RG_STEP(s0, s1, kt)
+      RG_STEP(s1, s2, kt + 1)
+      RG_STEP(s2, s3, kt + 2)
+      RG_STEP(s3, s0, kt + 3)
+    }
+    if (kt < 40) RG_STAMP2(2 + kt);
+    RG_TAIL(s1, kt)
+    RG_TAIL(s2, kt + 1)
+    RG_TAIL(s3, kt + 2)
+    compute((kt + 3) & 1);
+    __syncthreads();
+#undef RG_STEP
+#undef RG_TAIL
+  } else {
   // ---- software pipeline: tile t lives in register set (t & 1); prefetch distance 2
   St st0, st1;
   load_tile(st0, 0);
   if (nk > 1) load_tile(st1, 1);
   store_tile(st0, 0, 0);
   __syncthreads();
+  RG_STAMP2(1);
   for (int kt = 0; kt < nk; kt += 2) {
+    if (kt < 40) RG_STAMP2(2 + kt);
     if (kt + 2 < nk) load_tile(st0, kt + 2);
     compute(0);
     if (kt + 1 < nk) store_tile(st1, kt + 1, 1);
     __syncthreads();
     if (kt + 1 >= nk) break;
+    if (kt < 39) RG_STAMP2(3 + kt);
     if (kt + 3 < nk) load_tile(st1, kt + 3);
     compute(1);
     if (kt + 2 < nk) store_tile(st0, kt + 2, 0);
     __syncthreads();
   }
+  }
 
+  RG_STAMP2(60);
   // ---- epilogue through LDS: sC[64][SC_LD] fp32 (33.8 KiB <= 2 * STAGE_BYTES)
   float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
@@ -305,7 +361,12 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
         sC[(wr * 32 + i * 16 + fq * 4 + e) * SC_LD + wc * 64 + j * 16 + frow] = acc[i][j][e];
   __syncthreads();
 
+  RG_STAMP2(61);
   epilogue(p, sC, tid, m0, n0, tile_n, nt);
+  RG_STAMP2(62);
+#ifdef RG_STAMPS
+  if (g_stamp_buf2 && threadIdx.x == 0 && blockIdx.x == 0) g_stamp_buf2[126] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <bool A_BF16, bool SPLIT>
@@ -315,16 +376,26 @@ size_t lds_bytes(int nseg) {
   return stages + tables;
 }
 
-template <bool A_BF16, bool SPLIT>
+template <bool A_BF16, bool SPLIT, bool FAST>
 void launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
   static bool attr = false;
   const size_t lds = lds_bytes<A_BF16, SPLIT>(d->nseg);
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_BF16, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_BF16, SPLIT, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes<A_BF16, SPLIT>(RG_MAX_SEG));
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<A_BF16, SPLIT>), grid, dim3(NT), lds, s, *d);
+  hipLaunchKernelGGL((gemm_kernel<A_BF16, SPLIT, FAST>), grid, dim3(NT), lds, s, *d);
+}
+
+// aligned shapes whose K loop splits into quads of 64-wide tiles
+bool reg_fast_eligible(const rg_gemm_desc* d) {
+  if (d->K % 256 != 0 || d->W_lo) return false;
+  if (d->a_is_bf16) return (d->lda % 8) == 0;
+  if (d->seg_len % 64 != 0) return false;
+  for (int s = 0; s < d->nseg; ++s)
+    if ((d->seg[s].ld % 4) != 0) return false;
+  return true;
 }
 
 }  // namespace
@@ -369,14 +440,21 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
     (void)hipEventRecord(rec.start, rg_stream(stream));
   }
   if (d->W_lo) RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
-  if (!h->force_generic_gemm && rg_gemm_dma_eligible(d)) {
+  // gemm_path: 0 = auto (LDS-DMA kernel where eligible, else generic),
+  //            1 = generic only, 2 = prefer LDS-DMA, 3 = prefer register-staged FAST
+  const int path = h->gemm_path;
+  const bool fast_ok = reg_fast_eligible(d), dma_ok = rg_gemm_dma_eligible(d);
+  if (fast_ok && path == 3) {
+    if (d->a_is_bf16) launch<true, false, true>(d, grid, rg_stream(stream));
+    else launch<false, false, true>(d, grid, rg_stream(stream));
+  } else if (path != 1 && dma_ok) {
     rg_gemm_dma_launch(d, h->num_cus, stream);
   } else if (d->W_lo) {
-    launch<false, true>(d, grid, rg_stream(stream));
+    launch<false, true, false>(d, grid, rg_stream(stream));
   } else if (d->a_is_bf16) {
-    launch<true, false>(d, grid, rg_stream(stream));
+    launch<true, false, false>(d, grid, rg_stream(stream));
   } else {
-    launch<false, false>(d, grid, rg_stream(stream));
+    launch<false, false, false>(d, grid, rg_stream(stream));
   }
   RG_CHECK_LAUNCH(h);
   if (h->profiling) {
@@ -414,10 +492,15 @@ extern "C" int rg_profile_end(rg_handle* h, int variant, int64_t* launches, doub
   return RG_OK;
 }
 
-// Test hook: route every GEMM through the generic register-staged kernel (1) or allow the LDS-DMA
-// kernel for aligned shapes (0, default).
-extern "C" int rg_set_gemm_path(rg_handle* h, int force_generic) {
-  if (!h) return RG_ERR_INVALID;
-  h->force_generic_gemm = force_generic != 0;
+// Test / tuning hook, see the dispatch in rg_gemm.
+extern "C" int rg_set_gemm_path(rg_handle* h, int path) {
+  if (!h || path < 0 || path > 3) return RG_ERR_INVALID;
+  h->gemm_path = path;
   return RG_OK;
 }
+
+#ifdef RG_STAMPS
+extern "C" int rg_debug_set_stamp_buffer2(void* dev_ptr) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf2), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -2;
+}
+#endif

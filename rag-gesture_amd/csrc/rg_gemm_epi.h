@@ -52,8 +52,29 @@ __device__ __forceinline__ void tile_of_block(int bid, int mt, int nt, int& tile
 }
 
 // Every thread owns 32 consecutive columns of one row of sC (= one attention head).
+// Residual values of this thread's 32 outputs, optionally loaded before the K loop so that their
+// (cold) latency is hidden under the main loop instead of being exposed in the epilogue.
+struct ResidualPrefetch {
+  bool valid = false;
+  float r[32];
+};
+
+__device__ __forceinline__ void prefetch_residual(const rg_gemm_desc& p, int tid, int m0, int n0, ResidualPrefetch& pre) {
+  const int grow = m0 + (tid >> 2), gcol = n0 + (tid & 3) * 32;
+  pre.valid = false;
+  if (p.residual && grow < p.M && gcol + 32 <= p.N && (p.ldr & 3) == 0) {
+    const float* rp = p.residual + (size_t)grow * p.ldr + gcol;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(rp + 4 * q);
+      pre.r[4 * q] = t[0]; pre.r[4 * q + 1] = t[1]; pre.r[4 * q + 2] = t[2]; pre.r[4 * q + 3] = t[3];
+    }
+    pre.valid = true;
+  }
+}
+
 __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC, int tid, int m0, int n0, int tile_n,
-                                         int nt) {
+                                         int nt, const ResidualPrefetch* pre = nullptr) {
   const int erow = tid >> 2;           // 0..63
   const int ecol = (tid & 3) * 32;     // 0,32,64,96 : one 32-column head per thread
   const int grow = m0 + erow;
@@ -101,7 +122,10 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
 #pragma unroll
     for (int e = 0; e < 32; ++e) v[e] = fmaxf(v[e], 0.f);
   }
-  if (p.residual && row_ok) {
+  if (pre && pre->valid) {
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] += pre->r[e];
+  } else if (p.residual && row_ok) {
     const float* rp = p.residual + (size_t)grow * p.ldr + gcol;
     if (full && (p.ldr & 3) == 0) {
 #pragma unroll

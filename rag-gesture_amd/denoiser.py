@@ -15,6 +15,7 @@ buffers.  What is hoisted out of the 50-step loop, all exact alge
     one K=2048 GEMM instead of three 512x512 GEMMs plus the 1536->512 mix.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -151,6 +152,23 @@ class DenoiserWeights:
         self.js = f32(js)
 
 
+def xcd_affine_order(n_groups, items_per_group, T, tile_rows=64, n_xcd=8):
+    """Launch order for per-row-group kernels (attention): workgroups are dealt round-robin to the 8
+    XCDs (block b -> XCD b % 8) and the GEMMs put M-tile t (rows [64t, 64t+64)) on XCD t % 8, so
+    row group g (rows [g*T, (g+1)*T)) is listed in the slots of the XCD that owns its middle row:
+    its activations are then read from the L2 they were written to instead of across the fabric.
+    Returns an int32 array: launch slot -> work item (g * items_per_group + i), -1 = idle slot."""
+    lists = [[] for _ in range(n_xcd)]
+    for g in range(n_groups):
+        x = ((g * T + T // 2) // tile_rows) % n_xcd
+        lists[x].extend(g * items_per_group + i for i in range(items_per_group))
+    depth = max(len(l) for l in lists)
+    out = np.full(depth * n_xcd, -1, dtype=np.int32)
+    for x, l in enumerate(lists):
+        out[x:x + n_xcd * len(l):n_xcd] = l
+    return out
+
+
 class DenoiserSession:
     """Buffers + conditioning state for B clips (R = 2B rows: conditional rows first, then the
     classifier-free rows).  Not re-entrant; one per (model, batch size, stream)."""
@@ -176,6 +194,13 @@ class DenoiserSession:
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
         self.src_mask = torch.ones(self.R, T, device=dev)
         self.qmask = torch.ones(3, self.R, T, device=dev)
+        ng = D // 128
+        order = xcd_affine_order if os.environ.get("RG_XCD_AFFINE", "1") == "1" else \
+            (lambda n, ipg, T_: np.arange(n * ipg, dtype=np.int32))
+        dv = lambda a: torch.from_numpy(a).to(dev)
+        self.perm_sa = dv(order(self.R, ng, T))
+        self.perm_ca = dv(order(self.R, 3 * ng, T))
+        self.perm_cac = dv(order(B, 3 * ng, T))
 
     # ------------------------------------------------------------------ once per clip
     def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None):
@@ -240,7 +265,8 @@ class DenoiserSession:
             G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv,
                    segs=[G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])], seg_len=D,
                    bias=lw["b_qkv"], softmax_cols=D)
-            h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D)
+            h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
+                   self.perm_sa, self.perm_sa.numel())
             G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb,
                    segs=[G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"],
                                scale_shift=ss[0])], seg_len=D, bias=lw["b_sao"], residual=xa, stats_out=sb_)
@@ -252,7 +278,8 @@ class DenoiserSession:
                 G.gemm(h, M=Mc, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
                        segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
                        bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
-                h.call("ca_attention", self.q3, self.a_pre[l], None, self.qmask_c, self.y3, self.st3c, B, B, T, D, 3)
+                h.call("ca_attention", self.q3, self.a_pre[l], None, self.qmask_c, self.y3, self.st3c, B, B, T, D, 3,
+                       self.perm_cac, self.perm_cac.numel())
                 segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3c[c], gamma=lw["ca_sg"][c],
                               beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
                 segs.append(G.Seg(xb))
@@ -263,7 +290,8 @@ class DenoiserSession:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
                        segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
                        bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
-                h.call("ca_attention", self.q3, self.a_pre[l], lw["a_unc"], self.qmask, self.y3, self.st3, R, B, T, D, 3)
+                h.call("ca_attention", self.q3, self.a_pre[l], lw["a_unc"], self.qmask, self.y3, self.st3, R, B, T, D, 3,
+                       self.perm_ca, self.perm_ca.numel())
                 segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3[c], gamma=lw["ca_sg"][c],
                               beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
                 segs.append(G.Seg(xb))

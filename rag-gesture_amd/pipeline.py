@@ -11,7 +11,11 @@ returned, mutated, exactly like the reference's `results = kwargs`).  All arithm
 HIP extension; there is no CPU fallback.
 
 Differences that are deliberate and documented in DESIGN.md:
-  * exemplar DDIM inversions of all clips run as ONE batch (the reference loops at batch 1);
+  * exemplar DDIM inversions run batched (the reference loops at batch 1);
+  * clips are independent between VAE encode and VAE decode, and at 43 latent tokens per clip a
+    single kernel chain cannot fill 256 CUs (every kernel is latency-, not throughput-bound): the
+    batch is cut into `lanes` groups of clips, each with its own HIP stream, denoiser session and
+    captured graphs (inversion -> splice -> sampling), which the hardware queues run concurrently;
   * randomness: by default torch's generator on the device; `inference_kwargs["noise_tape"]`
     (an object with draw(shape)) replays explicit noise in the reference's consumption order
      for parity tests.
@@ -122,6 +126,8 @@ class MotionDiffusion:
         self._sessions = {}
         self._graphs = {}
         self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
+        self.lanes = int(os.environ.get("RG_LANES", "1"))  # concurrent clip groups (streams) per forward
+        self._lane_streams = []
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -146,7 +152,9 @@ class MotionDiffusion:
             return fn(inputs)
         ent = self._graphs.get(key)
         if ent is None:
-            static = {k: (None if v is None else torch.empty_like(v).copy_(v)) for k, v in inputs.items()}
+            torch.cuda.synchronize()  # other lanes may have work in flight: capture from a quiet device
+            static = {k: (None if v is None else torch.empty(v.shape, dtype=v.dtype, device=v.device).copy_(v))
+                      for k, v in inputs.items()}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # warm-up outside capture (lazy module loads, allocator)
@@ -173,11 +181,19 @@ class MotionDiffusion:
     def cuda(self, *a):
         return self
 
-    def _session(self, B, role="sample"):
-        key = (B, role)
+    def _session(self, B, role="sample", lane=0):
+        key = (B, role, lane)
         if key not in self._sessions:
             self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B)
         return self._sessions[key]
+
+    def _lane_plan(self, B):
+        """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips."""
+        n = max(1, min(int(self.lanes), B))
+        while len(self._lane_streams) < n:
+            self._lane_streams.append(torch.cuda.Stream(device=self.device))
+        cuts = [(B * i) // n for i in range(n + 1)]
+        return [(i, self._lane_streams[i], cuts[i], cuts[i + 1]) for i in range(n)]
 
     def __call__(self, **kwargs):
         return self.forward(**kwargs)
@@ -234,8 +250,14 @@ class MotionDiffusion:
 
         kwargs.update({"motion_mask": motion_mask, "text": kwargs["word"], "raw_text": kwargs.get("raw_word"),
                        "text_times": kwargs.get("text_segments")})
-        sess = self._session(B)
-        sess.set_conditions(kwargs["word"], kwargs["audio"], kwargs["speaker_ids"], motion_mask, query_masks)
+        plan = self._lane_plan(B)
+        main = torch.cuda.current_stream()
+        word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
+        for lane, stream, b0, b1 in plan:
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                self._session(b1 - b0, "sample", lane).set_conditions(
+                    word[b0:b1], audio[b0:b1], spk[b0:b1], motion_mask[b0:b1], {c: qmask[b0:b1] for c in denoiser.CONDS})
         retrieval_dict = kwargs.get("re_dict")
         if retrieval_dict is None and self.model.database is not None:
             retrieval_dict = self.model.database(kwargs, kwargs.get("motion_length"), dev, idx=kwargs.get("sample_name"),
@@ -255,39 +277,12 @@ class MotionDiffusion:
                 h.call("copy_rows", prev_latent, masked, B, 1, D, T, idx[-1], T, idx[0])
             prev_latent = masked
 
+        # ---- every random draw happens here, for the whole batch, in the reference's order
         start_noise, invl = None, None
         if use_inversion:
             start_noise = tape.draw((B, T, D)).to(dev).contiguous()
-            ex = []  # (clip index, q_idx)
-            for b in range(B):
-                for q_idx in retrieval_dict["retr_uncropped_latents"][b].keys():
-                    ex.append((b, q_idx))
             if use_insertion_guidance:
                 invl = torch.zeros(S, B, T, D, device=dev)
-            if ex:
-                E = len(ex)
-                lat = lambda b, q: retrieval_dict["retr_uncropped_latents"][b][q]
-                cat = lambda key: torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0)
-                esess = self._session(E, "invert")
-                eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
-                esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
-                                     cat("retr_motion_mask").float(), eqm)
-                x_e = cat("retr_motion_latent").float().contiguous()
-                (inv,) = self._graph_run(("invert", E), dict(x=x_e), lambda s: (
-                    sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, E, T, D, device=dev)),))
-                for e, (b, q_idx) in enumerate(ex):
-                    r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
-                    q0, q1 = retrieval_dict["query_startends"][b][q_idx]
-                    assert r1 - r0 == q1 - q0
-                    lvl = inversion_start_time % S
-                    h.call("splice_rows", inv[lvl], start_noise, T, D, n_lat, e, b, r0, r1, q0, q1)
-                    if use_insertion_guidance:
-                        h.call("splice_rows_rep", inv, invl, T, D, n_lat, e, b, r0, r1, q0, q1, S, E, B)
-            if use_insertion_guidance and use_prev_latent and prev_latent is not None:
-                for idx in (up_i, ha_i, fa_i, lt_i):
-                    invl[:, :, idx[0], :] = 0
-
-        if use_inversion:
             x = start_noise
         else:
             x = tape.draw((B, T, D)).to(dev).contiguous()
@@ -312,16 +307,53 @@ class MotionDiffusion:
         elif not isinstance(tape, _TorchNoise):
             for _ in range(S):
                 tape.draw((B, T, D))
-        loop_in = dict(x=x, in_seq=in_seq, noise=inseq_noise, invl=invl)
-        if use_insertion_guidance:
-            gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
-            key = ("guided", B, in_seq is not None, gi, lr)
-            (x,) = self._graph_run(key, loop_in, lambda s: (sampler.ddim_guided_sample_loop(
-                sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),))
-        else:
-            key = ("sample", B, in_seq is not None)
-            (x,) = self._graph_run(key, loop_in, lambda s: (sampler.ddim_sample_loop(
-                sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
+        x_out = torch.empty(B, T, D, device=dev)
+
+        # ---- lanes: [exemplar inversion -> splice -> sampling] per clip group, concurrently
+        for lane, stream, b0, b1 in plan:
+            Bl = b1 - b0
+            sess = self._session(Bl, "sample", lane)
+            stream.wait_stream(main)
+            with torch.cuda.stream(stream):
+                if use_inversion:
+                    ex = [(b, q_idx) for b in range(b0, b1) for q_idx in retrieval_dict["retr_uncropped_latents"][b].keys()]
+                    if ex:
+                        E = len(ex)
+                        lat = lambda b, q: retrieval_dict["retr_uncropped_latents"][b][q]
+                        cat = lambda key: torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0)
+                        esess = self._session(E, "invert", lane)
+                        eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
+                        esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
+                                             cat("retr_motion_mask").float(), eqm)
+                        x_e = cat("retr_motion_latent").float().contiguous()
+                        (inv,) = self._graph_run(("invert", E, lane), dict(x=x_e), lambda s, esess=esess, E=E: (
+                            sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, E, T, D, device=dev)),))
+                        for e, (b, q_idx) in enumerate(ex):
+                            r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
+                            q0, q1 = retrieval_dict["query_startends"][b][q_idx]
+                            assert r1 - r0 == q1 - q0
+                            lvl = inversion_start_time % S
+                            h.call("splice_rows", inv[lvl], start_noise, T, D, n_lat, e, b, r0, r1, q0, q1)
+                            if use_insertion_guidance:
+                                h.call("splice_rows_rep", inv, invl, T, D, n_lat, e, b, r0, r1, q0, q1, S, E, B)
+                    if use_insertion_guidance and use_prev_latent and prev_latent is not None:
+                        for idx in (up_i, ha_i, fa_i, lt_i):
+                            invl[:, b0:b1, idx[0], :] = 0
+                sl = lambda t, dim: None if t is None else (t[b0:b1] if dim == 0 else t[:, b0:b1])
+                loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(inseq_noise, 1), invl=sl(invl, 1))
+                if use_insertion_guidance:
+                    gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
+                    key = ("guided", Bl, lane, in_seq is not None, gi, lr)
+                    (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess, gi=gi, lr=lr: (sampler.ddim_guided_sample_loop(
+                        sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),))
+                else:
+                    key = ("sample", Bl, lane, in_seq is not None)
+                    (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess: (sampler.ddim_sample_loop(
+                        sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
+                x_out[b0:b1].copy_(xl)
+        for _, stream, _, _ in plan:
+            main.wait_stream(stream)
+        x = x_out
         output = self.model.post_process(x)
         results["prev_latentout"] = output
         up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B), dict(z=output), lambda s: gre.decode(s["z"]))
