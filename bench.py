@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 16 guided, 32 base)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--db-size", type=int, default=32768, help="retrieval DB entries (guided workload)")
+    ap.add_argument("--phases", action="store_true",
+                    help="after the timed run, one extra step with device syncs at phase boundaries; prints the breakdown to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,6 +140,18 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * 150 * args.steps / dt
+
+    if args.phases and rank == 0:
+        model.profile_phases, model.phase_ms = True, {}
+        if guided:
+            model.model.database.phase_ms = model.phase_ms
+        one_step()
+        torch.cuda.synchronize()
+        model.profile_phases = False
+        if guided:
+            model.model.database.phase_ms = None
+        print("phase breakdown (ms, one synchronised step): " +
+              ", ".join("%s %.1f" % kv for kv in model.phase_ms.items()), file=sys.stderr)
 
     # ---- roofline of the dominant kernel (HIP events around every rg_gemm launch, one extra step)
     roofline = None

@@ -265,6 +265,16 @@ int rg_discourse_scores(rg_handle* h, const int* spk, const int* rel_off, const 
                         const int* rel_conn, const double* rel_prom, int n_entries, int q_sense, int q_conn,
                         int q_spk, double q_prom, double* score_out, int* top_out, void* stream);
 
+/* Candidate selection for the ranking walk of rag/discourse_retrieval.py:224-300: the reference sorts
+ * all scores and visits entries until it holds 10, so only entries with score >= the 10th largest
+ * score (with multiplicity; all ties included) and score > 0 can be visited.  Appends those
+ * entries (index, top_rel_idx, score) in arbitrary order to out_*[0..cap) and leaves their count in
+ * *cursor (a count > cap means the lists were truncated).  workspace: rg_select_workspace_doubles(n)
+ * doubles.  Comparisons only: exact. */
+int rg_select_top_scores(rg_handle* h, const double* score, const int* top, int n_entries, double* workspace,
+                         int* cursor, int cap, int* out_idx, int* out_top, double* out_score, void* stream);
+int rg_select_workspace_doubles(int n_entries);
+
 /* Tie-break similarity (rag/utils.py:109-121): out[j] = mean_{i < min(Lq, L_c)} q[i,:].feats_c[i,:]
  * for candidate entries c = cand[j]; feats is the ragged [sum L, dim] fp32 token-feature table with
  * int64 row offsets feat_off[n_entries+1]; fp64 accumulation. */

@@ -92,7 +92,146 @@ __global__ void __launch_bounds__(256) text_diag_sim_kernel(const float* __restr
   if (threadIdx.x == 0) out[blockIdx.x] = n > 0 ? ((red[0] + red[1]) + (red[2] + red[3])) / (double)n : 0.0;
 }
 
+// ---- candidate selection on the device --------------------------------------------------------
+// The reference sorts all N scores and walks the ranking until it has 10 entries, so only entries
+// whose score reaches the 10th largest one (with multiplicity) can ever be visited -- including
+// EVERY entry tied at that score (they are ordered by the text-similarity tie-break).  Instead of
+// copying N scores to the host, find that threshold on the device and compact the survivors:
+//   topk_local : each workgroup extracts the 10 largest scores of its slice (10 rounds of a
+//                block-wide max that consumes one instance per round: multiplicity is preserved);
+//   topk_merge : one workgroup repeats that over the per-block lists -> threshold;
+//   compact    : entries with score >= threshold and score > 0 are appended (atomic cursor;
+//                the host re-sorts the few survivors by index, which restores the stable order).
+// Scores are >= 0, comparisons only: the selection is exact.
+constexpr int SEL_K = 10;
+constexpr int SEL_IPT = 4;   // items per thread held in registers
+
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_xor(v, off);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// 10 rounds of "largest remaining value" over the items each thread holds in v[]; tops[r] valid on thread 0
+__device__ __forceinline__ void block_top_rounds(double (&v)[SEL_IPT], double* red, double (&tops)[SEL_K]) {
+  __shared__ int owner;
+  for (int r = 0; r < SEL_K; ++r) {
+    double m = v[0];
+#pragma unroll
+    for (int i = 1; i < SEL_IPT; ++i) m = v[i] > m ? v[i] : m;
+    const double wm = wave_max_f64(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wm;
+    if (threadIdx.x == 0) owner = 0x7fffffff;
+    __syncthreads();
+    double bm = red[0];
+    for (int w = 1; w < 4; ++w) bm = red[w] > bm ? red[w] : bm;
+    if (m == bm) atomicMin(&owner, (int)threadIdx.x);
+    __syncthreads();
+    if ((int)threadIdx.x == owner) {   // consume ONE instance of the maximum
+      bool done = false;
+#pragma unroll
+      for (int i = 0; i < SEL_IPT; ++i)
+        if (!done && v[i] == bm) {
+          v[i] = -1.0;
+          done = true;
+        }
+    }
+    tops[r] = bm;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) topk_local_kernel(const double* __restrict__ score, int n,
+                                                        double* __restrict__ block_tops) {
+  __shared__ double red[4];
+  const int per_block = 256 * SEL_IPT;
+  double v[SEL_IPT], tops[SEL_K];
+#pragma unroll
+  for (int i = 0; i < SEL_IPT; ++i) {
+    const int e = blockIdx.x * per_block + i * 256 + threadIdx.x;
+    v[i] = e < n ? score[e] : -1.0;
+  }
+  block_top_rounds(v, red, tops);
+  if (threadIdx.x == 0)
+    for (int r = 0; r < SEL_K; ++r) block_tops[blockIdx.x * SEL_K + r] = tops[r];
+}
+
+__global__ void __launch_bounds__(256) topk_merge_kernel(const double* __restrict__ block_tops, int n_lists,
+                                                        int n_entries, double* __restrict__ threshold,
+                                                        int* __restrict__ cursor) {
+  __shared__ double red[4];
+  // the 10th largest score lies among the per-block top-10 lists; fold them 1024 at a time
+  double carry[SEL_K];
+  for (int r = 0; r < SEL_K; ++r) carry[r] = -1.0;
+  const int total = n_lists * SEL_K;
+  for (int base = 0; base < total; base += 256 * SEL_IPT - SEL_K) {
+    double v[SEL_IPT], tops[SEL_K];
+#pragma unroll
+    for (int i = 0; i < SEL_IPT; ++i) {
+      const int j = i * 256 + threadIdx.x;          // slots [0, SEL_K) carry the running top-10
+      double x = -1.0;
+      if (j >= SEL_K && base + j - SEL_K < total) x = block_tops[base + j - SEL_K];
+      v[i] = x;
+    }
+    if (threadIdx.x < SEL_K) {
+      double c = -1.0;
+      for (int r = 0; r < SEL_K; ++r) c = ((int)threadIdx.x == r) ? carry[r] : c;
+      v[0] = c;
+    }
+    block_top_rounds(v, red, tops);
+    for (int r = 0; r < SEL_K; ++r) carry[r] = tops[r];   // tops[] is uniform across the block
+  }
+  if (threadIdx.x == 0) {
+    // fewer than 10 entries in total, or a 10th largest of 0: keep every positive score
+    double t = carry[SEL_K - 1];
+    if (n_entries <= 64 || t < 0.0) t = 0.0;
+    *threshold = t;
+    *cursor = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) compact_kernel(const double* __restrict__ score, const int* __restrict__ top,
+                                                     int n, const double* __restrict__ threshold,
+                                                     int* __restrict__ cursor, int cap, int* __restrict__ out_idx,
+                                                     int* __restrict__ out_top, double* __restrict__ out_score) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const double s = score[e];
+  if (s >= *threshold && s > 0.0) {
+    const int pos = atomicAdd(cursor, 1);
+    if (pos < cap) {
+      out_idx[pos] = e;
+      out_top[pos] = top[e];
+      out_score[pos] = s;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int rg_select_top_scores(rg_handle* h, const double* score, const int* top, int n_entries,
+                                    double* workspace, int* cursor, int cap, int* out_idx, int* out_top,
+                                    double* out_score, void* stream) {
+  RG_REQUIRE(h, score && top && workspace && cursor && out_idx && out_top && out_score, "null pointer");
+  RG_REQUIRE(h, n_entries > 0 && cap > 0, "bad shape");
+  const int nb = (n_entries + 256 * SEL_IPT - 1) / (256 * SEL_IPT);
+  hipStream_t s = rg_stream(stream);
+  // workspace: [nb * 10] per-block tops, then the threshold
+  hipLaunchKernelGGL(topk_local_kernel, dim3(nb), dim3(256), 0, s, score, n_entries, workspace);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(256), 0, s, workspace, nb, n_entries, workspace + nb * SEL_K,
+                     cursor);
+  hipLaunchKernelGGL(compact_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, score, top, n_entries,
+                     workspace + nb * SEL_K, cursor, cap, out_idx, out_top, out_score);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_select_workspace_doubles(int n_entries) {
+  return (n_entries + 256 * SEL_IPT - 1) / (256 * SEL_IPT) * SEL_K + 1;
+}
 
 extern "C" int rg_discourse_scores(rg_handle* h, const int* spk, const int* rel_off, const int* rel_sense,
                                    const int* rel_conn, const double* rel_prom, int n_entries, int q_sense,

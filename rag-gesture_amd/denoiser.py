@@ -189,6 +189,9 @@ class DenoiserSession:
         self.yf, self.st_f = f(M, D), f(M, D // G.STATS_COLS, 2)
         self.head = f(M, D)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
+        self.abf = None
+        if w.precision == "bf16" and os.environ.get("RG_STYL_PREPASS", "1") == "1":
+            self.abf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.qmask_c = torch.ones(3, B, T, device=dev)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
@@ -267,9 +270,15 @@ class DenoiserSession:
                    bias=lw["b_qkv"], softmax_cols=D)
             h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
                    self.perm_sa, self.perm_sa.numel())
-            G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb,
-                   segs=[G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"],
-                               scale_shift=ss[0])], seg_len=D, bias=lw["b_sao"], residual=xa, stats_out=sb_)
+            sa_seg = G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"], scale_shift=ss[0])
+            if self.abf is not None:
+                # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
+                # pre-pass instead of once per column tile and wave pair inside the GEMM's A prologue
+                G.stylize(h, [sa_seg], D, M, self.abf)
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_)
+            else:
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, segs=[sa_seg], seg_len=D, bias=lw["b_sao"], residual=xa,
+                       stats_out=sb_)
             # --- three parallel cross attentions on the same input
             if self.hcat is not None:
                 # production path: query projection + cross attention on the conditional rows only; the
@@ -303,9 +312,13 @@ class DenoiserSession:
             else:
                 G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, segs=[G.Seg(self.g)], seg_len=w.FF,
                        bias=lw["b_ff2"], stats_out=self.st_f)
-            G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa,
-                   segs=[G.Seg(self.yf, mode=G.A_STYL, stats=self.st_f, gamma=lw["ff_sg"], beta=lw["ff_sb"],
-                               scale_shift=ss[4])], seg_len=D, bias=lw["b_ffo"], residual=xc, stats_out=sa_)
+            ff_seg = G.Seg(self.yf, mode=G.A_STYL, stats=self.st_f, gamma=lw["ff_sg"], beta=lw["ff_sb"], scale_shift=ss[4])
+            if self.abf is not None:
+                G.stylize(h, [ff_seg], D, M, self.abf)
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_)
+            else:
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, segs=[ff_seg], seg_len=D, bias=lw["b_ffo"], residual=xc,
+                       stats_out=sa_)
         G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, segs=[G.Seg(xa)], seg_len=D, bias=w.b_out)
         return self.head
 

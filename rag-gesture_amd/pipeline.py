@@ -20,8 +20,10 @@ Differences that are deliberate and documented in DESIGN.md:
     (an object with draw(shape)) replays explicit noise in the reference's consumption order
      for parity tests.
 """
+import contextlib
 import copy
 import os
+import time
 
 import torch
 import yaml
@@ -126,6 +128,7 @@ class MotionDiffusion:
         self._sessions = {}
         self._graphs = {}
         self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
+        self.profile_phases, self.phase_ms = False, {}
         self.lanes = int(os.environ.get("RG_LANES", "1"))  # concurrent clip groups (streams) per forward
         self._lane_streams = []
 
@@ -140,6 +143,7 @@ class MotionDiffusion:
         m = self.model
         m.weights = denoiser.DenoiserWeights(state, m.cfg, self.schedule, self.device, precision=self.precision)
         m.gesture_rep_encoder = vae_mod.GestureRepEncoder(state, m.vae_cfgs, self.device, self.precision)
+        m.gesture_rep_encoder.graph_runner = self._graph_run
         self._sessions = {}
         self._graphs = {}
         return self
@@ -177,6 +181,19 @@ class MotionDiffusion:
     def eval(self):
         self.training = False
         return self
+
+    @contextlib.contextmanager
+    def _phase(self, name):
+        """Wall time of one phase of forward() into self.phase_ms (only when self.profile_phases is
+        set: it synchronises the device at phase boundaries, which the production path never does)."""
+        if not getattr(self, "profile_phases", False):
+            yield
+            return
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        yield
+        torch.cuda.synchronize()
+        self.phase_ms[name] = self.phase_ms.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
     def cuda(self, *a):
         return self
@@ -230,12 +247,10 @@ class MotionDiffusion:
         D = gre.vae_latent_dim
         eps_list = [tape.draw((B * 10, 1, D)) for _ in range(4)]
         f = lambda t: t.to(dev).float().contiguous()
-        enc_in = dict(up=f(kwargs["motion_upper"]), lo=f(kwargs["motion_lower"]), fa=f(kwargs["motion_face"]),
-                      ha=f(kwargs["motion_hands"]), tr=f(kwargs["trans"]), fac=f(kwargs["facial"]),
-                      con=f(kwargs["contact"]), e0=f(eps_list[0]), e1=f(eps_list[1]), e2=f(eps_list[2]),
-                      e3=f(eps_list[3]))
-        motion, tr_rel = self._graph_run(("enc", B), enc_in, lambda s: gre.encode_device(
-            s["up"], s["lo"], s["fa"], s["ha"], s["tr"], s["fac"], s["con"], [s["e0"], s["e1"], s["e2"], s["e3"]]))
+        with self._phase("vae_encode"):
+            motion, tr_rel = gre.encode_device_graphed(
+                f(kwargs["motion_upper"]), f(kwargs["motion_lower"]), f(kwargs["motion_face"]), f(kwargs["motion_hands"]),
+                f(kwargs["trans"]), f(kwargs["facial"]), f(kwargs["contact"]), [f(e) for e in eps_list])
         kwargs["trans"].copy_(tr_rel.to(kwargs["trans"].device))  # the reference's in-place re-zeroing
         motion_mask = gre.latent_mask(kwargs["motion_mask"].float())
         T = motion.shape[1]
@@ -253,16 +268,18 @@ class MotionDiffusion:
         plan = self._lane_plan(B)
         main = torch.cuda.current_stream()
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
-        for lane, stream, b0, b1 in plan:
-            stream.wait_stream(main)
-            with torch.cuda.stream(stream):
-                self._session(b1 - b0, "sample", lane).set_conditions(
-                    word[b0:b1], audio[b0:b1], spk[b0:b1], motion_mask[b0:b1], {c: qmask[b0:b1] for c in denoiser.CONDS})
+        with self._phase("conditions"):
+            for lane, stream, b0, b1 in plan:
+                stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    self._session(b1 - b0, "sample", lane).set_conditions(
+                        word[b0:b1], audio[b0:b1], spk[b0:b1], motion_mask[b0:b1], {c: qmask[b0:b1] for c in denoiser.CONDS})
         retrieval_dict = kwargs.get("re_dict")
         if retrieval_dict is None and self.model.database is not None:
-            retrieval_dict = self.model.database(kwargs, kwargs.get("motion_length"), dev, idx=kwargs.get("sample_name"),
-                                                 retrieval_method=kwargs.get("retrieval_method", "discourse"),
-                                                 gesture_rep_encoder=gre, noise=tape)
+            with self._phase("retrieval"):
+                retrieval_dict = self.model.database(kwargs, kwargs.get("motion_length"), dev, idx=kwargs.get("sample_name"),
+                                                     retrieval_method=kwargs.get("retrieval_method", "discourse"),
+                                                     gesture_rep_encoder=gre, noise=tape)
         results = kwargs
         results["retrieval_dict"] = copy.copy(retrieval_dict)
 
@@ -322,12 +339,14 @@ class MotionDiffusion:
                         lat = lambda b, q: retrieval_dict["retr_uncropped_latents"][b][q]
                         cat = lambda key: torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0)
                         esess = self._session(E, "invert", lane)
-                        eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
-                        esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
-                                             cat("retr_motion_mask").float(), eqm)
-                        x_e = cat("retr_motion_latent").float().contiguous()
-                        (inv,) = self._graph_run(("invert", E, lane), dict(x=x_e), lambda s, esess=esess, E=E: (
-                            sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, E, T, D, device=dev)),))
+                        with self._phase("exemplar_conditions"):
+                            eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
+                            esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
+                                                 cat("retr_motion_mask").float(), eqm)
+                            x_e = cat("retr_motion_latent").float().contiguous()
+                        with self._phase("inversion"):
+                            (inv,) = self._graph_run(("invert", E, lane), dict(x=x_e), lambda s, esess=esess, E=E: (
+                                sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, E, T, D, device=dev)),))
                         for e, (b, q_idx) in enumerate(ex):
                             r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
                             q0, q1 = retrieval_dict["query_startends"][b][q_idx]
@@ -341,22 +360,24 @@ class MotionDiffusion:
                             invl[:, b0:b1, idx[0], :] = 0
                 sl = lambda t, dim: None if t is None else (t[b0:b1] if dim == 0 else t[:, b0:b1])
                 loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(inseq_noise, 1), invl=sl(invl, 1))
-                if use_insertion_guidance:
-                    gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
-                    key = ("guided", Bl, lane, in_seq is not None, gi, lr)
-                    (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess, gi=gi, lr=lr: (sampler.ddim_guided_sample_loop(
-                        sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),))
-                else:
-                    key = ("sample", Bl, lane, in_seq is not None)
-                    (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess: (sampler.ddim_sample_loop(
-                        sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
-                x_out[b0:b1].copy_(xl)
+                with self._phase("sampling"):
+                    if use_insertion_guidance:
+                        gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
+                        key = ("guided", Bl, lane, in_seq is not None, gi, lr)
+                        (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess, gi=gi, lr=lr: (
+                            sampler.ddim_guided_sample_loop(sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),))
+                    else:
+                        key = ("sample", Bl, lane, in_seq is not None)
+                        (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess: (sampler.ddim_sample_loop(
+                            sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
+                    x_out[b0:b1].copy_(xl)
         for _, stream, _, _ in plan:
             main.wait_stream(stream)
         x = x_out
         output = self.model.post_process(x)
         results["prev_latentout"] = output
-        up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B), dict(z=output), lambda s: gre.decode(s["z"]))
+        with self._phase("vae_decode"):
+            up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B), dict(z=output), lambda s: gre.decode(s["z"]))
         results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
         results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
         results["pred_contact"] = co

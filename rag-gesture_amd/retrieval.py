@@ -117,6 +117,51 @@ class DiscourseIndex:
             raise capi.RgError("rg_discourse_scores failed: %s" % lib.rg_last_error(self.h._h).decode())
         return self._score.cpu().numpy(), self._top.cpu().numpy()
 
+    def sweep_async(self, queries):
+        """Launch sweep + device-side candidate selection for a list of (sense, conn, speaker_id, q_prom)
+        without any host synchronisation; returns a ticket for collect()."""
+        lib, vp = self.h.lib, ctypes.c_void_p
+        Q, n = len(queries), self.n
+        cap = n
+        nws = lib.rg_select_workspace_doubles(n)
+        score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
+        top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
+        ws = torch.empty(Q, nws, dtype=torch.float64, device=self.dev)
+        cursor = torch.zeros(Q, dtype=torch.int32, device=self.dev)
+        o_idx = torch.empty(Q, cap, dtype=torch.int32, device=self.dev)
+        o_top = torch.empty(Q, cap, dtype=torch.int32, device=self.dev)
+        o_score = torch.empty(Q, cap, dtype=torch.float64, device=self.dev)
+        s = torch.cuda.current_stream().cuda_stream
+        for q, (sense, conn, speaker_id, q_prom) in enumerate(queries):
+            rc = lib.rg_discourse_scores(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
+                                         vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
+                                         vp(self.rel_prom.data_ptr()), n, self.sense_code.get(sense, -2),
+                                         self.conn_code.get(conn, -1), int(speaker_id),
+                                         ctypes.c_double(float("nan") if q_prom is None else float(q_prom)),
+                                         vp(score[q].data_ptr()), vp(top[q].data_ptr()), vp(s))
+            if rc == 0:
+                rc = lib.rg_select_top_scores(self.h._h, vp(score[q].data_ptr()), vp(top[q].data_ptr()), n,
+                                              vp(ws[q].data_ptr()), vp(cursor[q:].data_ptr()), cap,
+                                              vp(o_idx[q].data_ptr()), vp(o_top[q].data_ptr()),
+                                              vp(o_score[q].data_ptr()), vp(s))
+            if rc != 0:
+                raise capi.RgError("retrieval sweep failed: %s" % lib.rg_last_error(self.h._h).decode())
+        return dict(cursor=cursor, idx=o_idx, top=o_top, score=o_score, keep=(score, top, ws))
+
+    @staticmethod
+    def collect(ticket):
+        """One synchronisation for the whole batch: per query (entry idx ascending, score, top_rel_idx)."""
+        counts = ticket["cursor"].cpu().numpy()
+        m = int(counts.max()) if counts.size else 0
+        idx = ticket["idx"][:, :m].cpu().numpy()
+        top = ticket["top"][:, :m].cpu().numpy()
+        score = ticket["score"][:, :m].cpu().numpy()
+        out = []
+        for q, c in enumerate(counts):
+            o = np.argsort(idx[q, :c], kind="stable")
+            out.append((idx[q, :c][o], score[q, :c][o], top[q, :c][o]))
+        return out
+
     def sims(self, q_feat_dev, cand):
         """HIP tie-break reduction: mean diagonal similarity of the query to each candidate entry."""
         lib, vp = self.h.lib, ctypes.c_void_p
@@ -131,9 +176,18 @@ class DiscourseIndex:
         return out.cpu().numpy()
 
 
-def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text):
+def discourse_queries(discourse, prominence, speaker_id):
+    """The (sense, connective, speaker, query prominence) tuples discourse_retrieval sweeps the DB with."""
+    conns = [d[0] for d in discourse]
+    q_prom = map_conns_to_prominence(conns, prominence)
+    return [(d[1], d[0], speaker_id, None if q_prom[i] is None else q_prom[i][1]) for i, d in enumerate(discourse)]
+
+
+def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text, survivors=None):
     """Same contract as rag/discourse_retrieval.py:8-316 (returns sample_indexes, d_bounds,
-    query_bounds) with the DB sweep on the GPU."""
+    query_bounds) with the DB sweep and the candidate selection on the GPU.  `survivors`: the
+    collect()ed results of a sweep_async() over discourse_queries(...) launched earlier (batched over
+    clips); None = sweep here."""
     d_bounds, sample_indexes, query_bounds = {}, {}, {}
     if len(discourse) == 0:
         return sample_indexes, d_bounds, query_bounds
@@ -142,17 +196,16 @@ def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text):
     query_bounds = {i: (d[0].lower(), d[1], d[6], d[7]) for i, d in enumerate(discourse)}
     q_prom = map_conns_to_prominence(conns, prominence)
     q_dev = encoded_text.to(index.dev).float().contiguous()
+    if survivors is None:
+        survivors = index.collect(index.sweep_async(discourse_queries(discourse, prominence, speaker_id)))
     for qi, (q_sense, q_conn) in enumerate(zip(senses, conns)):
-        qp = q_prom[qi]
-        score, top = index.scores(q_sense, q_conn, speaker_id, None if qp is None else qp[1])
-        # Only the top tiers are ever visited (the walk stops at 10 entries): keep the entries whose score
-        # reaches the 10th largest one, then order them like sorted(..., reverse=True) (stable among equals).
-        if score.shape[0] > 64:
-            kth = np.partition(score, score.shape[0] - 10)[score.shape[0] - 10]
-            keep = np.flatnonzero((score >= kth) & (score > 0))
-        else:
-            keep = np.arange(score.shape[0])
-        order = keep[np.argsort(-score[keep], kind="stable")]
+        # Only the top tiers are ever visited (the walk stops at 10 entries): the device kept the entries
+        # whose score reaches the 10th largest one (all ties included); order them like
+        # sorted(..., reverse=True) (stable among equals).  score/top are sparse views indexed by entry.
+        keep, kscore, ktop = survivors[qi]
+        score = dict(zip(keep.tolist(), kscore.tolist()))
+        top = dict(zip(keep.tolist(), ktop.tolist()))
+        order = keep[np.argsort(-kscore, kind="stable")].tolist()
         ranked, i = [], 0
         while i < len(order) and len(ranked) < 10:
             sc = score[order[i]]
@@ -263,8 +316,9 @@ class RetrievalDatabase:
         self.latent_dim, self.text_latent_dim = latent_dim, text_latent_dim
         self.index = DiscourseIndex(metadata, device)
         self.test_indexes, self.test_dbounds, self.test_qbounds = {}, {}, {}
+        self.phase_ms = None  # dict: MotionDiffusion's phase profiler also collects the sub-phases here
 
-    def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None):
+    def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None, survivors=None):
         """raggesture.py:313-477 (eval branch, first-call behaviour; results cached per idx)."""
         if retr_method != "discourse":
             raise NotImplementedError("only the discourse retrieval method is built (llm / gesture_type: next)")
@@ -272,7 +326,7 @@ class RetrievalDatabase:
             si, db_b, qb = (self.test_indexes[idx][retr_method], self.test_dbounds[idx][retr_method],
                             self.test_qbounds[idx][retr_method])
         else:
-            si, db_b, qb = discourse_retrieval(self.index, discourse, prominence, speaker_id, text_features)
+            si, db_b, qb = discourse_retrieval(self.index, discourse, prominence, speaker_id, text_features, survivors)
             self.test_indexes.setdefault(idx, {})[retr_method] = si
             self.test_dbounds.setdefault(idx, {})[retr_method] = db_b
             self.test_qbounds.setdefault(idx, {})[retr_method] = qb
@@ -282,6 +336,17 @@ class RetrievalDatabase:
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
 
+    def _tick(self, name):
+        """Sub-phase wall times (with device syncs) when a profiler dict is attached; else a no-op."""
+        if self.phase_ms is None:
+            return
+        import time
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        if name is not None:
+            self.phase_ms[name] = self.phase_ms.get(name, 0.0) + (now - self._t_last) * 1e3
+        self._t_last = now
+
     def forward(self, conditions, lengths, device, idx=None, retrieval_method="gesture_type", gesture_rep_encoder=None,
                 noise=None):
         """conditions: the model's kwargs dict (text_features, discourse, prominence, speaker_ids, ...)."""
@@ -290,15 +355,32 @@ class RetrievalDatabase:
         B = len(conditions["text_features"])
         chunk, L = self.motion_framechunksize, self.max_seq_len // self.motion_framechunksize
         T, D = 4 * L + 3, self.latent_dim
+        tick = self._tick
+        tick(None)
         plans, ex = [], []
+        spks = [int(v) for v in conditions["speaker_ids"][:, 0].tolist()]
+        # every clip's DB sweeps are launched before the first host read-back: one synchronisation per batch
+        pending, queries = {}, []
+        if retrieval_method == "discourse":
+            for b in range(B):
+                key = idx[b] if idx is not None else None
+                if key is not None and key in self.test_indexes and retrieval_method in self.test_indexes[key]:
+                    continue
+                qs = discourse_queries(conditions["discourse"][b], conditions["prominence"][b], spks[b])
+                pending[b] = (len(queries), len(qs))
+                queries += qs
+        swept = self.index.collect(self.index.sweep_async(queries)) if queries else []
         for b in range(B):
-            spk = int(conditions["speaker_ids"][b, 0].item())
+            spk = spks[b]
+            surv = swept[pending[b][0]:pending[b][0] + pending[b][1]] if b in pending else None
             ri, rb, qb = self.retrieve(retrieval_method, conditions["text_features"][b], conditions["discourse"][b],
-                                       conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None)
+                                       conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None,
+                                       survivors=surv)
             plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
             plans.append((plan, rb, qb))
             for qp, name, placed in plan:
                 ex.append((b, qp, name, placed))
+        tick("retrieval.search")
         # ---- fetch + VAE-encode every visited exemplar in one batch (noise in the reference's order)
         recs = [self.dataset[name] for _, _, name, _ in ex]
         lat = None
@@ -310,6 +392,7 @@ class RetrievalDatabase:
             eps_list = [torch.cat([e[p].to(dev) for e in eps], dim=0) for p in range(4)]
             lat, _ = gre.encode(stack("motion_upper"), stack("motion_lower"), stack("motion_face"), stack("motion_hands"),
                                 stack("trans"), stack("facial"), stack("contact"), stack("motion_mask"), eps_list)
+        tick("retrieval.exemplar_encode")
         retr_se, query_se, retr_lats, names_out, type2words = ([{} for _ in range(B)] for _ in range(5))
         zero_motion = torch.zeros(B, T, D, device=dev)
         tmpl = self.dataset[0] if self.dataset is not None else None
@@ -343,6 +426,7 @@ class RetrievalDatabase:
         fl = list(range(2 * L + 2, 3 * L + 2)) + list(range(3 * L + 3, T))
         src_mask[:, fl] = 0
         raw_motion_latents[:, fl, :] = 0
+        tick("retrieval.assemble")
         return dict(re_text=None, re_motion=None, re_mask=src_mask,
                     raw_motion_latents=raw_motion_latents.view(B, self.num_retrieval, T, D),
                     raw_motion=raw_motion.view(B, self.num_retrieval, self.max_seq_len, -1),

@@ -253,11 +253,22 @@ class GestureRepEncoder:
         face, lowertrans = the reference's rsample order).  Returns (latent [B,43,D], mask [B,43]).
         Like the reference it re-zeroes x/z of `motion_transl` IN PLACE (:231-232)."""
         f = lambda t: t.to(self.dev).float().contiguous()
-        latent, tr_rel = self.encode_device(f(motion_upper), f(motion_lower), f(motion_face), f(motion_hands),
-                                            f(motion_transl), f(motion_facial), f(motion_contact),
-                                            [f(e) for e in eps_list])
+        latent, tr_rel = self.encode_device_graphed(f(motion_upper), f(motion_lower), f(motion_face), f(motion_hands),
+                                                    f(motion_transl), f(motion_facial), f(motion_contact),
+                                                    [f(e) for e in eps_list])
         motion_transl.copy_(tr_rel.to(motion_transl.device))  # the reference's in-place mutation
         return latent, self.latent_mask(motion_mask)
+
+    graph_runner = None  # callable(key, inputs, fn) -> outputs; set by MotionDiffusion (HIP-graph cache)
+
+    def encode_device_graphed(self, up, lo, fa, ha, tr, fac, con, eps_list):
+        """encode_device through the owner's graph cache (one captured launch sequence per batch size)."""
+        if self.graph_runner is None:
+            return self.encode_device(up, lo, fa, ha, tr, fac, con, eps_list)
+        ins = dict(up=up, lo=lo, fa=fa, ha=ha, tr=tr, fac=fac, con=con, e0=eps_list[0], e1=eps_list[1],
+                   e2=eps_list[2], e3=eps_list[3])
+        return self.graph_runner(("enc", up.shape[0]), ins, lambda s: self.encode_device(
+            s["up"], s["lo"], s["fa"], s["ha"], s["tr"], s["fac"], s["con"], [s["e0"], s["e1"], s["e2"], s["e3"]]))
 
     def latent_mask(self, motion_mask):
         mm = motion_mask.to(self.dev).float()[:, ::self.frame_chunk_size]
