@@ -88,6 +88,180 @@ __global__ void __launch_bounds__(256) mha_kernel(const float* __restrict__ q, i
   }
 }
 
+
+// ------------------------------------------------------------------------------ MHA on the matrix cores
+// bf16-path variant (the VAE linears around it already round their operands to bf16): K and V^T of
+// one (batch, head) are staged once per workgroup in LDS as bf16; every wave owns 16 query rows.
+//   S^T = K Q^T      v_mfma_f32_16x16x32_bf16, A = K rows from LDS (b128, row stride hd+8: conflict
+//                    free), B = Q (hi + lo bf16 split, registers);  C layout: lane -> query lane&15,
+//                    keys 16*nb + 4*(lane>>4) + e  ->  the softmax over keys is in-register plus two
+//                    cross-lane steps (xor 16, 32), and
+//   O   = P V        needs NO transposition of P: a lane's 4+4 probabilities of key blocks 2s, 2s+1
+//                    are exactly an A fragment of the k-step s if V^T is read with the same key
+//                    permutation (two b64 LDS reads per fragment).  P is split hi + lo as well.
+typedef __attribute__((ext_vector_type(8))) __bf16 mh_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float mh_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int mh_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int mh_u32x2;
+
+constexpr int MH_MAX_SK = 192;
+
+__device__ __forceinline__ unsigned short mh_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float mh_bf16_val(float f) { return (float)(__bf16)f; }
+__device__ __forceinline__ unsigned int mh_pack(float a, float b) {
+  return (unsigned int)mh_bf16_bits(a) | ((unsigned int)mh_bf16_bits(b) << 16);
+}
+
+// HD_ = head dim padded to a multiple of 32 (the MFMA k-step); HDR = real head dim (16 -> zero padded)
+template <int HD_, int HDR>
+__global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                      int ldk, const float* __restrict__ v, int ldv,
+                                                      float* __restrict__ o, int ldo, int H, int Sq, int Sk, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+  constexpr int KST = HD_ + 8;                 // bf16 elements per K row (pad: 16 key rows hit 16 bank groups)
+  constexpr int KS = HD_ / 32;                 // k-steps of S^T = K Q^T
+  constexpr int ND = HDR / 16;                 // 16-column blocks of O
+  constexpr int NB = MH_MAX_SK / 16;           // key blocks held in registers
+  const int Skp = (Sk + 31) & ~31;             // keys padded to whole PV k-steps (P = 0, V^T = 0 there)
+  const int VST = Skp + 8;                     // bf16 elements per V^T row
+  unsigned short* sK = reinterpret_cast<unsigned short*>(smraw);           // [Skp][KST]
+  unsigned short* sVt = sK + (size_t)Skp * KST;                            // [HD_][VST]
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  // ---- stage K (row major) and V^T as bf16
+  for (int i = threadIdx.x; i < Skp * (HD_ / 4); i += 256) {
+    const int j = i / (HD_ / 4), d4 = (i % (HD_ / 4)) * 4;
+    mh_f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (j < Sk && d4 < HDR) {
+      kv = *reinterpret_cast<const mh_f32x4*>(k + ((size_t)b * Sk + j) * ldk + h * HDR + d4);
+      vv = *reinterpret_cast<const mh_f32x4*>(v + ((size_t)b * Sk + j) * ldv + h * HDR + d4);
+    }
+    *reinterpret_cast<mh_u32x2*>(sK + (size_t)j * KST + d4) = mh_u32x2{mh_pack(kv[0], kv[1]), mh_pack(kv[2], kv[3])};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sVt[(size_t)(d4 + e) * VST + j] = mh_bf16_bits(vv[e]);
+  }
+  __syncthreads();
+
+  const int q0 = blockIdx.y * 64 + wave * 16;
+  if (q0 >= Sq) return;
+  // ---- Q fragments (B operand): lane -> query q0 + l15, d = 32*ks + 8*g .. +7, scaled, hi/lo split
+  mh_bf16x8 qh[KS], ql[KS];
+  {
+    const int qr = min(q0 + l15, Sq - 1);
+    const float* qp = q + ((size_t)b * Sq + qr) * ldq + h * HDR + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      mh_f32x4 a = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+      if (32 * ks + 8 * g < HDR) {
+        a = *reinterpret_cast<const mh_f32x4*>(qp + 32 * ks);
+        c = *reinterpret_cast<const mh_f32x4*>(qp + 32 * ks + 4);
+      }
+      float x[8] = {a[0] * scale, a[1] * scale, a[2] * scale, a[3] * scale,
+                    c[0] * scale, c[1] * scale, c[2] * scale, c[3] * scale};
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = x[e] - mh_bf16_val(x[e]);
+      qh[ks] = __builtin_bit_cast(mh_bf16x8, mh_u32x4{mh_pack(x[0], x[1]), mh_pack(x[2], x[3]), mh_pack(x[4], x[5]), mh_pack(x[6], x[7])});
+      ql[ks] = __builtin_bit_cast(mh_bf16x8, mh_u32x4{mh_pack(r[0], r[1]), mh_pack(r[2], r[3]), mh_pack(r[4], r[5]), mh_pack(r[6], r[7])});
+    }
+  }
+  // ---- S^T blocks
+  const int nblk = Skp / 16;
+  mh_f32x4 sc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    sc[nb] = mh_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (nb < nblk) {
+      const unsigned short* kr = sK + (size_t)(16 * nb + l15) * KST + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const mh_bf16x8 kf = *reinterpret_cast<const mh_bf16x8*>(kr + 32 * ks);
+        sc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qh[ks], sc[nb], 0, 0, 0);
+        sc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, ql[ks], sc[nb], 0, 0, 0);
+      }
+    }
+  }
+  // ---- softmax over keys for query l15: keys 16*nb + 4*g + e
+  float mx = -INFINITY;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool valid = nb < nblk && 16 * nb + 4 * g + e < Sk;
+      sc[nb][e] = valid ? sc[nb][e] : -INFINITY;
+      mx = fmaxf(mx, sc[nb][e]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float p = (sc[nb][e] == -INFINITY) ? 0.f : expf(sc[nb][e] - mx);
+      sc[nb][e] = p;
+      sum += p;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  // ---- O = P V
+  mh_f32x4 oc[ND];
+#pragma unroll
+  for (int nd = 0; nd < ND; ++nd) oc[nd] = mh_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s2 = 0; s2 < NB / 2; ++s2) {
+    if (2 * s2 < nblk) {
+      float p[8], r[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        p[e] = sc[2 * s2][e] * inv;
+        p[4 + e] = sc[2 * s2 + 1][e] * inv;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = p[e] - mh_bf16_val(p[e]);
+      const mh_bf16x8 ph = __builtin_bit_cast(mh_bf16x8, mh_u32x4{mh_pack(p[0], p[1]), mh_pack(p[2], p[3]), mh_pack(p[4], p[5]), mh_pack(p[6], p[7])});
+      const mh_bf16x8 pl = __builtin_bit_cast(mh_bf16x8, mh_u32x4{mh_pack(r[0], r[1]), mh_pack(r[2], r[3]), mh_pack(r[4], r[5]), mh_pack(r[6], r[7])});
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) {
+        const unsigned short* vr = sVt + (size_t)(16 * nd + l15) * VST + 32 * s2 + 4 * g;
+        const mh_u32x2 v0 = *reinterpret_cast<const mh_u32x2*>(vr);
+        const mh_u32x2 v1 = *reinterpret_cast<const mh_u32x2*>(vr + 16);
+        const mh_bf16x8 vf = __builtin_bit_cast(mh_bf16x8, mh_u32x4{v0[0], v0[1], v1[0], v1[1]});
+        oc[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vf, oc[nd], 0, 0, 0);
+        oc[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vf, oc[nd], 0, 0, 0);
+      }
+    }
+  }
+  // ---- store: lane -> rows q0 + 4*g + e, column 16*nd + l15
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int r = q0 + 4 * g + e;
+    if (r < Sq) {
+      float* orow = o + ((size_t)b * Sq + r) * ldo + h * HDR;
+#pragma unroll
+      for (int nd = 0; nd < ND; ++nd) orow[16 * nd + l15] = oc[nd][e];
+    }
+  }
+}
+
+template <int HD_, int HDR>
+static int launch_mha_mfma(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                           float* o, int ldo, int B, int H, int Sq, int Sk, hipStream_t s) {
+  const int Skp = (Sk + 31) & ~31;
+  const size_t lds = ((size_t)Skp * (HD_ + 8) + (size_t)HD_ * (Skp + 8)) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)mha_mfma_kernel<HD_, HDR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((mha_mfma_kernel<HD_, HDR>), dim3(B * H, (Sq + 63) / 64), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, o, ldo,
+                     H, Sq, Sk, 1.0f / sqrtf((float)HDR));
+  return 0;
+}
+
 // ------------------------------------------------------------------------------ LayerNorm, one wave per row
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                        const float* __restrict__ b, float* __restrict__ out, int rows,
@@ -258,6 +432,21 @@ extern "C" int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int
   }
   hipLaunchKernelGGL(mha_kernel, dim3(B * H, (Sq + QB - 1) / QB), dim3(256), lds, rg_stream(stream), q, ldq, k, ldk, v,
                      ldv, o, ldo, H, Sq, Sk, hd, 1.0f / sqrtf((float)hd));
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_mha_bf16(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                           float* o, int ldo, int B, int H, int Sq, int Sk, int hd, void* stream) {
+  RG_REQUIRE(h, q && k && v && o, "null pointer");
+  RG_REQUIRE(h, B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= MH_MAX_SK, "bad shape (Sk <= 192)");
+  RG_REQUIRE(h, hd == 128 || hd == 64 || hd == 32 || hd == 16, "head dim must be 16, 32, 64 or 128");
+  RG_REQUIRE(h, ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "row strides must be multiples of 4 floats");
+  hipStream_t s = rg_stream(stream);
+  if (hd == 128) launch_mha_mfma<128, 128>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
+  else if (hd == 64) launch_mha_mfma<64, 64>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
+  else if (hd == 32) launch_mha_mfma<32, 32>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
+  else launch_mha_mfma<32, 16>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

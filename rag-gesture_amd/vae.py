@@ -72,6 +72,7 @@ class TransformerVAE:
         self.cfg = vcfg
         self.dev = torch.device(device)
         self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        self.precision = precision
         split = precision == "fp32"
         D = self.D = vcfg["latent_dim"]
         self.nfeats, self.chunk, self.frames = vcfg["nfeats"], vcfg["frame_chunk_size"], vcfg["num_frames"]
@@ -129,8 +130,12 @@ class TransformerVAE:
         hd = self.D // heads
         s = torch.cuda.current_stream().cuda_stream
         vp = ctypes.c_void_p
-        rc = self.h.lib.rg_mha(self.h._h, vp(q.data_ptr()), ldq, vp(k.data_ptr()), ldk, vp(v.data_ptr()), ldv,
-                               vp(o.data_ptr()), self.D, B, heads, Sq, Sk, hd, vp(s))
+        # bf16 path: attention on the matrix cores; fp32 ("bf16x3") path: the exact fp32 VALU kernel
+        fast = self.precision == "bf16" and hd in (16, 32, 64, 128) and Sk <= 192 and ldq % 4 == 0 and ldk % 4 == 0 \
+            and ldv % 4 == 0
+        fn = self.h.lib.rg_mha_bf16 if fast else self.h.lib.rg_mha
+        rc = fn(self.h._h, vp(q.data_ptr()), ldq, vp(k.data_ptr()), ldk, vp(v.data_ptr()), ldv,
+                vp(o.data_ptr()), self.D, B, heads, Sq, Sk, hd, vp(s))
         if rc != 0:
             raise capi.RgError("rg_mha failed: %s" % self.h.lib.rg_last_error(self.h._h).decode())
 
