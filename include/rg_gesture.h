@@ -122,8 +122,9 @@ typedef struct rg_gemm_desc {
   int seg_len;            // K columns per fp32 segment (K = nseg * seg_len, last may be short)
   int nseg;
   rg_a_segment seg[RG_MAX_SEG];
-  int gb_group;           // >0: gamma/beta of every segment are offset by (n0 / gb_group) * gb_stride
-  int gb_stride;
+  int gb_group;           // >0: column tiles [g*gb_group, (g+1)*gb_group) form group g: gamma/beta of every fp32
+  int gb_stride;          //     segment, or the bf16 A pointer, are offset by g * gb_stride elements (several
+                          //     projections of differently normalised copies of the same rows in one launch)
   const void* W;          // bf16 [Np, ldw]  (rows = output features, K contiguous, zero padded)
   int ldw;
   int act;                // 0 none, 1 GELU(erf), 2 ReLU
@@ -136,10 +137,12 @@ typedef struct rg_gemm_desc {
   int out_bf16;           // 1: out is bf16, 0: fp32
   void* out;
   int ldo;
-  int pad2_;
+  int ldo2;               // row stride (elements) of out2
   float* stats_out;       // [M][N/64][2] partial (sum, sumsq) of the final fp32 output, or null
   const void* W_lo;       // null, or bf16 [Np, ldw] = bf16(W - float(bf16(W))): selects the precise
                           // "bf16x3" mode (hi*hi + hi*lo + lo*hi), fp32 A segments only
+  void* out2;             // null, or bf16 [M, ldo2]: a second, bf16-rounded copy of the output (the next
+                          // GEMM's A operand, written by the producer instead of converted by every consumer tile)
 } rg_gemm_desc;
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);

@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
       if constexpr (SPLIT) st.wlo[j] = *reinterpret_cast<const u32x4*>(Wl + off);
     }
     if constexpr (A_BF16) {
-      const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A);
+      const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A) +
+                                 (p.gb_group > 0 ? (n0 / p.gb_group) * p.gb_stride : 0);   // grouped A (see header)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (FAST || (arow_ok[j] && k0 + 8 <= p.K))

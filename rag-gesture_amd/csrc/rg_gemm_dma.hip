@@ -120,7 +120,8 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
     unsigned char* st = smem + (kt % NS) * STAGE;
     const int k0 = kt * BK;
     if constexpr (A_BF16) {
-      const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A);
+      const unsigned short* Ab = reinterpret_cast<const unsigned short*>(p.A) +
+                                 (p.gb_group > 0 ? (n0 / p.gb_group) * p.gb_stride : 0);   // grouped A (see header)
 #pragma unroll
       for (int i = 0; i < ACH; ++i)
         __builtin_amdgcn_global_load_lds((const void*)(Ab + (size_t)a_rowidx[i] * p.lda + k0 + a_lc[i] * 8),

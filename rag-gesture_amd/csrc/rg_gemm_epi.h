@@ -153,6 +153,18 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
     }
   }
   if (!row_ok) return;
+  if (p.out2) {
+    unsigned short* o2 = reinterpret_cast<unsigned short*>(p.out2) + (size_t)grow * p.ldo2 + gcol;
+    if (full && (p.ldo2 & 7) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        reinterpret_cast<uint4*>(o2)[q] = make_uint4(pack2(v[8 * q], v[8 * q + 1]), pack2(v[8 * q + 2], v[8 * q + 3]),
+                                                     pack2(v[8 * q + 4], v[8 * q + 5]), pack2(v[8 * q + 6], v[8 * q + 7]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) if (gcol + e < p.N) o2[e] = f2bf(v[e]);
+    }
+  }
   if (p.out_bf16) {
     unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)grow * p.ldo + gcol;
     if (full && (p.ldo & 7) == 0) {

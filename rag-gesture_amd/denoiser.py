@@ -192,6 +192,7 @@ class DenoiserSession:
         self.abf = None
         if w.precision == "bf16" and os.environ.get("RG_STYL_PREPASS", "1") == "1":
             self.abf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+            self.abf3 = torch.empty(B * T, 3 * D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.qmask_c = torch.ones(3, B, T, device=dev)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
@@ -265,9 +266,15 @@ class DenoiserSession:
         for l, lw in enumerate(w.layers):
             ss = w.ss[step, l]
             # --- self attention
-            G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv,
-                   segs=[G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])], seg_len=D,
-                   bias=lw["b_qkv"], softmax_cols=D)
+            qkv_seg = G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])
+            if self.abf is not None:
+                # bf16 A operands: LayerNorm once per element in a pre-pass (the GEMM's 12 column tiles would
+                # each redo it and fetch fp32 rows: measured 35.3 -> 4.1 + 22.7 us at M = 4128)
+                G.stylize(h, [qkv_seg], D, M, self.abf)
+                G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv, A=self.abf, bias=lw["b_qkv"], softmax_cols=D)
+            else:
+                G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv, segs=[qkv_seg], seg_len=D,
+                       bias=lw["b_qkv"], softmax_cols=D)
             h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
                    self.perm_sa, self.perm_sa.numel())
             sa_seg = G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"], scale_shift=ss[0])
@@ -284,9 +291,17 @@ class DenoiserSession:
                 # production path: query projection + cross attention on the conditional rows only; the
                 # classifier-free rows take their (constant) stylized cross-attention rows from the table
                 Mc = B * T
-                G.gemm(h, M=Mc, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
-                       segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
-                       bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
+                if self.abf is not None:
+                    # the three query projections normalise the same rows with their own gamma/beta:
+                    # pre-pass writes [Mc, 3*D] bf16 (one LN segment per condition), then one GEMM per condition
+                    q3_segs = [G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"][c], beta=lw["ca_b"][c]) for c in range(3)]
+                    G.stylize(h, q3_segs, D, Mc, self.abf3)
+                    G.gemm(h, M=Mc, N=3 * D, K=D, W=lw["w_q3"], out=self.q3, A=self.abf3, bias=lw["b_q3"],
+                           softmax_cols=3 * D, gb_group=D, gb_stride=D)
+                else:
+                    G.gemm(h, M=Mc, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
+                           segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
+                           bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
                 h.call("ca_attention", self.q3, self.a_pre[l], None, self.qmask_c, self.y3, self.st3c, B, B, T, D, 3,
                        self.perm_cac, self.perm_cac.numel())
                 segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3c[c], gamma=lw["ca_sg"][c],
@@ -294,7 +309,7 @@ class DenoiserSession:
                 segs.append(G.Seg(xb))
                 # the SiLU prologue of the K = 2048 GEMM once per element instead of once per column tile
                 G.stylize(h, segs, D, M, self.hcat, m_cond=Mc, unc_nseg=3, unc_tab=lw["unc_tab"][step], qmask=self.qmask)
-                G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"])
+                G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"], out2=self.abf)
             else:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
                        segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
@@ -306,7 +321,10 @@ class DenoiserSession:
                 segs.append(G.Seg(xb))
                 G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, segs=segs, seg_len=D, bias=lw["b_mix"])
             # --- FFN
-            G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, segs=[G.Seg(xc)], seg_len=D, bias=lw["b_ff1"], act=1)
+            if self.abf is not None and self.hcat is not None:   # A = bf16 copy of xc written by the ca_mix epilogue
+                G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, A=self.abf, bias=lw["b_ff1"], act=1)
+            else:
+                G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, segs=[G.Seg(xc)], seg_len=D, bias=lw["b_ff1"], act=1)
             if w.precision == "bf16":
                 G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f)
             else:
