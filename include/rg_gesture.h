@@ -201,6 +201,20 @@ int rg_ca_attention(rg_handle* h, const float* q3, const float* Apre, const floa
                     float* y3, float* stats, int R, int Rc, int T, int D, int ncond, const int* perm, int nperm,
                     void* stream);
 
+/* rg_ca_attention + the stylization front half (StylizationBlock: LN, *(1+scale)+shift, SiLU;
+ * stylization_block.py:30-47) of the three cross-attention outputs in one launch, one workgroup per
+ * (conditional row group, condition): out[b*T+n][c*D + col] (bf16, row stride ldo) for the Rc conditional
+ * row groups (y = Q A on the matrix cores, Q and A as bf16 hi + lo pairs: At_bf16 = rg_split_transpose_bf16 of
+ * the rg_kv_reduce output, [ncond][Rc][H][2][32][32]); the Ru classifier-free row groups [Rc, Rc+Ru) receive unc_tab[flag][0 .. ncond*D) (flag = 1
+ * where qmask == 0), see rg_stylize.  q3 holds the conditional rows only ([Rc*T][ncond*D]);
+ * qmask is [ncond][Rc+Ru][T] or NULL; gamma/beta [ncond][D]; scale_shift [ncond][2*D]. */
+int rg_ca_stylize(rg_handle* h, const float* q3, const void* At_bf16, const float* qmask, const float* gamma,
+                  const float* beta, const float* scale_shift, const void* unc_tab_bf16, void* out_bf16, int ldo,
+                  int Rc, int Ru, int T, int D, int ncond, void* stream);
+
+/* At[m] = (bf16(A[m]^T), bf16(A[m]^T - hi)) for n_mat fp32 32x32 matrices: the B-operand layout rg_ca_stylize reads. */
+int rg_split_transpose_bf16(rg_handle* h, const float* A, void* At_bf16, int n_mat, void* stream);
+
 /* A[b][h] = softmax_over_tokens(K[b,:,h,:])^T V[b,:,h,:]  (efficient_attention.py:82-90) for B rows
  * of N conditioning tokens; kv is [B*N, ldkv] fp32 with k in columns [0,D) and v in [D,2D).
  * A is [B][H][32][32].  Loop invariant over the 50 DDIM steps: run once per clip. */

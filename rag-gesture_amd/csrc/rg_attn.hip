@@ -413,6 +413,241 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ cross attention + stylization
+// One workgroup (8 waves) per (conditional row group b, condition c): all H heads of the group, so the
+// LayerNorm statistics of the 512-wide cross-attention output never leave the CU:
+//   y = softmax_hd(Q_c) A_c  (fp32 VALU, as rg_ca_attention), "-1e6" quantisation on masked query rows,
+//   LN over D, * (1 + scale) + shift, SiLU, bf16  ->  out[b*T + n][c*D + col]
+// i.e. rg_ca_attention + the cross-attention segments of rg_stylize in one launch: y3, its statistics and
+// one kernel boundary disappear.  Workgroups [Rc*ncond, Rc*ncond + Ru) fill the classifier-free rows from
+// the (step, layer) table like rg_stylize does.
+struct CaStylizeArgs {
+  const float* q3;        // [Rc*T][ncond*D] softmaxed queries (conditional rows only)
+  const unsigned short* At;  // [ncond][Rc][H][2 (hi, lo)][32 l][32 d] bf16: A^T split (rg_split_transpose_bf16)
+  const float* qmask;     // [ncond][Rc+Ru][T] or null
+  const float* gamma;     // [ncond][D]   proj_out.norm of each condition
+  const float* beta;      // [ncond][D]
+  const float* scale_shift;  // [ncond][2*D]: (scale | shift) of each condition at this step
+  const unsigned short* unc_tab;  // [2][ncond*D] bf16
+  unsigned short* out;    // bf16 [(Rc+Ru)*T][ldo]
+  int ldo, Rc, Ru, T, D, ncond;
+};
+
+// At[m][0][l][d] = bf16(A[m][d][l]), At[m][1][l][d] = bf16(A[m][d][l] - float(hi)) for n_mat 32x32 matrices
+__global__ void __launch_bounds__(256) split_transpose_kernel(const float* __restrict__ A, unsigned short* __restrict__ At,
+                                                             int n_mat) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_mat * HD * HD) return;
+  const int m = i / (HD * HD), l = (i / HD) % HD, d = i % HD;
+  const float x = A[(size_t)m * HD * HD + d * HD + l];
+  const __bf16 hi = (__bf16)x;
+  const __bf16 lo = (__bf16)(x - (float)hi);
+  At[(size_t)m * 2 * HD * HD + l * HD + d] = __builtin_bit_cast(unsigned short, hi);
+  At[(size_t)m * 2 * HD * HD + HD * HD + l * HD + d] = __builtin_bit_cast(unsigned short, lo);
+}
+
+constexpr int CS_WAVES = 16;   // one wave per head at D = 512
+
+__global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStylizeArgs a) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  constexpr int NTH = CS_WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int T = a.T, D = a.D, H = D / HD, ncond = a.ncond;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Tp = (T + 7) & ~7;
+  if ((int)blockIdx.x >= a.Rc * ncond) {
+    // ---- classifier-free row group: copy the tabulated rows
+    const int u = blockIdx.x - a.Rc * ncond;
+    const int R = a.Rc + a.Ru;
+    int* sflag = reinterpret_cast<int*>(sm);   // [ncond][T]: which of the two table rows a token takes
+    for (int i = threadIdx.x; i < ncond * T; i += NTH) {
+      const int cseg = i / T, n = i % T;
+      sflag[i] = (a.qmask && a.qmask[((size_t)cseg * R + a.Rc + u) * T + n] == 0.f) ? 1 : 0;
+    }
+    __syncthreads();
+    const int vec = ncond * D / 8;  // 16-B vectors per row
+    unsigned short* orow = a.out + (size_t)(a.Rc + u) * T * a.ldo;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < T * vec; i += NTH) {
+      const int n = i / vec, k8 = (i % vec) * 8;
+      const int flag = sflag[(k8 / D) * T + n];
+      *reinterpret_cast<u4*>(orow + (size_t)n * a.ldo + k8) =
+          *reinterpret_cast<const u4*>(a.unc_tab + (size_t)flag * ncond * D + k8);
+    }
+    return;
+  }
+  const int b = blockIdx.x / ncond, c = blockIdx.x % ncond;
+  float* sstat = sm;                           // [CS_WAVES][Tp][2]
+  float* srow = sstat + CS_WAVES * 2 * Tp;     // [Tp][2] (mean, rstd)
+  float* smask = srow + 2 * Tp;                // [Tp]
+  float* tiles = smask + Tp;                   // [H][Tp][32]
+  const int ld = ncond * D;
+  const int hpw = H / CS_WAVES;                // heads per wave (1 at D = 512)
+  const int l = lane & 31, half = lane >> 5;
+  // ---- q tiles of this wave's heads straight into LDS (8 rows x 128 B per 1-KiB LDS-DMA)
+  for (int hh = 0; hh < hpw; ++hh) {
+    const int h = wave * hpw + hh;
+    const float* src = a.q3 + (size_t)b * T * ld + c * D + h * HD + (lane & 7) * 4;
+    float* sq = tiles + (size_t)h * Tp * HD;
+    for (int r0 = 0; r0 < Tp; r0 += 8) {
+      int r = r0 + (lane >> 3);
+      r = r < T ? r : T - 1;
+      __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)r * ld), (lds_void*)(sq + r0 * HD), 16, 0, 0);
+    }
+  }
+  // this wave's first head: B fragments of y = q A (A^T rows, bf16 hi/lo), in flight together with the tile
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const int l15 = lane & 15, g = lane >> 4;
+  bf16x8 bh[2], bl[2];
+  auto load_b = [&](int h) {
+    const unsigned short* Ap = a.At + ((((size_t)c * a.Rc + b) * H + h) * 2) * HD * HD;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      bh[nb] = *reinterpret_cast<const bf16x8*>(Ap + (16 * nb + l15) * HD + 8 * g);
+      bl[nb] = *reinterpret_cast<const bf16x8*>(Ap + HD * HD + (16 * nb + l15) * HD + 8 * g);
+    }
+  };
+  load_b(wave * hpw);
+  // stylization parameters of this thread's column pair: requested now, used after the attention
+  const int col0 = (threadIdx.x & 255) * 2;
+  float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f;
+  if (col0 < D) {
+    const float* ss = a.scale_shift + (size_t)c * 2 * D;
+    const float2 gg = *reinterpret_cast<const float2*>(a.gamma + c * D + col0);
+    const float2 bb = *reinterpret_cast<const float2*>(a.beta + c * D + col0);
+    const float2 sc = *reinterpret_cast<const float2*>(ss + col0);
+    const float2 sh = *reinterpret_cast<const float2*>(ss + D + col0);
+    g0 = gg.x; g1 = gg.y; b0 = bb.x; b1 = bb.y; sc0 = 1.0f + sc.x; sc1 = 1.0f + sc.y; sh0 = sh.x; sh1 = sh.y;
+  }
+  const int R = a.Rc + a.Ru;
+  if (a.qmask)
+    for (int n = threadIdx.x; n < T; n += NTH) smask[n] = a.qmask[((size_t)c * R + b) * T + n];
+  float* mystat = sstat + wave * 2 * Tp;
+  for (int n = lane; n < Tp; n += 64) {
+    mystat[2 * n] = 0.f;
+    mystat[2 * n + 1] = 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float* qm = a.qmask ? smask : nullptr;
+  auto pk = [](float x, float y) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
+  };
+  for (int hh = 0; hh < hpw; ++hh) {
+    const int h = wave * hpw + hh;
+    float* sq = tiles + (size_t)h * Tp * HD;
+    if (hh > 0) load_b(h);
+    // y[16 rb + 4g + e][16 nb + l15] = sum_d q[row][d] A[d][col]: v_mfma_f32_16x16x32_bf16 with q and A as
+    // bf16 hi + lo pairs (hi*hi + hi*lo + lo*hi, fp32 accumulate: error ~2^-17 relative per product)
+    const int nrb = Tp / 16;   // Tp is a multiple of 8; the tile has whole 16-row blocks when Tp % 16 == 0
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      acc[rb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[rb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (rb * 16 < Tp) {
+        int row = 16 * rb + l15;
+        row = row < Tp ? row : Tp - 1;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sq + row * HD + 8 * g);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(sq + row * HD + 8 * g + 4);
+        const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = x[e] - (float)(__bf16)x[e];
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, u32x4{pk(x[0], x[1]), pk(x[2], x[3]), pk(x[4], x[5]), pk(x[6], x[7])});
+        const bf16x8 al = __builtin_bit_cast(bf16x8, u32x4{pk(r[0], r[1]), pk(r[2], r[3]), pk(r[4], r[5]), pk(r[6], r[7])});
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[rb][nb], 0, 0, 0);
+          acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[rb][nb], 0, 0, 0);
+          acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], acc[rb][nb], 0, 0, 0);
+        }
+      }
+    }
+    (void)nrb;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane's q reads are complete before y overwrites the tile
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * rb + 4 * g + e;
+        if (row < T) {
+          const bool masked = qm && qm[row] == 0.f;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            float v = acc[rb][nb][e];
+            if (masked) {   // fp32 rounding of the reference's y + (1 - query_mask) * -1e6
+              const float z = v + (-1000000.0f);
+              v = z + 1000000.0f;
+            }
+            sq[row * HD + 16 * nb + l15] = v;
+          }
+        }
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < T) {
+      const float* yr = sq + lane * HD;
+      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < HD; j += 2) {
+        const float v0 = yr[(j + lane) & 31], v1 = yr[(j + 1 + lane) & 31];
+        s0 += v0;
+        s1 += v1;
+        q0 = fmaf(v0, v0, q0);
+        q1 = fmaf(v1, v1, q1);
+      }
+      mystat[2 * lane] += s0 + s1;
+      mystat[2 * lane + 1] += q0 + q1;
+    }
+  }
+  __syncthreads();
+  for (int n = threadIdx.x; n < T; n += NTH) {
+    float su = 0.f, sq2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < CS_WAVES; ++w) {
+      su += sstat[w * 2 * Tp + 2 * n];
+      sq2 += sstat[w * 2 * Tp + 2 * n + 1];
+    }
+    const float inv = 1.0f / (float)D;
+    const float mu = su * inv;
+    float var = sq2 * inv - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    srow[2 * n] = mu;
+    srow[2 * n + 1] = rsqrtf(var + 1e-5f);
+  }
+  __syncthreads();
+  // ---- LN + stylization + SiLU -> bf16; thread -> (two adjacent columns, every 4th token)
+  const int rq = threadIdx.x >> 8;   // NTH / 256 = 4 row phases
+  for (int col = col0; col < D; col += 512) {
+    if (col != col0) {
+      const float* ss = a.scale_shift + (size_t)c * 2 * D;
+      g0 = a.gamma[c * D + col]; g1 = a.gamma[c * D + col + 1];
+      b0 = a.beta[c * D + col]; b1 = a.beta[c * D + col + 1];
+      sc0 = 1.0f + ss[col]; sc1 = 1.0f + ss[col + 1];
+      sh0 = ss[D + col]; sh1 = ss[D + col + 1];
+    }
+    const float* yt = tiles + (size_t)(col >> 5) * Tp * HD + (col & 31);
+    unsigned short* op = a.out + (size_t)b * T * a.ldo + c * D + col;
+#pragma unroll 4
+    for (int n = rq; n < T; n += NTH / 256) {
+      const float mu = srow[2 * n], rs = srow[2 * n + 1];
+      const float2 y = *reinterpret_cast<const float2*>(yt + n * HD);
+      float t0 = ((y.x - mu) * rs * g0 + b0) * sc0 + sh0;
+      float t1 = ((y.y - mu) * rs * g1 + b1) * sc1 + sh1;
+      t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t0 * -1.44269504088896340736f));
+      t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t1 * -1.44269504088896340736f));
+      const __bf16 lo = (__bf16)t0, hi = (__bf16)t1;
+      *reinterpret_cast<unsigned*>(op + (size_t)n * a.ldo) =
+          (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16,
@@ -493,6 +728,38 @@ extern "C" int rg_linear_f32(rg_handle* h, const float* a, const float* w, const
   RG_REQUIRE(h, M > 0 && N > 0 && K > 0, "bad shape");
   hipLaunchKernelGGL(linear_f32_kernel, dim3((N * 64 + 255) / 256), dim3(256), 0, rg_stream(stream), a, w, bias,
                      out, M, N, K, silu_in, silu_out);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_ca_stylize(rg_handle* h, const float* q3, const void* At_bf16, const float* qmask, const float* gamma,
+                             const float* beta, const float* scale_shift, const void* unc_tab_bf16, void* out_bf16,
+                             int ldo, int Rc, int Ru, int T, int D, int ncond, void* stream) {
+  RG_REQUIRE(h, q3 && At_bf16 && gamma && beta && scale_shift && out_bf16, "null pointer");
+  RG_REQUIRE(h, Rc > 0 && Ru >= 0 && (Ru == 0 || unc_tab_bf16), "classifier-free rows need the table");
+  RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * CS_WAVES) == 0 && ncond > 0 && ldo % 8 == 0, "bad shape");
+  const int Tp = (T + 7) & ~7;
+  const size_t lds = ((size_t)CS_WAVES * 2 * Tp + 2 * Tp + Tp + (size_t)(D / HD) * Tp * HD) * sizeof(float);
+  RG_REQUIRE(h, lds <= 160 * 1024, "row group does not fit LDS (D <= 768)");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)ca_stylize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  CaStylizeArgs a;
+  a.q3 = q3; a.At = reinterpret_cast<const unsigned short*>(At_bf16); a.qmask = qmask; a.gamma = gamma; a.beta = beta; a.scale_shift = scale_shift;
+  a.unc_tab = reinterpret_cast<const unsigned short*>(unc_tab_bf16);
+  a.out = reinterpret_cast<unsigned short*>(out_bf16);
+  a.ldo = ldo; a.Rc = Rc; a.Ru = Ru; a.T = T; a.D = D; a.ncond = ncond;
+  hipLaunchKernelGGL(ca_stylize_kernel, dim3(Rc * ncond + Ru), dim3(CS_WAVES * 64), lds, rg_stream(stream), a);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_split_transpose_bf16(rg_handle* h, const float* A, void* At_bf16, int n_mat, void* stream) {
+  RG_REQUIRE(h, A && At_bf16 && n_mat > 0, "bad arguments");
+  hipLaunchKernelGGL(split_transpose_kernel, dim3((n_mat * HD * HD + 255) / 256), dim3(256), 0, rg_stream(stream), A,
+                     reinterpret_cast<unsigned short*>(At_bf16), n_mat);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -91,6 +91,7 @@ class DenoiserWeights:
             lw["b_kv"] = [f32(torch.cat([g(q + "key.bias"), g(q + "value.bias")], 0)) for q in cq]
             lw["ca_sg"] = [f32(g(q + "proj_out.norm.weight")) for q in cq]
             lw["ca_sb"] = [f32(g(q + "proj_out.norm.bias")) for q in cq]
+            lw["ca_sgs"], lw["ca_sbs"] = torch.stack(lw["ca_sg"]).contiguous(), torch.stack(lw["ca_sb"]).contiguous()
             # classifier-free rows: A[c][h][d][l] = b_v[h*32 + l]
             bv = torch.stack([g(q + "value.bias") for q in cq])  # [3, D]
             lw["a_unc"] = f32(bv.view(3, self.H, 1, 32).expand(3, self.H, 32, 32))
@@ -196,6 +197,7 @@ class DenoiserSession:
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.qmask_c = torch.ones(3, B, T, device=dev)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
+        self.a_pre_t = torch.empty(w.L, 3, B, w.H, 2, 32, 32, device=dev, dtype=torch.bfloat16)  # A^T as bf16 hi/lo
         self.src_mask = torch.ones(self.R, T, device=dev)
         self.qmask = torch.ones(3, self.R, T, device=dev)
         ng = D // 128
@@ -251,6 +253,8 @@ class DenoiserSession:
                        segs=[G.Seg(xf, mode=G.A_LN, stats=st, gamma=lw["tn_g"][ci], beta=lw["tn_b"][ci])],
                        seg_len=D, bias=lw["b_kv"][ci], ldo=2 * D)
                 h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci], B, n_tok, D)
+        if self.abf is not None:
+            h.call("split_transpose_bf16", self.a_pre, self.a_pre_t, w.L * 3 * B * w.H)
         self._keep = srcs
 
     # ------------------------------------------------------------------ per step
@@ -282,7 +286,9 @@ class DenoiserSession:
                 # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
                 # pre-pass instead of once per column tile and wave pair inside the GEMM's A prologue
                 G.stylize(h, [sa_seg], D, M, self.abf)
-                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_)
+                # out2: bf16 copy of xb = 4th K-segment of the ca_mix GEMM's A operand
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
+                       out2=self.hcat[:, 3 * D:])
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, segs=[sa_seg], seg_len=D, bias=lw["b_sao"], residual=xa,
                        stats_out=sb_)
@@ -302,13 +308,19 @@ class DenoiserSession:
                     G.gemm(h, M=Mc, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
                            segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
                            bias=lw["b_q3"], softmax_cols=3 * D, gb_group=D, gb_stride=D)
-                h.call("ca_attention", self.q3, self.a_pre[l], None, self.qmask_c, self.y3, self.st3c, B, B, T, D, 3,
-                       self.perm_cac, self.perm_cac.numel())
-                segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3c[c], gamma=lw["ca_sg"][c],
-                              beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
-                segs.append(G.Seg(xb))
-                # the SiLU prologue of the K = 2048 GEMM once per element instead of once per column tile
-                G.stylize(h, segs, D, M, self.hcat, m_cond=Mc, unc_nseg=3, unc_tab=lw["unc_tab"][step], qmask=self.qmask)
+                if self.abf is not None:
+                    # cross attention + LN/stylization/SiLU of its three outputs in one launch, straight into
+                    # the bf16 A operand of the ca_mix GEMM (classifier-free rows: the (step, layer) table)
+                    h.call("ca_stylize", self.q3, self.a_pre_t[l], self.qmask, lw["ca_sgs"], lw["ca_sbs"], ss[1:4],
+                           lw["unc_tab"][step], self.hcat, 4 * D, B, B, T, D, 3)
+                else:
+                    h.call("ca_attention", self.q3, self.a_pre[l], None, self.qmask_c, self.y3, self.st3c, B, B, T, D, 3,
+                           self.perm_cac, self.perm_cac.numel())
+                    segs = [G.Seg(self.y3, ld=3 * D, mode=G.A_STYL, stats=self.st3c[c], gamma=lw["ca_sg"][c],
+                                  beta=lw["ca_sb"][c], scale_shift=ss[1 + c], col_offset=c * D) for c in range(3)]
+                    segs.append(G.Seg(xb))
+                    # the SiLU prologue of the K = 2048 GEMM once per element instead of once per column tile
+                    G.stylize(h, segs, D, M, self.hcat, m_cond=Mc, unc_nseg=3, unc_tab=lw["unc_tab"][step], qmask=self.qmask)
                 G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"], out2=self.abf)
             else:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
