@@ -143,6 +143,10 @@ typedef struct rg_gemm_desc {
                           // "bf16x3" mode (hi*hi + hi*lo + lo*hi), fp32 A segments only
   void* out2;             // null, or bf16 [M, ldo2]: a second, bf16-rounded copy of the output (the next
                           // GEMM's A operand, written by the producer instead of converted by every consumer tile)
+  const float* ln_stats;  // null, or [M][ln_nparts][2] partial (sum, sumsq) of the fp32 rows whose bf16 copy is A:
+  const float* ln_c1;     //   LayerNorm folded into the epilogue.  With W' = W diag(gamma) packed as the weight,
+  int ln_nparts;          //   c1[n] = sum_k W'[n][k] and bias[n] = b[n] + sum_k W[n][k] beta[k]:
+  int pad3_;              //   out = rstd * (A W'^T - mean * c1) + bias  ==  LN(x) W^T + b   (mean/rstd over K columns)
 } rg_gemm_desc;
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);

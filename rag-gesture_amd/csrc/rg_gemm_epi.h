@@ -87,6 +87,24 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
     v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
   }
   const bool full = (gcol + 32 <= p.N);
+  if (p.ln_stats) {   // LayerNorm of the A rows, folded: rstd * (acc - mean * c1[n]); the bias below carries beta
+    const float* sp = p.ln_stats + (size_t)(row_ok ? grow : 0) * p.ln_nparts * 2;
+    float su = 0.f, sq = 0.f;
+    for (int q = 0; q < p.ln_nparts; ++q) {
+      su += sp[2 * q];
+      sq += sp[2 * q + 1];
+    }
+    const float inv = 1.0f / (float)p.K;
+    const float mu = su * inv;
+    float var = sq * inv - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    const float rs = rsqrtf(var + 1e-5f);
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+      const float c1 = (gcol + e < p.N) ? p.ln_c1[gcol + e] : 0.f;
+      v[e] = rs * (v[e] - mu * c1);
+    }
+  }
   if (p.bias) {
     if (full) {
 #pragma unroll

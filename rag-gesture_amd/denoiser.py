@@ -35,6 +35,17 @@ def _timestep_embedding(timesteps, dim, max_period=10000):
 
 
 class DenoiserWeights:
+    @staticmethod
+    def _fold_ln(W, b, gamma, beta, pw, f32):
+        """LN(x) W^T + b = rstd (x W'^T - mean c1) + c2 with W' = W diag(gamma), c1 = rowsum(bf16(W')) (what the
+        matrix cores actually multiply), c2 = b + W beta.  Returns (W' [packed if pw], c1, c2)."""
+        Wp = (W.double() * gamma.double()[None, :]).float()
+        c1 = Wp.to(torch.bfloat16).double().sum(1).float()
+        c2 = (b.double() + W.double() @ beta.double()).float()
+        if pw is None:
+            return Wp, c1, c2
+        return pw(Wp), f32(c1), f32(c2)
+
     """Device-resident packed weights of one ReGestureTransformer (bf16 GEMM operands [N,K]
     zero-padded to 64, fp32 biases / LayerNorm parameters / tables)."""
 
@@ -78,6 +89,11 @@ class DenoiserWeights:
             lw["sa_g"], lw["sa_b"] = f32(g(p + "sa_block.norm.weight")), f32(g(p + "sa_block.norm.bias"))
             lw["w_qkv"] = pw(torch.cat([g(p + "sa_block.%s.weight" % n) for n in ("query", "key", "value")], 0))
             lw["b_qkv"] = f32(torch.cat([g(p + "sa_block.%s.bias" % n) for n in ("query", "key", "value")], 0))
+            if precision == "bf16":  # LayerNorm folded into the GEMM epilogue (include/rg_gesture.h: ln_stats)
+                lw["w_qkv_ln"], lw["c1_qkv"], lw["c2_qkv"] = self._fold_ln(
+                    torch.cat([g(p + "sa_block.%s.weight" % n) for n in ("query", "key", "value")], 0),
+                    torch.cat([g(p + "sa_block.%s.bias" % n) for n in ("query", "key", "value")], 0),
+                    g(p + "sa_block.norm.weight"), g(p + "sa_block.norm.bias"), pw, f32)
             lw["sa_sg"], lw["sa_sb"] = f32(g(p + "sa_block.proj_out.norm.weight")), f32(g(p + "sa_block.proj_out.norm.bias"))
             lw["w_sao"], lw["b_sao"] = pw(g(p + "sa_block.proj_out.out_layers.2.weight")), f32(g(p + "sa_block.proj_out.out_layers.2.bias"))
             cq = [p + "ca_blocks.%s." % c for c in CONDS]
@@ -85,6 +101,12 @@ class DenoiserWeights:
             lw["ca_b"] = f32(torch.stack([g(q + "norm.bias") for q in cq]))
             lw["w_q3"] = pw(torch.cat([g(q + "query.weight") for q in cq], 0))
             lw["b_q3"] = f32(torch.cat([g(q + "query.bias") for q in cq], 0))
+            if precision == "bf16":
+                parts = [self._fold_ln(g(q + "query.weight"), g(q + "query.bias"), g(q + "norm.weight"), g(q + "norm.bias"),
+                                       None, None) for q in cq]
+                lw["w_q3_ln"] = pw(torch.cat([pt[0] for pt in parts], 0))
+                lw["c1_q3"] = f32(torch.cat([pt[1] for pt in parts], 0))
+                lw["c2_q3"] = f32(torch.cat([pt[2] for pt in parts], 0))
             lw["tn_g"] = [f32(g(q + "text_norm.weight")) for q in cq]
             lw["tn_b"] = [f32(g(q + "text_norm.bias")) for q in cq]
             lw["w_kv"] = [pw(torch.cat([g(q + "key.weight"), g(q + "value.weight")], 0)) for q in cq]
@@ -190,10 +212,12 @@ class DenoiserSession:
         self.yf, self.st_f = f(M, D), f(M, D // G.STATS_COLS, 2)
         self.head = f(M, D)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
-        self.abf = None
+        self.abf = self.xa_bf = None
         if w.precision == "bf16" and os.environ.get("RG_STYL_PREPASS", "1") == "1":
             self.abf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
             self.abf3 = torch.empty(B * T, 3 * D, device=dev, dtype=torch.bfloat16)
+            if os.environ.get("RG_LN_EPILOGUE", "1") == "1":
+                self.xa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.qmask_c = torch.ones(3, B, T, device=dev)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
@@ -266,12 +290,17 @@ class DenoiserSession:
         sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c
         # h = joint_embed(x) + positional tables, duplicated for the two CFG branches
         G.gemm(h, M=M, N=D, K=D, W=w.w_embed, out=xa, segs=[G.Seg(x.view(B * T, D))], seg_len=D, a_row_mod=B * T,
-               bias=w.b_embed, tbias=w.tbias, tb_period=T, stats_out=sa_)
+               bias=w.b_embed, tbias=w.tbias, tb_period=T, stats_out=sa_, out2=self.xa_bf)
         for l, lw in enumerate(w.layers):
             ss = w.ss[step, l]
             # --- self attention
             qkv_seg = G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])
-            if self.abf is not None:
+            if self.xa_bf is not None:
+                # A = bf16 copy of xa written by the producing GEMM; the LayerNorm is folded into this GEMM's
+                # epilogue (rstd * (acc - mean * c1) + c2): no normalisation pass, no extra launch
+                G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv_ln"], out=self.qkv, A=self.xa_bf, bias=lw["c2_qkv"],
+                       ln_stats=sa_, ln_c1=lw["c1_qkv"], softmax_cols=D)
+            elif self.abf is not None:
                 # bf16 A operands: LayerNorm once per element in a pre-pass (the GEMM's 12 column tiles would
                 # each redo it and fetch fp32 rows: measured 35.3 -> 4.1 + 22.7 us at M = 4128)
                 G.stylize(h, [qkv_seg], D, M, self.abf)
@@ -297,7 +326,12 @@ class DenoiserSession:
                 # production path: query projection + cross attention on the conditional rows only; the
                 # classifier-free rows take their (constant) stylized cross-attention rows from the table
                 Mc = B * T
-                if self.abf is not None:
+                if self.xa_bf is not None:
+                    # A = the bf16 copy of xb the SA-out epilogue left in hcat[:, 3D:]; per-condition LayerNorms
+                    # folded into the epilogue (gamma in the weights, beta in the bias)
+                    G.gemm(h, M=Mc, N=3 * D, K=D, W=lw["w_q3_ln"], out=self.q3, A=self.hcat[:, 3 * D:], bias=lw["c2_q3"],
+                           ln_stats=sb_, ln_c1=lw["c1_q3"], softmax_cols=3 * D)
+                elif self.abf is not None:
                     # the three query projections normalise the same rows with their own gamma/beta:
                     # pre-pass writes [Mc, 3*D] bf16 (one LN segment per condition), then one GEMM per condition
                     q3_segs = [G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"][c], beta=lw["ca_b"][c]) for c in range(3)]
@@ -345,7 +379,8 @@ class DenoiserSession:
             ff_seg = G.Seg(self.yf, mode=G.A_STYL, stats=self.st_f, gamma=lw["ff_sg"], beta=lw["ff_sb"], scale_shift=ss[4])
             if self.abf is not None:
                 G.stylize(h, [ff_seg], D, M, self.abf)
-                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_)
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_,
+                       out2=self.xa_bf)
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, segs=[ff_seg], seg_len=D, bias=lw["b_ffo"], residual=xc,
                        stats_out=sa_)
