@@ -164,7 +164,8 @@ int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_le
                int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask, void* stream);
 
 /* Kernel selection hook for tests / tuning: 0 = auto, 1 = generic register-staged kernel only (any
- * shape), 2 = prefer the LDS-DMA ring kernel, 3 = prefer the depth-4 register-staged kernel. */
+ * shape), 2 = prefer the LDS-DMA ring kernel, 3 = prefer the depth-4 register-staged kernel, 4 = prefer the
+ * 128-row big-tile kernel (bf16 A), 5 = never use it. */
 int rg_set_gemm_path(rg_handle* h, int path);
 /* Tuning knob: waves per workgroup of the LDS-DMA GEMM kernel (0 = auto by shape, 4 or 8; process-wide, default 0). */
 int rg_set_gemm_waves(int waves);

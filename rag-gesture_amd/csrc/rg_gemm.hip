@@ -403,6 +403,9 @@ bool reg_fast_eligible(const rg_gemm_desc* d) {
 
 bool rg_gemm_dma_eligible(const rg_gemm_desc* d);          // rg_gemm_dma.hip
 void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream);
+bool rg_gemm_big_eligible(const rg_gemm_desc* d);          // rg_gemm_big.hip
+int rg_gemm_big_width(const rg_gemm_desc* d, int num_cus); // 0 = do not use, else 128 / 256
+void rg_gemm_big_launch(const rg_gemm_desc* d, int bn, void* stream);
 
 extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   RG_REQUIRE(h, d != nullptr, "null descriptor");
@@ -443,9 +446,14 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   if (d->W_lo) RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
   // gemm_path: 0 = auto (LDS-DMA kernel where eligible, else generic),
   //            1 = generic only, 2 = prefer LDS-DMA, 3 = prefer register-staged FAST
+  //            4 = prefer the 128-row big-tile kernel (bf16 A), 5 = never use it
   const int path = h->gemm_path;
   const bool fast_ok = reg_fast_eligible(d), dma_ok = rg_gemm_dma_eligible(d);
-  if (fast_ok && path == 3) {
+  const bool big_ok = rg_gemm_big_eligible(d);
+  const int big_bn = big_ok ? (path == 4 ? (d->N >= 256 ? 256 : 128) : (path == 0 ? rg_gemm_big_width(d, h->num_cus) : 0)) : 0;
+  if (big_bn) {
+    rg_gemm_big_launch(d, big_bn, stream);
+  } else if (fast_ok && path == 3) {
     if (d->a_is_bf16) launch<true, false, true>(d, grid, rg_stream(stream));
     else launch<false, false, true>(d, grid, rg_stream(stream));
   } else if (path != 1 && dma_ok) {
@@ -495,7 +503,7 @@ extern "C" int rg_profile_end(rg_handle* h, int variant, int64_t* launches, doub
 
 // Test / tuning hook, see the dispatch in rg_gemm.
 extern "C" int rg_set_gemm_path(rg_handle* h, int path) {
-  if (!h || path < 0 || path > 3) return RG_ERR_INVALID;
+  if (!h || path < 0 || path > 5) return RG_ERR_INVALID;
   h->gemm_path = path;
   return RG_OK;
 }
