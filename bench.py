@@ -164,9 +164,11 @@ def main():
         one_step()
         model.use_graphs = True
         n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-        h.lib.rg_profile_end(h._h, 0, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+        # variant 1 = bf16-A GEMMs (gemm_dma_kernel<true,...> / gemm_bf16_big_kernel): every per-step denoiser
+        # GEMM and ~2/3 of the GPU time of a step
+        h.lib.rg_profile_end(h._h, 1, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
         ach = fl.value / (ms.value * 1e-3) if ms.value > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm_kernel<false,false> (fp32-source A, bf16 MFMA)",
+        roofline = {"bound": "mfma", "kernel": "rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)",
                     "achieved": round(ach / 1e12, 3), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK, 5), "traffic": None, "launches": n.value,
                     "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
