@@ -189,9 +189,11 @@ int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* 
  * `key + (1-mask)*-1e6` and `value*mask`).  Writes y [R*T, ldy] fp32 and per-row partial
  * LayerNorm statistics stats[R*T][D/128][2] (sum, sumsq over each 128-column head group).
  * perm (device, nperm ints, or NULL): launch order -> work item (row * D/128 + head group, -1 = idle
- * block); lets the caller place a row group on the XCD whose L2 already holds its rows. */
+ * block); lets the caller place a row group on the XCD whose L2 already holds its rows.
+ * use_mfma = 1: P^T V and Q A on the matrix cores (bf16 hi + lo operand pairs, fp32 accumulate: the bf16
+ * production path); 0: exact fp32 VALU products (precision = "fp32"). */
 int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
-                    float* stats, int R, int T, int D, const int* perm, int nperm, void* stream);
+                    float* stats, int R, int T, int D, const int* perm, int nperm, int use_mfma, void* stream);
 
 /* Cross-attention core of EfficientCrossAttention for ncond parallel conditions
  * (efficient_attention.py:90-98; diffusion_transformer.py:105-118): y3[:, c*D:(c+1)*D] = Q_c A_c

@@ -76,6 +76,9 @@ __device__ __forceinline__ void qa_and_store(float* sq, const float (&Areg)[HD],
   }
 }
 
+// MFMA_ = false: exact fp32 VALU products (precision = "fp32" path);  true: both products on the matrix
+// cores with bf16 hi + lo operand pairs and fp32 accumulation (~2^-17 relative per product).
+template <bool MFMA_>
 __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
                                                           const float* __restrict__ src_mask, float* __restrict__ y,
                                                           int ldy, float* __restrict__ stats, int T,
@@ -146,6 +149,124 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
   __builtin_amdgcn_wave_barrier();
+  if constexpr (MFMA_) {
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    auto pk = [](float x, float y) {
+      return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
+    };
+    auto split = [&](const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = x[e] - (float)(__bf16)x[e];
+      hi = __builtin_bit_cast(bf16x8, u32x4{pk(x[0], x[1]), pk(x[2], x[3]), pk(x[4], x[5]), pk(x[6], x[7])});
+      lo = __builtin_bit_cast(bf16x8, u32x4{pk(r[0], r[1]), pk(r[2], r[3]), pk(r[4], r[5]), pk(r[6], r[7])});
+    };
+    const int l15 = lane & 15, g = lane >> 4;
+    // ---- A[d][l] = sum_n P[n][d] V[n][l]: rows d (2 blocks), columns l (2 blocks), K = tokens (2 x 32, zero
+    // beyond T; masked tokens have P = 0 exactly).  lane -> row/col 16*blk + l15, tokens 32*ks + 8*g + j
+    f32x4 accA[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) accA[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ph[2], pl[2], vh[2], vl[2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        float pv[8], vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int n = 32 * ks + 8 * g + j;
+          const bool ok = n < T;
+          pv[j] = ok ? sk[n * HD + 16 * blk + l15] : 0.f;
+          vv[j] = ok ? sv[n * HD + 16 * blk + l15] : 0.f;
+        }
+        split(pv, ph[blk], pl[blk]);
+        split(vv, vh[blk], vl[blk]);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          accA[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rb], vh[nb], accA[rb][nb], 0, 0, 0);
+          accA[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rb], vl[nb], accA[rb][nb], 0, 0, 0);
+          accA[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rb], vh[nb], accA[rb][nb], 0, 0, 0);
+        }
+    }
+    // ---- y = q A.  accA[rb][nb][e] = A[16 rb + 4 g + e][16 nb + l15] is already a B fragment if the
+    // contraction index is enumerated as slot (g, j) <-> d = 16*(j/4) + 4*g + j%4; q is read with the same
+    // permutation (two 16-B LDS reads per fragment), so A never leaves the registers.
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float av[8] = {accA[0][nb][0], accA[0][nb][1], accA[0][nb][2], accA[0][nb][3],
+                           accA[1][nb][0], accA[1][nb][1], accA[1][nb][2], accA[1][nb][3]};
+      split(av, ah[nb], al[nb]);
+    }
+    f32x4 accY[4][2];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      accY[tb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accY[tb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (16 * tb < Tp) {
+        int row = 16 * tb + l15;
+        row = row < Tp ? row : Tp - 1;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(sq + row * HD + 4 * g);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(sq + row * HD + 16 + 4 * g);
+        const float qv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+        bf16x8 qh, ql;
+        split(qv, qh, ql);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          accY[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql, ah[nb], accY[tb][nb], 0, 0, 0);
+          accY[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, al[nb], accY[tb][nb], 0, 0, 0);
+          accY[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, ah[nb], accY[tb][nb], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane's q reads are complete before y overwrites the tile
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = 16 * tb + 4 * g + e;
+        if (row < T) {
+          sq[row * HD + l15] = accY[tb][0][e];
+          sq[row * HD + 16 + l15] = accY[tb][1][e];
+        }
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // coalesced y store (8 rows x 128 B per wave-instruction) and per-token statistics from the tile
+    {
+      float* yout = y + (size_t)b * T * ldy + h * HD;
+      for (int r0 = 0; r0 < T; r0 += 8) {
+        const int r = r0 + (lane >> 3);
+        if (r < T)
+          *reinterpret_cast<f32x4*>(yout + (size_t)r * ldy + (lane & 7) * 4) =
+              *reinterpret_cast<const f32x4*>(sq + r * HD + (lane & 7) * 4);
+      }
+      float* mystat = sstat + wave * 2 * Tp;
+      if (lane < T) {
+        const float* yr = sq + lane * HD;
+        float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < HD; j += 2) {
+          const float v0 = yr[(j + lane) & 31], v1 = yr[(j + 1 + lane) & 31];
+          s0 += v0;
+          s1 += v1;
+          q0 = fmaf(v0, v0, q0);
+          q1 = fmaf(v1, v1, q1);
+        }
+        mystat[2 * lane] = s0 + s1;
+        mystat[2 * lane + 1] = q0 + q1;
+      }
+    }
+  } else {
   // A[d][l] = sum_n P[n][d] * (V[n][l] * mask[n]); lane -> (d = lane&31, 16 l's)
   {
     const int d = lane & 31, l0 = (lane >> 5) * 16;
@@ -177,6 +298,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
 #pragma unroll
   for (int d = 0; d < HD; ++d) Areg[d] = sA[d * AS + (lane & 31)];
   qa_and_store(sq, Areg, y + (size_t)b * T * ldy + h * HD, ldy, T, lane, nullptr, sstat + wave * 2 * Tp);
+  }
   __syncthreads();
   const int ngroups = D / (HD * WAVES);
   for (int n = threadIdx.x; n < T; n += 256) {
@@ -686,14 +808,21 @@ extern "C" int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows
 }
 
 extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
-                               float* stats, int R, int T, int D, const int* perm, int nperm, void* stream) {
+                               float* stats, int R, int T, int D, const int* perm, int nperm, int use_mfma,
+                               void* stream) {
   RG_REQUIRE(h, qkv && src_mask && y && stats, "null pointer");
   RG_REQUIRE(h, T >= 33 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape (33 <= T <= 64)");
   const int Tp = (T + 7) & ~7;
   const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * (3 * Tp * HD)) * sizeof(float);
   RG_REQUIRE(h, !perm || nperm >= R * (D / (HD * WAVES)), "perm shorter than the work list");
-  hipLaunchKernelGGL(sa_attention_kernel, dim3(perm ? nperm : R * (D / (HD * WAVES))), dim3(256), lds, rg_stream(stream),
-                     qkv, ldqkv, D, src_mask, y, ldy, stats, T, perm);
+  RG_REQUIRE(h, !use_mfma || (ldy % 4 == 0), "ldy must be a multiple of 4 floats");
+  const dim3 grid(perm ? nperm : R * (D / (HD * WAVES)));
+  if (use_mfma)
+    hipLaunchKernelGGL(sa_attention_kernel<true>, grid, dim3(256), lds, rg_stream(stream), qkv, ldqkv, D, src_mask, y, ldy,
+                       stats, T, perm);
+  else
+    hipLaunchKernelGGL(sa_attention_kernel<false>, grid, dim3(256), lds, rg_stream(stream), qkv, ldqkv, D, src_mask, y,
+                       ldy, stats, T, perm);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -309,7 +309,7 @@ class DenoiserSession:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv, segs=[qkv_seg], seg_len=D,
                        bias=lw["b_qkv"], softmax_cols=D)
             h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
-                   self.perm_sa, self.perm_sa.numel())
+                   self.perm_sa, self.perm_sa.numel(), 1 if w.precision == "bf16" else 0)
             sa_seg = G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"], scale_shift=ss[0])
             if self.abf is not None:
                 # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
