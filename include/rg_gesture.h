@@ -282,6 +282,26 @@ int rg_aa_to_6d(rg_handle* h, const float* aa, int ld_in, float* out, int ld_out
 int rg_6d_to_aa(rg_handle* h, const float* d6, int ld_in, int col_off, float* out, int ld_out, int rows, int joints,
                 void* stream);
 
+/* ---------------------------------------------------------------- caller-side packing
+ * tools/visualize.py:208-213: pred_motion[..., part_mask] = pred_part for upper / lower / hands / face in one
+ * pass.  The masks are whole joints: src_part[j] in {0 upper, 1 lower, 2 hands, 3 face, -1 none (zeros)},
+ * src_joint[j] = joint index inside that part.  out is [rows, joints*3]. */
+int rg_scatter_joints(rg_handle* h, const float* upper, int ld_u, const float* lower, int ld_l, const float* hands,
+                      int ld_h, const float* face, int ld_f, const int* src_part, const int* src_joint, float* out,
+                      int rows, int joints, void* stream);
+/* tools/visualize.py:266-291 / longform_synthesis.py:714-741: axis-angle -> 6D, F.interpolate(mode='linear',
+ * scale_factor=scale, align_corners=False) along time, 6D -> axis-angle, fused.  aa [B,n,joints*3] ->
+ * out [B,n*scale,joints*3].  rg_interp_linear: the same interpolation for plain features (expressions, trans). */
+int rg_interp_aa(rg_handle* h, const float* aa, float* out, int B, int n, int joints, int scale, void* stream);
+int rg_interp_linear(rg_handle* h, const float* x, float* out, int B, int n, int dim, int scale, void* stream);
+/* tools/longform_synthesis.py:431-476: blend of a new window with the last `overlap` frames of the motion so
+ * far.  Every frame of the window goes axis-angle -> 6D -> axis-angle; on frames t < overlap the 6D value is
+ * prev6D*(1-w_t) + new6D*w_t, w = torch.linspace(0, 1, overlap).  prev_tail [B,overlap,joints*3], cur/out
+ * [B,n,joints*3].  rg_blend_linear blends plain features in place on cur[:, :overlap]. */
+int rg_blend_aa(rg_handle* h, const float* prev_tail, const float* cur, float* out, int B, int n, int joints, int overlap,
+                void* stream);
+int rg_blend_linear(rg_handle* h, const float* prev_tail, float* cur, int B, int n, int dim, int overlap, void* stream);
+
 /* ---------------------------------------------------------------- retrieval sweep
  * Score of every DB entry for ONE query relation (sense, connective), float64, the reference's
  * operation order (rag/discourse_retrieval.py:86-222): +2 sense present, +4 exact connective among the

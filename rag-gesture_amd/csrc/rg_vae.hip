@@ -401,6 +401,133 @@ __global__ void __launch_bounds__(256) sixd_to_aa_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------ caller-side packing
+// (tools/visualize.py:204-291, tools/longform_synthesis.py:413-476, 714-741)
+//
+// scatter_joints: pred_motion[..., part_mask] = pred_part for the four body parts in one pass.  The boolean
+//   masks are whole joints, so the map is per joint: src_part[j] (0..3, -1 = joint in no part -> 0) and
+//   src_joint[j] (index inside the part).
+struct PartPtrs {
+  const float* p[4];
+  int ld[4];
+};
+__global__ void __launch_bounds__(256) scatter_joints_kernel(PartPtrs parts, const int* __restrict__ src_part,
+                                                            const int* __restrict__ src_joint, float* __restrict__ out,
+                                                            int rows, int joints) {
+  const int64_t total = (int64_t)rows * joints;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / joints), j = (int)(i % joints);
+    const int pt = src_part[j];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (pt >= 0) {
+      const float* sp = (pt == 0 ? parts.p[0] : pt == 1 ? parts.p[1] : pt == 2 ? parts.p[2] : parts.p[3]) +
+                        (size_t)r * (pt == 0 ? parts.ld[0] : pt == 1 ? parts.ld[1] : pt == 2 ? parts.ld[2] : parts.ld[3]) +
+                        src_joint[j] * 3;
+      a0 = sp[0]; a1 = sp[1]; a2 = sp[2];
+    }
+    float* q = out + (size_t)r * joints * 3 + j * 3;
+    q[0] = a0; q[1] = a1; q[2] = a2;
+  }
+}
+
+// F.interpolate(x.permute(0,2,1), scale_factor=s, mode='linear') source coordinates (align_corners=False):
+// src = (dst + 0.5) / s - 0.5 clamped at 0, i1 = min(i0 + 1, n - 1), w1 = src - i0, out = w0*x[i0] + w1*x[i1]
+__device__ __forceinline__ void lerp_coord(int t, int n, float inv_scale, int& i0, int& i1, float& w0, float& w1) {
+  float src = ((float)t + 0.5f) * inv_scale - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = (int)src;
+  if (i0 > n - 1) i0 = n - 1;
+  i1 = i0 + (i0 < n - 1 ? 1 : 0);
+  w1 = src - (float)i0;
+  w0 = 1.0f - w1;
+}
+
+// aa -> 6D, temporal linear interpolation in 6D, 6D -> aa, fused per (clip, output frame, joint)
+__global__ void __launch_bounds__(256) interp_aa_kernel(const float* __restrict__ aa, float* __restrict__ out, int B, int n,
+                                                       int joints, int scale) {
+  const int n_out = n * scale;
+  const int64_t total = (int64_t)B * n_out * joints;
+  const float inv_scale = 1.0f / (float)scale;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % joints);
+    const int t = (int)((i / joints) % n_out);
+    const int b = (int)(i / ((int64_t)joints * n_out));
+    int i0, i1;
+    float w0, w1;
+    lerp_coord(t, n, inv_scale, i0, i1, w0, w1);
+    const float* p0 = aa + ((size_t)b * n + i0) * joints * 3 + j * 3;
+    const float* p1 = aa + ((size_t)b * n + i1) * joints * 3 + j * 3;
+    float a0[3] = {p0[0], p0[1], p0[2]}, a1[3] = {p1[0], p1[1], p1[2]}, d0[6], d1[6], d[6], o[3];
+    aa_to_6d_one(a0, d0);
+    aa_to_6d_one(a1, d1);
+#pragma unroll
+    for (int e = 0; e < 6; ++e) d[e] = w0 * d0[e] + w1 * d1[e];
+    sixd_to_aa_one(d, o);
+    float* q = out + ((size_t)b * n_out + t) * joints * 3 + j * 3;
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+  }
+}
+
+__global__ void __launch_bounds__(256) interp_linear_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int n,
+                                                           int dim, int scale) {
+  const int n_out = n * scale;
+  const int64_t total = (int64_t)B * n_out * dim;
+  const float inv_scale = 1.0f / (float)scale;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % dim);
+    const int t = (int)((i / dim) % n_out);
+    const int b = (int)(i / ((int64_t)dim * n_out));
+    int i0, i1;
+    float w0, w1;
+    lerp_coord(t, n, inv_scale, i0, i1, w0, w1);
+    out[i] = w0 * x[((size_t)b * n + i0) * dim + c] + w1 * x[((size_t)b * n + i1) * dim + c];
+  }
+}
+
+// long-form overlap blend (longform_synthesis.py:431-476): the whole new window goes aa -> 6D -> aa; on its
+// first `overlap` frames the 6D values are prev6D * (1 - w) + new6D * w with w = linspace(0, 1, overlap)[t]
+__global__ void __launch_bounds__(256) blend_aa_kernel(const float* __restrict__ prev_tail, const float* __restrict__ cur,
+                                                      float* __restrict__ out, int B, int n, int joints, int overlap) {
+  const int64_t total = (int64_t)B * n * joints;
+  const float step = overlap > 1 ? 1.0f / (float)(overlap - 1) : 0.f;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % joints);
+    const int t = (int)((i / joints) % n);
+    const int b = (int)(i / ((int64_t)joints * n));
+    const float* pc = cur + ((size_t)b * n + t) * joints * 3 + j * 3;
+    float a[3] = {pc[0], pc[1], pc[2]}, d[6], o[3];
+    aa_to_6d_one(a, d);
+    if (t < overlap) {
+      const float* pp = prev_tail + ((size_t)b * overlap + t) * joints * 3 + j * 3;
+      float ap[3] = {pp[0], pp[1], pp[2]}, dp[6];
+      aa_to_6d_one(ap, dp);
+      // torch.linspace(0, 1, overlap): start + step*t on the lower half, end - step*(overlap-1-t) on the upper half
+      const float wn = (t < overlap / 2) ? step * (float)t : 1.0f - step * (float)(overlap - 1 - t);
+      const float wp = 1.0f - wn;
+#pragma unroll
+      for (int e = 0; e < 6; ++e) d[e] = dp[e] * wp + d[e] * wn;
+    }
+    sixd_to_aa_one(d, o);
+    float* q = out + ((size_t)b * n + t) * joints * 3 + j * 3;
+    q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+  }
+}
+
+__global__ void __launch_bounds__(256) blend_linear_kernel(const float* __restrict__ prev_tail, float* __restrict__ cur, int B,
+                                                          int n, int dim, int overlap) {
+  const int64_t total = (int64_t)B * overlap * dim;
+  const float step = overlap > 1 ? 1.0f / (float)(overlap - 1) : 0.f;
+  for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % dim);
+    const int t = (int)((i / dim) % overlap);
+    const int b = (int)(i / ((int64_t)dim * overlap));
+    const float wn = (t < overlap / 2) ? step * (float)t : 1.0f - step * (float)(overlap - 1 - t);
+    const float wp = 1.0f - wn;
+    float* q = cur + ((size_t)b * n + t) * dim + c;
+    *q = prev_tail[((size_t)b * overlap + t) * dim + c] * wp + *q * wn;
+  }
+}
+
 // generic strided 2-D copy of fp32 columns: dst[r, dcol + c] = src[r, scol + c] (+ optional
 // "subtract first frame" on selected columns, used for trans x/z re-zeroing)
 __global__ void __launch_bounds__(256) copy_cols_kernel(const float* __restrict__ src, int ld_src, int scol,
@@ -517,6 +644,58 @@ extern "C" int rg_copy_cols(rg_handle* h, const float* src, int ld_src, int scol
   RG_REQUIRE(h, rows > 0 && ncols > 0 && ncols <= 32 * 8, "bad shape");
   hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for((int64_t)rows * ncols)), dim3(256), 0, rg_stream(stream), src,
                      ld_src, scol, dst, ld_dst, dcol, rows, ncols, frames, rel_mask);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_scatter_joints(rg_handle* h, const float* upper, int ld_u, const float* lower, int ld_l, const float* hands,
+                                 int ld_h, const float* face, int ld_f, const int* src_part, const int* src_joint, float* out,
+                                 int rows, int joints, void* stream) {
+  RG_REQUIRE(h, upper && lower && hands && face && src_part && src_joint && out, "null pointer");
+  RG_REQUIRE(h, rows > 0 && joints > 0, "bad shape");
+  PartPtrs pp;
+  pp.p[0] = upper; pp.p[1] = lower; pp.p[2] = hands; pp.p[3] = face;
+  pp.ld[0] = ld_u; pp.ld[1] = ld_l; pp.ld[2] = ld_h; pp.ld[3] = ld_f;
+  hipLaunchKernelGGL(scatter_joints_kernel, dim3(grid_for((int64_t)rows * joints)), dim3(256), 0, rg_stream(stream), pp,
+                     src_part, src_joint, out, rows, joints);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_interp_aa(rg_handle* h, const float* aa, float* out, int B, int n, int joints, int scale, void* stream) {
+  RG_REQUIRE(h, aa && out, "null pointer");
+  RG_REQUIRE(h, B > 0 && n > 0 && joints > 0 && scale >= 1, "bad shape");
+  hipLaunchKernelGGL(interp_aa_kernel, dim3(grid_for((int64_t)B * n * scale * joints)), dim3(256), 0, rg_stream(stream), aa,
+                     out, B, n, joints, scale);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_interp_linear(rg_handle* h, const float* x, float* out, int B, int n, int dim, int scale, void* stream) {
+  RG_REQUIRE(h, x && out, "null pointer");
+  RG_REQUIRE(h, B > 0 && n > 0 && dim > 0 && scale >= 1, "bad shape");
+  hipLaunchKernelGGL(interp_linear_kernel, dim3(grid_for((int64_t)B * n * scale * dim)), dim3(256), 0, rg_stream(stream), x,
+                     out, B, n, dim, scale);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_blend_aa(rg_handle* h, const float* prev_tail, const float* cur, float* out, int B, int n, int joints,
+                           int overlap, void* stream) {
+  RG_REQUIRE(h, cur && out && (prev_tail || overlap == 0), "null pointer");
+  RG_REQUIRE(h, B > 0 && n > 0 && joints > 0 && overlap >= 0 && overlap <= n, "bad shape");
+  hipLaunchKernelGGL(blend_aa_kernel, dim3(grid_for((int64_t)B * n * joints)), dim3(256), 0, rg_stream(stream), prev_tail,
+                     cur, out, B, n, joints, overlap);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_blend_linear(rg_handle* h, const float* prev_tail, float* cur, int B, int n, int dim, int overlap,
+                               void* stream) {
+  RG_REQUIRE(h, prev_tail && cur, "null pointer");
+  RG_REQUIRE(h, B > 0 && n > 0 && dim > 0 && overlap > 0 && overlap <= n, "bad shape");
+  hipLaunchKernelGGL(blend_linear_kernel, dim3(grid_for((int64_t)B * overlap * dim)), dim3(256), 0, rg_stream(stream),
+                     prev_tail, cur, B, n, dim, overlap);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -1,0 +1,122 @@
+"""Long-form synthesis driver: tools/longform_synthesis.py around `model(**chunk_data)`.
+
+    :262-287  window split (hop = max_seq_len - frame_chunk_size = 135 frames), zero padding of the tail,
+              motion_mask / speaker_ids padded by repeating their last frames
+    :300-377  per-window slices of the motion tensors and of the time-stamped annotations (text segments,
+              discourse relations, prominence, gesture labels: kept if fully inside the window, shifted)
+    :378-398  inference_kwargs with use_prev_latent = True and prev_latent = the previous window's latent
+    :431-476  15-frame linear blend with the motion so far, in 6D for the pose           -> rg_blend_aa / rg_blend_linear
+    :714-741  final 15 -> 30 fps interpolation of the whole motion                        -> packing.upsample_*
+
+Per-window conditioning features (wav2vec2 on the window's audio, BERT on its words: :320-343) are not part
+of this path: the caller supplies `features(cidx, t0, t1, annotations) -> dict` with at
+least `audio` [B,499,768] and `text_features`.
+"""
+import torch
+
+from . import capi, packing
+
+MOTION_KEYS = ("motion", "motion_upper", "motion_lower", "motion_face", "motion_hands", "contact", "trans", "facial", "beta",
+               "word")
+REPEAT_KEYS = ("motion_mask", "speaker_ids")
+
+
+def window_bounds(sample_len, seqlen=150, overlap=15):
+    """longform_synthesis.py:262-265 -> (starts, ends, frames of padding needed at the end)."""
+    hop = seqlen - overlap
+    starts = [0] + list(range(hop, sample_len, hop))
+    ends = [s + seqlen for s in starts]
+    return starts, ends, max(0, ends[-1] - sample_len)
+
+
+def pad_tail(data, remainder):
+    """longform_synthesis.py:267-287 (zero padding; mask / speaker ids repeat their last `remainder` frames)."""
+    if remainder <= 0:
+        return data
+    out = dict(data)
+    for k in MOTION_KEYS:
+        if k in out and torch.is_tensor(out[k]):
+            z = torch.zeros(out[k].shape[0], remainder, out[k].shape[2], dtype=out[k].dtype, device=out[k].device)
+            out[k] = torch.cat([out[k], z], dim=1)
+    for k in REPEAT_KEYS:
+        if k in out and torch.is_tensor(out[k]):
+            out[k] = torch.cat([out[k], out[k][:, -remainder:]], dim=1)
+    return out
+
+
+def window_annotations(data, t0, t1):
+    """longform_synthesis.py:333-377 for a batch-of-one sample: annotations fully inside [t0, t1], window time."""
+    first = lambda k: (data.get(k) or [[]])[0]
+    segs = [[[s[0][0] - t0, s[0][1] - t0], s[1]] for s in first("text_segments") if s[0][0] >= t0 and s[0][1] <= t1]
+    disc = [(d[0], d[1], d[2], d[3], d[4] - t0, d[5] - t0, d[6] - t0, d[7] - t0) for d in first("discourse")
+            if d[4] >= t0 and d[5] <= t1]
+    prom = [(p[0], p[1] - t0, p[2] - t0, p[3]) for p in first("prominence") if p[1] >= t0 and p[2] <= t1]
+    labels = [dict(start=g["start"] - t0, end=g["end"] - t0, name=g["name"], word=g["word"])
+              for g in first("gesture_labels") if g["start"] >= t0 and g["end"] <= t1]
+    return dict(text_segments=[segs], discourse=[disc], prominence=[prom], gesture_labels=[labels])
+
+
+def blend_window(prev, cur, overlap):
+    """prev / cur = (motion [B,*,165] axis-angle, facial, trans) device tensors; returns the extended triple
+    (longform_synthesis.py:431-476, prediction branch).  The whole new window passes through 6D like the
+    reference's, the first `overlap` frames are blended with the tail of `prev`."""
+    pm, pf, pt = (t.float().contiguous() for t in prev)
+    cm, cf, ct = (t.float().contiguous().clone() for t in cur)
+    B, n, dim = cm.shape
+    h = capi.get_handle(cm.device.index)
+    out_m = torch.empty_like(cm)
+    h.call("blend_aa", pm[:, -overlap:].contiguous(), cm, out_m, B, n, dim // 3, overlap)
+    h.call("blend_linear", pf[:, -overlap:].contiguous(), cf, B, n, cf.shape[-1], overlap)
+    h.call("blend_linear", pt[:, -overlap:].contiguous(), ct, B, n, ct.shape[-1], overlap)
+    return (torch.cat([pm[:, :-overlap], out_m], 1), torch.cat([pf[:, :-overlap], cf], 1),
+            torch.cat([pt[:, :-overlap], ct], 1))
+
+
+class LongformSynthesizer:
+    """model: a rag-gesture_amd MotionDiffusion.  `run(data, features, **inference flags)` mirrors the
+    per-sample loop of tools/longform_synthesis.py and returns 30-fps numpy arrays cut to the sample length."""
+
+    def __init__(self, model, motion_fps=15, max_seq_len=150, overlap=None, target_fps=30):
+        self.model, self.fps, self.seqlen, self.target_fps = model, motion_fps, max_seq_len, target_fps
+        self.overlap = overlap if overlap is not None else model.model.cfg["frame_chunk_size"]
+
+    def run(self, data, features, use_inversion=False, insertion_guidance=False, guidance_iters=None, guidance_lr=0.1,
+            outpaint=False, inversion_start_time=-1, retrieval_method="discourse", noise_tape=None):
+        sample_len = data["motion"].shape[1]
+        starts, ends, remainder = window_bounds(sample_len, self.seqlen, self.overlap)
+        data = pad_tail(data, remainder)
+        prev_latent, so_far, latents = None, None, []
+        for cidx, (c0, c1) in enumerate(zip(starts, ends)):
+            t0, t1 = c0 / self.fps, c1 / self.fps
+            chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
+            assert chunk["motion"].shape[1] == self.seqlen
+            chunk["motion_length"] = [self.seqlen] * chunk["motion"].shape[0]
+            ann = window_annotations(data, t0, t1)
+            chunk.update(ann)
+            chunk.update(features(cidx, t0, t1, ann))
+            if "sample_name" in data:
+                chunk["sample_name"] = [data["sample_name"][0].replace("/0", "/%d" % cidx)]
+            chunk["retrieval_method"] = retrieval_method
+            ikw = dict(use_inversion=use_inversion, outpaint=outpaint, inversion_start_time=inversion_start_time,
+                       insertion_guidance=insertion_guidance, guidance_lr=guidance_lr, use_prev_latent=True,
+                       prev_latent=prev_latent)
+            if guidance_iters is not None:
+                ikw["guidance_iters"] = guidance_iters
+            if noise_tape is not None:
+                ikw["noise_tape"] = noise_tape
+            chunk["inference_kwargs"] = ikw
+            out = self.model(**chunk)
+            prev_latent = out["prev_latentout"]
+            latents.append(prev_latent)
+            cur = (packing.scatter_parts(out["pred_upper"], out["pred_lower"], out["pred_hands"], out["pred_facepose"]),
+                   out["pred_exps"].float(), out["pred_transl"].float())
+            so_far = cur if cidx == 0 else blend_window(so_far, cur, self.overlap)
+        motion, facial, trans = so_far
+        scale = self.target_fps // self.fps
+        if scale != 1:
+            motion, facial, trans = (packing.upsample_motion(motion, scale), packing.upsample_features(facial, scale),
+                                     packing.upsample_features(trans, scale))
+        n_out = sample_len * scale
+        cut = lambda t: t[0, :n_out].detach().cpu().numpy()
+        return dict(poses=cut(motion), expressions=cut(facial), trans=cut(trans), latents=latents,
+                    windows=list(zip(starts, ends)))

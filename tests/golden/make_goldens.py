@@ -158,6 +158,11 @@ def main():
     e2 = (orot.matrix_to_axis_angle(orot.rotation_6d_to_matrix(d6_in)) - aa_out).abs().max().item()
     print("rotation oracle-vs-ref max abs", e1, e2)
 
+    # ---- (ii-b) caller-side packing / long-form helpers ---------------------
+    run_packing_goldens(ns)
+    if "--packing-only" in sys.argv:
+        return
+
     # ---- (iii)-(v),(viii): model-level goldens --------------------------------------------
     with tempfile.TemporaryDirectory() as tmp:
         for tag, L, arch in (("L2_allenc", 2, "all_encoder"), ("L8_encdec", 8, "encoder_decoder")):
@@ -169,6 +174,91 @@ def main():
                 run_model_goldens(ns, model, full, cfg, vae_cfgs, tag)
             if tag == "L2_allenc":
                 run_retrieval_goldens(ns, model, tag)
+
+
+def run_packing_goldens(ns):
+    """tools/visualize.py:208-213, 266-291 and tools/longform_synthesis.py:262-265, 431-476, 714-741 are inline
+    script code, not functions: the same call sequence is issued here on the REFERENCE's own rotation_conversions
+    and torch ops, on seeded inputs; the body-part masks are built from the reference's joint table
+    (mogen/datasets/utils/beatx_utils.py) exactly as beatx_dataset.py:82-109 builds them."""
+    import importlib.util
+    import torch.nn.functional as F
+    from oracle import packing as opk
+    spec = importlib.util.spec_from_file_location("beatx_utils", os.path.join(_ref_import.REF_ROOT, "mogen/datasets/utils/beatx_utils.py"))
+    bu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bu)
+    jl = bu.joints_list
+    ori = jl["beat_smplx_joints"]
+    masks = {}
+    for part in ("upper", "lower", "hands", "face"):
+        m = np.zeros(len(ori) * 3)
+        for name in jl["beat_smplx_" + part]:
+            m[ori[name][1] - ori[name][0]:ori[name][1]] = 1
+        masks[part] = m
+    om = opk.part_masks()
+    for part in masks:
+        assert np.array_equal(masks[part].astype(bool), om[part]), part
+    rc = ns.rc
+    g = np.random.Generator(np.random.PCG64(4242))
+    u = lambda *sh: torch.from_numpy(g.uniform(-0.6, 0.6, size=sh).astype(np.float32))
+    B, n = 1, 150
+    up, lo, ha, fa = u(B, n, 39), u(B, n, 27), u(B, n, 90), u(B, n, 3)
+    facial, trans = u(B, n, 100), u(B, n, 3)
+    pred = torch.zeros(B, n, 165)
+    pred[..., masks["upper"].astype(bool)] = up
+    pred[..., masks["lower"].astype(bool)] = lo
+    pred[..., masks["hands"].astype(bool)] = ha
+    pred[..., masks["face"].astype(bool)] = fa
+
+    def to30(m):
+        bs, nn, dim = m.shape
+        nj = dim // 3
+        x = rc.matrix_to_rotation_6d(rc.axis_angle_to_matrix(m.reshape(bs, nn, nj, 3))).reshape(bs, nn, nj * 6)
+        x = F.interpolate(x.permute(0, 2, 1), scale_factor=30 / 15, mode="linear").permute(0, 2, 1)
+        return rc.matrix_to_axis_angle(rc.rotation_6d_to_matrix(x.reshape(bs, nn * 2, nj, 6))).reshape(bs, nn * 2, nj * 3)
+
+    lin = lambda x: F.interpolate(x.permute(0, 2, 1), scale_factor=30 / 15, mode="linear").permute(0, 2, 1)
+    poses30, facial30, trans30 = to30(pred), lin(facial), lin(trans)
+    # long-form: two windows blended on 15 frames, then the final interpolation of the 285-frame motion
+    ov = 15
+    up2, lo2, ha2, fa2 = u(B, n, 39), u(B, n, 27), u(B, n, 90), u(B, n, 3)
+    facial2, trans2 = u(B, n, 100), u(B, n, 3)
+    pred2 = torch.zeros(B, n, 165)
+    pred2[..., masks["upper"].astype(bool)] = up2
+    pred2[..., masks["lower"].astype(bool)] = lo2
+    pred2[..., masks["hands"].astype(bool)] = ha2
+    pred2[..., masks["face"].astype(bool)] = fa2
+    nj = 55
+    keep_m, tail_m = pred[:, :-ov], pred[:, -ov:]
+    m6 = rc.matrix_to_rotation_6d(rc.axis_angle_to_matrix(pred2.reshape(B, n, nj, 3))).reshape(B, n, nj * 6)
+    t6 = rc.matrix_to_rotation_6d(rc.axis_angle_to_matrix(tail_m.reshape(B, ov, nj, 3))).reshape(B, ov, nj * 6)
+    wn = torch.linspace(0, 1, ov).unsqueeze(0).unsqueeze(-1)
+    wp = 1 - wn
+    m6[:, :ov] = t6 * wp + m6[:, :ov] * wn
+    f2, t2 = facial2.clone(), trans2.clone()
+    f2[:, :ov] = facial[:, -ov:] * wp + f2[:, :ov] * wn
+    t2[:, :ov] = trans[:, -ov:] * wp + t2[:, :ov] * wn
+    m2 = rc.matrix_to_axis_angle(rc.rotation_6d_to_matrix(m6.reshape(B, n, nj, 6))).reshape(B, n, nj * 3)
+    long_m = torch.cat([keep_m, m2], 1)
+    long_f = torch.cat([facial[:, :-ov], f2], 1)
+    long_t = torch.cat([trans[:, :-ov], t2], 1)
+    assert long_m.shape[1] == 285
+    long30 = to30(long_m)
+    sample_len = 700
+    starts = [0] + list(range(150 - 15, sample_len, 150 - 15))
+    ends = [i + 150 for i in starts]
+    np.savez(os.path.join(HERE, "packing.npz"), mask_upper=masks["upper"], mask_lower=masks["lower"], mask_hands=masks["hands"],
+             mask_face=masks["face"], pred_motion=t2n(pred), poses30=t2n(poses30), facial30=t2n(facial30), trans30=t2n(trans30),
+             long_motion=t2n(long_m), long_facial=t2n(long_f), long_trans=t2n(long_t), long30=t2n(long30),
+             starts_700=np.array(starts), ends_700=np.array(ends))
+    # oracle == reference
+    e = lambda a, b: (a - b).abs().max().item()
+    o_pred = opk.scatter_parts(up, lo, ha, fa)
+    o_long = opk.blend_window(pred, facial, trans, pred2, facial2, trans2, ov)
+    print("packing oracle-vs-ref max abs: scatter %g, to30 %g, lin %g, blend (m,f,t) %g %g %g, long30 %g; windows %s" % (
+        e(o_pred, pred), e(opk.interp_motion(pred, 2), poses30), e(opk.interp_features(facial, 2), facial30),
+        e(o_long[0], long_m), e(o_long[1], long_f), e(o_long[2], long_t), e(opk.interp_motion(o_long[0], 2), long30),
+        opk.window_bounds(sample_len)[:2] == (starts, ends)))
 
 
 class _FakeDataset:
