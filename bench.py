@@ -168,9 +168,18 @@ def main():
         # GEMM and ~2/3 of the GPU time of a step
         h.lib.rg_profile_end(h._h, 1, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
         ach = fl.value / (ms.value * 1e-3) if ms.value > 0 else 0.0
+        # HBM-side bytes per launch from the committed PMC passes over the same kernels and shapes
+        # (profiles/r01e_pmc_gemm_traffic.txt explains how they were collected and corrected); null if absent
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_gemm_traffic.json")) as f:
+                rows = json.load(f)
+            traffic = round(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows))
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
+            pass
         roofline = {"bound": "mfma", "kernel": "rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)",
                     "achieved": round(ach / 1e12, 3), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK, 5), "traffic": None, "launches": n.value,
+                    "frac": round(ach / MFMA_BF16_PEAK, 5), "traffic": traffic, "launches": n.value,
                     "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
                     "flops_per_launch_avg": round(fl.value / max(1, n.value))}
     if dist is not None:
