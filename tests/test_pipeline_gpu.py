@@ -176,3 +176,31 @@ def test_concurrent_lanes_equal_single_lane(rg, models):
     for lat, up in outs[1:]:
         # same kernels on the same rows; only the GEMM tile a row falls into (and so nothing numerical) changes
         assert relerr(lat, outs[0][0]) <= 1e-6 and relerr(up, outs[0][1]) <= 1e-5
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_outpaint_vs_oracle(rg, models, precision):
+    """inference_kwargs["outpaint"]: the retrieved latents (re_dict["raw_motion_latents"]) are re-inserted as
+    q_sample(in_seq) on every step (diffusion_architecture.py:283-292, 566-573).  No reference golden for this
+    mode; the oracle's in_seq path is the one pinned bit-exact by the prev-latent goldens."""
+    from oracle import diffusion as odf
+    model = models[("L2", precision)]
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    B = 2
+    g = np.random.Generator(np.random.PCG64(9))
+    rml = torch.from_numpy(g.standard_normal((B, 1, 43, 512)).astype(np.float32))
+    rml[:, :, 25:] = 0          # a partially filled exemplar canvas, like RetrievalDatabase.forward builds
+    rml[:, :, [10, 21, 32]] = 0
+    re = dict(raw_motion_latents=rml)
+    data = rg.synth.synth_batch(B, seed=4321)
+    out = model(**dict(data, re_dict=re, retrieval_method="discourse",
+                       inference_kwargs=dict(outpaint=True, noise_tape=rg.synth.NoiseTape(606))))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), rg.synth.synth_batch(B, seed=4321),
+                                             rg.synth.NoiseTape(606), re_dict=re, outpaint=True)
+    e = relerr(out["prev_latentout"].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP])
+    print("outpaint", precision, "final latent rel err %.3e" % e)
+    assert e <= (1e-2 if precision == "fp32" else 3e-2)
