@@ -366,13 +366,19 @@ __global__ void __launch_bounds__(256, 4) ca_attention_kernel(const float* __res
 // One workgroup per (batch row, head): A[d][l] = sum_n softmax_n(K[n][d]) * V[n][l] over N tokens.
 __global__ void __launch_bounds__(256) kv_reduce_kernel(const float* __restrict__ kv, int ldkv, int D, int N,
                                                        float* __restrict__ A, int H) {
+  // thread -> (key column d, token residue class `part` of 8).  Two passes over K (column max, then the
+  // exponentials), ONE over V: every thread accumulates all 32 value columns for its tokens (the 32 lanes of
+  // a part read the same 128-B V row: one request), then the 8 partial (sum, A-row) sets are added through LDS
+  // in a fixed order.
   __shared__ float red[8][HD];
-  __shared__ float smax[HD], sinv[HD];
+  __shared__ float smax[HD];
+  __shared__ float sacc[8][HD][HD + 1];
   const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int d = threadIdx.x & 31, part = threadIdx.x >> 5;  // 8 parts over tokens
+  const int d = threadIdx.x & 31, part = threadIdx.x >> 5;
   const float* kb = kv + (size_t)b * N * ldkv + h * HD;
   const float* vb = kb + D;
   float mx = -INFINITY;
+#pragma unroll 4
   for (int n = part; n < N; n += 8) mx = fmaxf(mx, kb[(size_t)n * ldkv + d]);
   red[part][d] = mx;
   __syncthreads();
@@ -384,28 +390,40 @@ __global__ void __launch_bounds__(256) kv_reduce_kernel(const float* __restrict_
   __syncthreads();
   mx = smax[d];
   float sum = 0.f;
-  for (int n = part; n < N; n += 8) sum += expf(kb[(size_t)n * ldkv + d] - mx);
+  float acc[HD];
+#pragma unroll
+  for (int l = 0; l < HD; ++l) acc[l] = 0.f;
+#pragma unroll 2
+  for (int n = part; n < N; n += 8) {
+    const float pn = expf(kb[(size_t)n * ldkv + d] - mx);
+    sum += pn;
+    const float4* vr = reinterpret_cast<const float4*>(vb + (size_t)n * ldkv);
+#pragma unroll
+    for (int q = 0; q < HD / 4; ++q) {
+      const float4 vv = vr[q];
+      acc[4 * q] = fmaf(pn, vv.x, acc[4 * q]);
+      acc[4 * q + 1] = fmaf(pn, vv.y, acc[4 * q + 1]);
+      acc[4 * q + 2] = fmaf(pn, vv.z, acc[4 * q + 2]);
+      acc[4 * q + 3] = fmaf(pn, vv.w, acc[4 * q + 3]);
+    }
+  }
   __syncthreads();
   red[part][d] = sum;
+#pragma unroll
+  for (int l = 0; l < HD; ++l) sacc[part][d][l] = acc[l];
   __syncthreads();
-  if (part == 0) {
-    float s = 0.f;
-    for (int q = 0; q < 8; ++q) s += red[q][d];
-    sinv[d] = 1.0f / s;
-  }
-  __syncthreads();
-  const float inv = sinv[d];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s += red[q][d];
+  const float inv = 1.0f / s;
   const int l0 = part * 4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int n = 0; n < N; ++n) {
-    const float pn = expf(kb[(size_t)n * ldkv + d] - mx) * inv;
-    const float4 vv = *reinterpret_cast<const float4*>(vb + (size_t)n * ldkv + l0);
-    acc.x = fmaf(pn, vv.x, acc.x);
-    acc.y = fmaf(pn, vv.y, acc.y);
-    acc.z = fmaf(pn, vv.z, acc.z);
-    acc.w = fmaf(pn, vv.w, acc.w);
-  }
-  *reinterpret_cast<float4*>(A + (((size_t)b * H + h) * HD + d) * HD + l0) = acc;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] += sacc[q][d][l0 + e];
+  *reinterpret_cast<float4*>(A + (((size_t)b * H + h) * HD + d) * HD + l0) =
+      make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
 }
 
 // Exact fp32 linear for tiny, load-time problems (time-embedding tables): out[m][n] = a[m].w[n] + bias,
