@@ -246,13 +246,13 @@ int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const
            int ldo, int B, int H, int Sq, int Sk, int hd, void* stream);
 /* Same operation on the matrix cores for the bf16 path (K, V rounded to bf16, Q and the softmax
  * probabilities as bf16 hi + lo pairs, fp32 accumulation): hd in {16, 32, 64, 128}, Sk <= 192, row
- * strides multiples of 4 floats. */
-int rg_mha_bf16(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
-           int ldo, int B, int H, int Sq, int Sk, int hd, void* stream);
+ * strides multiples of 4 floats.  out_is_bf16 = 1: o is bf16 [B*Sq, ldo] (the A operand of the out-projection). */
+int rg_mha_bf16(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, void* o, int ldo,
+                int out_is_bf16, int B, int H, int Sq, int Sk, int hd, void* stream);
 
 /* nn.LayerNorm(dim), eps 1e-5, fp32 rows (detr_utils.py norm1/norm2/norm3, encoder/decoder norm). */
-int rg_layernorm(rg_handle* h, const float* x, const float* gamma, const float* beta, float* out, int rows,
-                 int dim, void* stream);
+int rg_layernorm(rg_handle* h, const float* x, const float* gamma, const float* beta, float* out, int rows, int dim,
+                 void* out_bf16, void* stream);
 
 /* out[i] = a[i] + b[i % period]: positional embeddings / `with_pos_embed` (detr_utils.py:357-358). */
 int rg_add_rows(rg_handle* h, const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream);

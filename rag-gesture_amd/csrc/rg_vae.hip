@@ -116,7 +116,8 @@ __device__ __forceinline__ unsigned int mh_pack(float a, float b) {
 template <int HD_, int HDR>
 __global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                       int ldk, const float* __restrict__ v, int ldv,
-                                                      float* __restrict__ o, int ldo, int H, int Sq, int Sk, float scale) {
+                                                      float* __restrict__ o, int ldo, int H, int Sq, int Sk, float scale,
+                                                      int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   constexpr int KST = HD_ + 8;                 // bf16 elements per K row (pad: 16 key rows hit 16 bank groups)
   constexpr int KS = HD_ / 32;                 // k-steps of S^T = K Q^T
@@ -240,16 +241,22 @@ __global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__
   for (int e = 0; e < 4; ++e) {
     const int r = q0 + 4 * g + e;
     if (r < Sq) {
-      float* orow = o + ((size_t)b * Sq + r) * ldo + h * HDR;
+      if (out_bf16) {   // the output only feeds the out-projection GEMM: hand it over as its bf16 A operand
+        unsigned short* orow = reinterpret_cast<unsigned short*>(o) + ((size_t)b * Sq + r) * ldo + h * HDR;
 #pragma unroll
-      for (int nd = 0; nd < ND; ++nd) orow[16 * nd + l15] = oc[nd][e];
+        for (int nd = 0; nd < ND; ++nd) orow[16 * nd + l15] = mh_bf16_bits(oc[nd][e]);
+      } else {
+        float* orow = o + ((size_t)b * Sq + r) * ldo + h * HDR;
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd) orow[16 * nd + l15] = oc[nd][e];
+      }
     }
   }
 }
 
 template <int HD_, int HDR>
 static int launch_mha_mfma(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                           float* o, int ldo, int B, int H, int Sq, int Sk, hipStream_t s) {
+                           float* o, int ldo, int B, int H, int Sq, int Sk, int out_bf16, hipStream_t s) {
   const int Skp = (Sk + 31) & ~31;
   const size_t lds = ((size_t)Skp * (HD_ + 8) + (size_t)HD_ * (Skp + 8)) * sizeof(unsigned short);
   static bool attr_set = false;
@@ -258,14 +265,14 @@ static int launch_mha_mfma(rg_handle* h, const float* q, int ldq, const float* k
     attr_set = true;
   }
   hipLaunchKernelGGL((mha_mfma_kernel<HD_, HDR>), dim3(B * H, (Sq + 63) / 64), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, o, ldo,
-                     H, Sq, Sk, 1.0f / sqrtf((float)HDR));
+                     H, Sq, Sk, 1.0f / sqrtf((float)HDR), out_bf16);
   return 0;
 }
 
 // ------------------------------------------------------------------------------ LayerNorm, one wave per row
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                        const float* __restrict__ b, float* __restrict__ out, int rows,
-                                                       int dim, float eps) {
+                                                       int dim, float eps, unsigned short* __restrict__ out_bf16) {
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * dim;
@@ -283,7 +290,11 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   for (int off = 1; off < 64; off <<= 1) ss += __shfl_xor(ss, off);
   const float rstd = rsqrtf(ss / (float)dim + eps);
   float* orow = out + (size_t)row * dim;
-  for (int i = lane; i < dim; i += 64) orow[i] = (xr[i] - mean) * rstd * g[i] + b[i];
+  for (int i = lane; i < dim; i += 64) {
+    const float v = (xr[i] - mean) * rstd * g[i] + b[i];
+    orow[i] = v;
+    if (out_bf16) out_bf16[(size_t)row * dim + i] = __builtin_bit_cast(unsigned short, (__bf16)v);   // next GEMM's A operand
+  }
 }
 
 __global__ void __launch_bounds__(256) add_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
@@ -564,26 +575,26 @@ extern "C" int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int
 }
 
 extern "C" int rg_mha_bf16(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                           float* o, int ldo, int B, int H, int Sq, int Sk, int hd, void* stream) {
+                           void* o, int ldo, int out_is_bf16, int B, int H, int Sq, int Sk, int hd, void* stream) {
   RG_REQUIRE(h, q && k && v && o, "null pointer");
   RG_REQUIRE(h, B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= MH_MAX_SK, "bad shape (Sk <= 192)");
   RG_REQUIRE(h, hd == 128 || hd == 64 || hd == 32 || hd == 16, "head dim must be 16, 32, 64 or 128");
   RG_REQUIRE(h, ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "row strides must be multiples of 4 floats");
   hipStream_t s = rg_stream(stream);
-  if (hd == 128) launch_mha_mfma<128, 128>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
-  else if (hd == 64) launch_mha_mfma<64, 64>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
-  else if (hd == 32) launch_mha_mfma<32, 32>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
-  else launch_mha_mfma<32, 16>(h, q, ldq, k, ldk, v, ldv, o, ldo, B, H, Sq, Sk, s);
+  if (hd == 128) launch_mha_mfma<128, 128>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else if (hd == 64) launch_mha_mfma<64, 64>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else if (hd == 32) launch_mha_mfma<32, 32>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else launch_mha_mfma<32, 16>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }
 
 extern "C" int rg_layernorm(rg_handle* h, const float* x, const float* gamma, const float* beta, float* out, int rows,
-                            int dim, void* stream) {
+                            int dim, void* out_bf16, void* stream) {
   RG_REQUIRE(h, x && gamma && beta && out, "null pointer");
   RG_REQUIRE(h, rows > 0 && dim > 0, "bad shape");
   hipLaunchKernelGGL(layernorm_kernel, dim3(((int64_t)rows * 64 + 255) / 256), dim3(256), 0, rg_stream(stream), x, gamma,
-                     beta, out, rows, dim, 1e-5f);
+                     beta, out, rows, dim, 1e-5f, reinterpret_cast<unsigned short*>(out_bf16));
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -11,6 +11,8 @@ batch-major [B*S, D] (the reference is sequence-major; attention is per sequence
 The VAE hyper-parameters come from the YAML shipped with each checkpoint, so
 nothing here is specialised to one width/depth/arch.
 """
+import os
+
 import torch
 
 from . import capi, gemm as G
@@ -73,6 +75,10 @@ class TransformerVAE:
         self.dev = torch.device(device)
         self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
         self.precision = precision
+        # bf16 path: every op that feeds a GEMM hands over a bf16 copy (LayerNorm, attention, FF1) so the GEMMs
+        # read bf16 A operands instead of converting fp32 tiles in each of their column tiles
+        self.chain = precision == "bf16" and os.environ.get("RG_VAE_CHAIN", "1") == "1"
+        self._copies = None
         split = precision == "fp32"
         D = self.D = vcfg["latent_dim"]
         self.nfeats, self.chunk, self.frames = vcfg["nfeats"], vcfg["frame_chunk_size"], vcfg["num_frames"]
@@ -96,8 +102,14 @@ class TransformerVAE:
             raise ValueError("Not support architecture!")
 
     # ---------------------------------------------------------------- building blocks
-    def _lin(self, lin, x, M, out=None, residual=None, act=0, tbias=None, tb_period=0, segs=None):
-        out = torch.empty(M, lin.n, device=self.dev) if out is None else out
+    def _lin(self, lin, x, M, out=None, residual=None, act=0, tbias=None, tb_period=0, segs=None, bf16_out=False):
+        """x: fp32 [M,K] (converted tile by tile in the GEMM prologue) or bf16 [M,K] (used as is)."""
+        if out is None:
+            out = torch.empty(M, lin.n, device=self.dev, dtype=torch.bfloat16 if bf16_out else torch.float32)
+        if x is not None and x.dtype == torch.bfloat16:
+            G.gemm(self.h, M=M, N=lin.n, K=lin.k, W=lin.w, out=out, A=x, bias=lin.b, residual=residual, act=act,
+                   tbias=tbias, tb_period=tb_period)
+            return out
         segs = segs or [G.Seg(x)]
         seg_len = None if len(segs) == 1 else segs[0].src.shape[-1]
         G.gemm(self.h, M=M, N=lin.n, K=lin.k, W=lin.w, out=out, segs=segs, seg_len=seg_len, bias=lin.b,
@@ -105,25 +117,39 @@ class TransformerVAE:
         return out
 
     def _ln(self, x, gb, M):
+        """fp32 LayerNorm; on the bf16 path the kernel also leaves a bf16 copy (the next GEMM's A operand),
+        looked up by _b16()."""
         out = torch.empty_like(x)
-        self.h.call("layernorm", x, gb[0], gb[1], out, M, self.D)
+        o16 = torch.empty(x.shape, device=self.dev, dtype=torch.bfloat16) if self.chain else None
+        self.h.call("layernorm", x, gb[0], gb[1], out, M, self.D, o16)
+        if o16 is not None:
+            self._copies = (out, o16)
         return out
+
+    def _b16(self, x):
+        """the bf16 copy of x if the op that produced x left one (aligned rows only), else x itself"""
+        c = self._copies
+        return c[1] if (c is not None and c[0] is x and self.D % 8 == 0) else x
 
     def _self_attn(self, blk, x, B, S, heads, pos, M):
         D = self.D
         if pos is None:
-            qkv = self._lin(blk.qkv, x, M)
+            qkv = self._lin(blk.qkv, self._b16(x), M)
             q, k, v, ld = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D
             ldv = 3 * D
         else:
             xp = torch.empty_like(x)
             self.h.call("add_rows", x, pos, xp, capi.I64(x.numel()), capi.I64(x.numel()))
             qk = self._lin(blk.qk, xp, M)
-            v = self._lin(blk.v, x, M)
+            v = self._lin(blk.v, self._b16(x), M)
             q, k, ld, ldv = qk, qk[:, D:], 2 * D, D
-        o = torch.empty(M, D, device=self.dev)
+        o = torch.empty(M, D, device=self.dev, dtype=torch.bfloat16 if self._mha_fast(D // heads, S, ld, ld, ldv) else torch.float32)
         self._mha(q, ld, k, ld, v, ldv, o, B, heads, S, S)
         return o
+
+    def _mha_fast(self, hd, Sk, ldq, ldk, ldv):
+        return (self.precision == "bf16" and hd in (16, 32, 64, 128) and Sk <= 192 and ldq % 4 == 0 and ldk % 4 == 0
+                and ldv % 4 == 0 and self.D % 8 == 0)
 
     def _mha(self, q, ldq, k, ldk, v, ldv, o, B, heads, Sq, Sk):
         import ctypes
@@ -131,11 +157,14 @@ class TransformerVAE:
         s = torch.cuda.current_stream().cuda_stream
         vp = ctypes.c_void_p
         # bf16 path: attention on the matrix cores; fp32 ("bf16x3") path: the exact fp32 VALU kernel
-        fast = self.precision == "bf16" and hd in (16, 32, 64, 128) and Sk <= 192 and ldq % 4 == 0 and ldk % 4 == 0 \
-            and ldv % 4 == 0
-        fn = self.h.lib.rg_mha_bf16 if fast else self.h.lib.rg_mha
-        rc = fn(self.h._h, vp(q.data_ptr()), ldq, vp(k.data_ptr()), ldk, vp(v.data_ptr()), ldv,
-                vp(o.data_ptr()), self.D, B, heads, Sq, Sk, hd, vp(s))
+        if self._mha_fast(hd, Sk, ldq, ldk, ldv):
+            rc = self.h.lib.rg_mha_bf16(self.h._h, vp(q.data_ptr()), ldq, vp(k.data_ptr()), ldk, vp(v.data_ptr()), ldv,
+                                        vp(o.data_ptr()), self.D, 1 if o.dtype == torch.bfloat16 else 0, B, heads, Sq, Sk, hd,
+                                        vp(s))
+        else:
+            assert o.dtype == torch.float32
+            rc = self.h.lib.rg_mha(self.h._h, vp(q.data_ptr()), ldq, vp(k.data_ptr()), ldk, vp(v.data_ptr()), ldv,
+                                   vp(o.data_ptr()), self.D, B, heads, Sq, Sk, hd, vp(s))
         if rc != 0:
             raise capi.RgError("rg_mha failed: %s" % self.h.lib.rg_last_error(self.h._h).decode())
 
@@ -145,7 +174,7 @@ class TransformerVAE:
         if not self.pre:
             a = self._self_attn(blk, x, B, S, heads, pos, M)
             x = self._ln(self._lin(blk.out, a, M, residual=x), blk.n1, M)
-            hmid = self._lin(blk.l1, x, M, act=self.act)
+            hmid = self._lin(blk.l1, self._b16(x), M, act=self.act, bf16_out=self.chain)
             return self._ln(self._lin(blk.l2, hmid, M, residual=x), blk.n2, M)
         x2 = self._ln(x, blk.n1, M)
         a = self._self_attn(blk, x2, B, S, heads, pos, M)
