@@ -50,6 +50,8 @@ def build_submodule(cfg, **kwargs):
 
 
 class _TorchNoise:
+    order_free = True  # draws come from torch's generator: consumers may batch / reorder them
+
     def __init__(self, device, generator=None):
         self.device, self.generator = device, generator
 

@@ -387,9 +387,12 @@ class RetrievalDatabase:
         if ex:
             E = len(ex)
             stack = lambda k: torch.stack([r[k] for r in recs]).to(dev).float().contiguous()
-            draw = (lambda shape: noise.draw(shape)) if noise is not None else (lambda shape: torch.randn(*shape, device=dev))
-            eps = [[draw((L, 1, D)) for _ in range(4)] for _ in range(E)]
-            eps_list = [torch.cat([e[p].to(dev) for e in eps], dim=0) for p in range(4)]
+            if noise is not None and not getattr(noise, "order_free", False):
+                # explicit noise: the reference draws 4 x [L,1,D] per exemplar, exemplar-major (rsample order)
+                eps = [[noise.draw((L, 1, D)) for _ in range(4)] for _ in range(E)]
+                eps_list = [torch.cat([e[p].to(dev) for e in eps], dim=0) for p in range(4)]
+            else:
+                eps_list = [torch.randn(E * L, 1, D, device=dev) for _ in range(4)]  # generator noise: order is immaterial
             lat, _ = gre.encode(stack("motion_upper"), stack("motion_lower"), stack("motion_face"), stack("motion_hands"),
                                 stack("trans"), stack("facial"), stack("contact"), stack("motion_mask"), eps_list)
         tick("retrieval.exemplar_encode")
@@ -399,6 +402,11 @@ class RetrievalDatabase:
         raw_motion = torch.zeros(B, self.max_seq_len, tmpl["motion"].shape[-1], device=dev)
         raw_trans = torch.zeros(B, self.max_seq_len, tmpl["trans"].shape[-1], device=dev)
         raw_facial = torch.zeros(B, self.max_seq_len, tmpl["facial"].shape[-1], device=dev)
+        # all row copies of the exemplar canvases are gathered into index lists and issued as one gather/scatter
+        # per tensor (a guided batch has ~50 exemplars x 7 small copies otherwise); later spans overwrite earlier
+        # ones exactly as the reference's sequential slice assignments do (index_copy_ with unique keys)
+        lat_copy, frame_copy = {}, {}
+        lmask = gre.latent_mask(torch.stack([r["motion_mask"] for r in recs])) if ex else None
         for e, (b, qp, name, placed) in enumerate(ex):
             if placed is None:
                 continue
@@ -408,18 +416,26 @@ class RetrievalDatabase:
             retr_lats[b][qp] = dict(retr_motion_latent=lat[e:e + 1], retr_text=rec["word"].unsqueeze(0).to(dev),
                                     retr_audio=rec["audio"].unsqueeze(0).to(dev),
                                     retr_spkid=rec["speaker_id"].unsqueeze(0).to(dev),
-                                    retr_motion_mask=gre.latent_mask(rec["motion_mask"].unsqueeze(0)))
+                                    retr_motion_mask=lmask[e:e + 1])
             for part in range(4):
                 o = part * (L + 1)
-                zero_motion[b, o + s0:o + s1] = lat[e, o + r0:o + r1]
-            f0, f1, g0, g1 = s0 * chunk, s1 * chunk, r0 * chunk, r1 * chunk
-            raw_motion[b, f0:f1] = rec["motion"].to(dev)[g0:g1]
-            raw_trans[b, f0:f1] = rec["trans"].to(dev)[g0:g1]
-            raw_facial[b, f0:f1] = rec["facial"].to(dev)[g0:g1]
+                for i in range(s1 - s0):
+                    lat_copy[b * T + o + s0 + i] = e * T + o + r0 + i
+            f0, g0 = s0 * chunk, r0 * chunk
+            for i in range((s1 - s0) * chunk):
+                frame_copy[b * self.max_seq_len + f0 + i] = e * self.max_seq_len + g0 + i
             q_word, q_type = qb[qp][0], qb[qp][1]
             r_word, r_type = rb[qp][name][0], rb[qp][name][1]
             type2words[b][qp] = (q_word, q_type, r_word, r_type)
             names_out[b][q_word] = name
+        if lat_copy:
+            idx = lambda d: (torch.tensor(list(d.keys()), device=dev), torch.tensor(list(d.values()), device=dev))
+            dst, src = idx(lat_copy)
+            zero_motion.view(B * T, D).index_copy_(0, dst, lat.reshape(E * T, D).index_select(0, src))
+            dst, src = idx(frame_copy)
+            for canvas, key in ((raw_motion, "motion"), (raw_trans, "trans"), (raw_facial, "facial")):
+                allrec = torch.stack([r[key] for r in recs]).to(dev).float()
+                canvas.view(B * self.max_seq_len, -1).index_copy_(0, dst, allrec.view(E * self.max_seq_len, -1).index_select(0, src))
         src_mask = (zero_motion != 0).any(dim=-1).to(torch.int)
         raw_latent_mask = src_mask.clone()
         raw_motion_latents = zero_motion.clone()
