@@ -164,6 +164,10 @@ class DiscourseIndex:
 
     def sims(self, q_feat_dev, cand):
         """HIP tie-break reduction: mean diagonal similarity of the query to each candidate entry."""
+        return self.sims_async(q_feat_dev, cand).cpu().numpy()
+
+    def sims_async(self, q_feat_dev, cand):
+        """Launch only: float64 device tensor [len(cand)]."""
         lib, vp = self.h.lib, ctypes.c_void_p
         c = torch.tensor(cand, dtype=torch.int32, device=self.dev)
         out = torch.empty(len(cand), dtype=torch.float64, device=self.dev)
@@ -173,7 +177,7 @@ class DiscourseIndex:
                                   vp(out.data_ptr()), vp(s))
         if rc != 0:
             raise capi.RgError("rg_text_diag_sim failed: %s" % lib.rg_last_error(self.h._h).decode())
-        return out.cpu().numpy()
+        return out
 
 
 def discourse_queries(discourse, prominence, speaker_id):
@@ -183,43 +187,58 @@ def discourse_queries(discourse, prominence, speaker_id):
     return [(d[1], d[0], speaker_id, None if q_prom[i] is None else q_prom[i][1]) for i, d in enumerate(discourse)]
 
 
-def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text, survivors=None):
-    """Same contract as rag/discourse_retrieval.py:8-316 (returns sample_indexes, d_bounds,
-    query_bounds) with the DB sweep and the candidate selection on the GPU.  `survivors`: the
-    collect()ed results of a sweep_async() over discourse_queries(...) launched earlier (batched over
-    clips); None = sweep here."""
-    d_bounds, sample_indexes, query_bounds = {}, {}, {}
+def discourse_retrieval_begin(index, discourse, prominence, speaker_id, encoded_text, survivors=None):
+    """First half of discourse_retrieval: orders the survivors of every query relation, cuts the leading score
+    tiers the reference's ranking walk can reach (it stops once it holds 10 entries) and LAUNCHES the
+    tie-break similarity of every multi-member tier without reading anything back.  Returns a pending record
+    for discourse_retrieval_finish; `pending["sims"]` are device tensors (one per tie tier)."""
+    pend = dict(discourse=discourse, queries=[], sims=[])
     if len(discourse) == 0:
-        return sample_indexes, d_bounds, query_bounds
-    senses = [d[1] for d in discourse]
-    conns = [d[0] for d in discourse]
-    query_bounds = {i: (d[0].lower(), d[1], d[6], d[7]) for i, d in enumerate(discourse)}
-    q_prom = map_conns_to_prominence(conns, prominence)
+        return pend
     q_dev = encoded_text.to(index.dev).float().contiguous()
+    pend["q_dev"] = q_dev   # keeps the features alive until the kernels have run
     if survivors is None:
         survivors = index.collect(index.sweep_async(discourse_queries(discourse, prominence, speaker_id)))
-    for qi, (q_sense, q_conn) in enumerate(zip(senses, conns)):
-        # Only the top tiers are ever visited (the walk stops at 10 entries): the device kept the entries
-        # whose score reaches the 10th largest one (all ties included); order them like
-        # sorted(..., reverse=True) (stable among equals).  score/top are sparse views indexed by entry.
+    for qi in range(len(discourse)):
+        # Only the top tiers are ever visited: the device kept the entries whose score reaches the 10th largest
+        # one (all ties included); order them like sorted(..., reverse=True) (stable among equals).
         keep, kscore, ktop = survivors[qi]
-        score = dict(zip(keep.tolist(), kscore.tolist()))
         top = dict(zip(keep.tolist(), ktop.tolist()))
-        order = keep[np.argsort(-kscore, kind="stable")].tolist()
-        ranked, i = [], 0
-        while i < len(order) and len(ranked) < 10:
-            sc = score[order[i]]
+        o = np.argsort(-kscore, kind="stable")
+        order, oscore = keep[o].tolist(), kscore[o].tolist()
+        tiers, i, n = [], 0, 0
+        while i < len(order) and n < 10:
+            sc = oscore[i]
             if not sc > 0:
                 break
             j = i
-            while j < len(order) and score[order[j]] == sc:
+            while j < len(order) and oscore[j] == sc:
                 j += 1
             tier = [int(e) for e in order[i:j]]
+            slot = None
             if len(tier) > 1:
-                sim = index.sims(q_dev, tier)
-                tier = [tier[k] for k in np.argsort(-sim, kind="stable")]
-            ranked += tier
+                slot = len(pend["sims"])
+                pend["sims"].append(index.sims_async(q_dev, tier))
+            tiers.append((tier, slot))
+            n += len(tier)
             i = j
+        pend["queries"].append((tiers, top))
+    return pend
+
+
+def discourse_retrieval_finish(index, pend, sims_host):
+    """Second half: sims_host[slot] = the tie-break similarities (numpy) of pending["sims"][slot]."""
+    discourse = pend["discourse"]
+    d_bounds, sample_indexes, query_bounds = {}, {}, {}
+    if len(discourse) == 0:
+        return sample_indexes, d_bounds, query_bounds
+    query_bounds = {i: (d[0].lower(), d[1], d[6], d[7]) for i, d in enumerate(discourse)}
+    for qi, (tiers, top) in enumerate(pend["queries"]):
+        ranked = []
+        for tier, slot in tiers:
+            if slot is not None:
+                tier = [tier[k] for k in np.argsort(-sims_host[slot], kind="stable")]
+            ranked += tier
         ranked = ranked[:10]
         sample_indexes[qi] = [index.names[e] for e in ranked]
         d_bounds[qi] = {}
@@ -227,6 +246,31 @@ def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text, 
             b = index.db["idx_2_discbounds"][index.names[e]][int(top[e])]
             d_bounds[qi][index.names[e]] = (b[1], b[0], round(b[4], 3), round(b[5], 3))
     return sample_indexes, d_bounds, query_bounds
+
+
+def fetch_sims(pendings):
+    """One read-back for the tie-break similarities of any number of pending retrievals."""
+    tensors = [t for p in pendings for t in p["sims"]]
+    if not tensors:
+        return [[] for _ in pendings]
+    flat = torch.cat(tensors).cpu().numpy()
+    out, pos = [], 0
+    for p in pendings:
+        cur = []
+        for t in p["sims"]:
+            cur.append(flat[pos:pos + t.numel()])
+            pos += t.numel()
+        out.append(cur)
+    return out
+
+
+def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text, survivors=None):
+    """Same contract as rag/discourse_retrieval.py:8-316 (returns sample_indexes, d_bounds,
+    query_bounds) with the DB sweep, the candidate selection and the tie-break similarity on the GPU.
+    `survivors`: the collect()ed results of a sweep_async() over discourse_queries(...) launched earlier
+    (batched over clips); None = sweep here."""
+    pend = discourse_retrieval_begin(index, discourse, prominence, speaker_id, encoded_text, survivors)
+    return discourse_retrieval_finish(index, pend, fetch_sims([pend])[0])
 
 
 def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="discourse", fps=15, chunk=15,
@@ -318,7 +362,7 @@ class RetrievalDatabase:
         self.test_indexes, self.test_dbounds, self.test_qbounds = {}, {}, {}
         self.phase_ms = None  # dict: MotionDiffusion's phase profiler also collects the sub-phases here
 
-    def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None, survivors=None):
+    def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None, ready=None):
         """raggesture.py:313-477 (eval branch, first-call behaviour; results cached per idx)."""
         if retr_method != "discourse":
             raise NotImplementedError("only the discourse retrieval method is built (llm / gesture_type: next)")
@@ -326,7 +370,8 @@ class RetrievalDatabase:
             si, db_b, qb = (self.test_indexes[idx][retr_method], self.test_dbounds[idx][retr_method],
                             self.test_qbounds[idx][retr_method])
         else:
-            si, db_b, qb = discourse_retrieval(self.index, discourse, prominence, speaker_id, text_features, survivors)
+            si, db_b, qb = ready if ready is not None else discourse_retrieval(self.index, discourse, prominence,
+                                                                                  speaker_id, text_features)
             self.test_indexes.setdefault(idx, {})[retr_method] = si
             self.test_dbounds.setdefault(idx, {})[retr_method] = db_b
             self.test_qbounds.setdefault(idx, {})[retr_method] = qb
@@ -370,12 +415,18 @@ class RetrievalDatabase:
                 pending[b] = (len(queries), len(qs))
                 queries += qs
         swept = self.index.collect(self.index.sweep_async(queries)) if queries else []
+        # tie-break similarities of all clips: launched back to back, one read-back
+        order_b = sorted(pending)
+        begun = [discourse_retrieval_begin(self.index, conditions["discourse"][b], conditions["prominence"][b], spks[b],
+                                           conditions["text_features"][b],
+                                           swept[pending[b][0]:pending[b][0] + pending[b][1]]) for b in order_b]
+        sims = fetch_sims(begun)
+        ready = {b: discourse_retrieval_finish(self.index, p, sm) for b, p, sm in zip(order_b, begun, sims)}
         for b in range(B):
             spk = spks[b]
-            surv = swept[pending[b][0]:pending[b][0] + pending[b][1]] if b in pending else None
             ri, rb, qb = self.retrieve(retrieval_method, conditions["text_features"][b], conditions["discourse"][b],
                                        conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None,
-                                       survivors=surv)
+                                       ready=ready.get(b))
             plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
             plans.append((plan, rb, qb))
             for qp, name, placed in plan:
