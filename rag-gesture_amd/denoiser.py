@@ -384,7 +384,10 @@ class DenoiserSession:
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, segs=[ff_seg], seg_len=D, bias=lw["b_ffo"], residual=xc,
                        stats_out=sa_)
-        G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, segs=[G.Seg(xa)], seg_len=D, bias=w.b_out)
+        if self.xa_bf is not None:   # the last FFN-out epilogue left the bf16 copy of xa
+            G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, A=self.xa_bf, bias=w.b_out)
+        else:
+            G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, segs=[G.Seg(xa)], seg_len=D, bias=w.b_out)
         return self.head
 
     def cfg_ddim(self, x, x_out, step, c_a, c_b, x0_out=None):
