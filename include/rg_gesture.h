@@ -146,7 +146,9 @@ typedef struct rg_gemm_desc {
   const float* ln_stats;  // null, or [M][ln_nparts][2] partial (sum, sumsq) of the fp32 rows whose bf16 copy is A:
   const float* ln_c1;     //   LayerNorm folded into the epilogue.  With W' = W diag(gamma) packed as the weight,
   int ln_nparts;          //   c1[n] = sum_k W'[n][k] and bias[n] = b[n] + sum_k W[n][k] beta[k]:
-  int pad3_;              //   out = rstd * (A W'^T - mean * c1) + bias  ==  LN(x) W^T + b   (mean/rstd over K columns)
+  int split_col;          //   out = rstd * (A W'^T - mean * c1) + bias  ==  LN(x) W^T + b   (mean/rstd over K columns)
+                          // split_col > 0 (multiple of 128): output columns >= split_col go ONLY to out2 (bf16, column
+                          // index - split_col), columns below it only to out: a GEMM with an fp32 and a bf16 consumer
 } rg_gemm_desc;
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
@@ -194,6 +196,16 @@ int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* 
  * production path); 0: exact fp32 VALU products (precision = "fp32"). */
 int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
                     float* stats, int R, int T, int D, const int* perm, int nperm, int use_mfma, void* stream);
+
+/* rg_sa_attention (matrix-core form) + the stylization front half of the self-attention block
+ * (efficient_attention.py:32-46, stylization_block.py:30-47) in one launch, one 16-wave workgroup per batch row:
+ * qk fp32 [R*T][ldqk] with q (softmaxed) in columns [0,D) and k in [D,2D); v bf16 [R*T][ldv] (the QKV
+ * GEMM's split output, rg_gemm_desc.split_col); writes bf16(SiLU(LN(y)*(1+scale)+shift)) [R*T][ldo], the
+ * A operand of the SA-out GEMM.  D must be 512 (one wave per head); perm as for rg_sa_attention with one
+ * work item per row. */
+int rg_sa_stylize(rg_handle* h, const float* qk, int ldqk, const void* v_bf16, int ldv, const float* src_mask,
+                  const float* gamma, const float* beta, const float* scale_shift, void* out_bf16, int ldo, int R, int T,
+                  int D, const int* perm, int nperm, void* stream);
 
 /* Cross-attention core of EfficientCrossAttention for ncond parallel conditions
  * (efficient_attention.py:90-98; diffusion_transformer.py:105-118): y3[:, c*D:(c+1)*D] = Q_c A_c

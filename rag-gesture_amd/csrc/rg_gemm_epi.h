@@ -176,9 +176,14 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
   // wave-instruction writes whole contiguous rows (2 x 512 B fp32 or 4 x 256 B bf16) instead of 64
   // scattered 16-B pieces at a 128-B stride (measured 3 us -> 1 us per 64x128 tile).
   const bool tile_full = (n0 + BN <= p.N);
-  const bool fast_f32 = tile_full && !p.out_bf16 && (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
-  const bool fast_bf16 = tile_full && p.out_bf16 && (p.ldo & 7) == 0 && (((uintptr_t)p.out) & 15) == 0;
-  const bool fast_o2 = tile_full && p.out2 && (p.ldo2 & 7) == 0 && (((uintptr_t)p.out2) & 15) == 0;
+  // split output: this tile's columns go either to out (below split_col) or to out2 (bf16, from split_col on)
+  const bool to_o2_only = p.split_col > 0 && n0 >= p.split_col;
+  const bool want_main = !to_o2_only;
+  const bool want_o2 = p.out2 && (p.split_col == 0 || to_o2_only);
+  const int o2c0 = p.split_col > 0 ? p.split_col : 0;   // column origin of out2
+  const bool fast_f32 = want_main && tile_full && !p.out_bf16 && (p.ldo & 3) == 0 && (((uintptr_t)p.out) & 15) == 0;
+  const bool fast_bf16 = want_main && tile_full && p.out_bf16 && (p.ldo & 7) == 0 && (((uintptr_t)p.out) & 15) == 0;
+  const bool fast_o2 = want_o2 && tile_full && (p.ldo2 & 7) == 0 && (((uintptr_t)p.out2) & 15) == 0 && (o2c0 & 7) == 0;
   if (fast_f32 || fast_bf16 || fast_o2) {
     float* mine = const_cast<float*>(sC) + erow * SC_LD + ecol;
 #pragma unroll
@@ -209,14 +214,14 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
           if (fast_bf16)
             *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)(m0 + r) * p.ldo + n0 + c8) = pk;
           if (fast_o2)
-            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.out2) + (size_t)(m0 + r) * p.ldo2 + n0 + c8) = pk;
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(p.out2) + (size_t)(m0 + r) * p.ldo2 + n0 - o2c0 + c8) = pk;
         }
       }
     }
   }
   if (!row_ok) return;
-  if (p.out2 && !fast_o2) {
-    unsigned short* o2 = reinterpret_cast<unsigned short*>(p.out2) + (size_t)grow * p.ldo2 + gcol;
+  if (want_o2 && !fast_o2) {
+    unsigned short* o2 = reinterpret_cast<unsigned short*>(p.out2) + (size_t)grow * p.ldo2 + gcol - o2c0;
     if (full && (p.ldo2 & 7) == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -227,7 +232,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
       for (int e = 0; e < 32; ++e) if (gcol + e < p.N) o2[e] = f2bf(v[e]);
     }
   }
-  if (fast_f32 || fast_bf16) return;
+  if (fast_f32 || fast_bf16 || !want_main) return;
   if (p.out_bf16) {
     unsigned short* o = reinterpret_cast<unsigned short*>(p.out) + (size_t)grow * p.ldo + gcol;
     if (full && (p.ldo & 7) == 0) {

@@ -212,12 +212,17 @@ class DenoiserSession:
         self.yf, self.st_f = f(M, D), f(M, D // G.STATS_COLS, 2)
         self.head = f(M, D)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
-        self.abf = self.xa_bf = None
+        self.abf = self.xa_bf = self.v_sa = None
         if w.precision == "bf16" and os.environ.get("RG_STYL_PREPASS", "1") == "1":
             self.abf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
             self.abf3 = torch.empty(B * T, 3 * D, device=dev, dtype=torch.bfloat16)
             if os.environ.get("RG_LN_EPILOGUE", "1") == "1":
                 self.xa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+                # experimental: self-attention + stylization in one 16-wave kernel (rg_sa_stylize).  Measured
+                # slower than the two separate kernels at B <= 48 (it concentrates 16 heads on R <= 96 CUs:
+                # sampling 50.4 vs 48.1 ms, inversion equal), so it is off unless asked for
+                if os.environ.get("RG_SA_FUSED", "0") == "1" and D == 512:
+                    self.v_sa = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.qmask_c = torch.ones(3, B, T, device=dev)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
@@ -229,6 +234,7 @@ class DenoiserSession:
             (lambda n, ipg, T_: np.arange(n * ipg, dtype=np.int32))
         dv = lambda a: torch.from_numpy(a).to(dev)
         self.perm_sa = dv(order(self.R, ng, T))
+        self.perm_sa1 = dv(order(self.R, 1, T))
         self.perm_ca = dv(order(self.R, 3 * ng, T))
         self.perm_cac = dv(order(B, 3 * ng, T))
 
@@ -295,7 +301,13 @@ class DenoiserSession:
             ss = w.ss[step, l]
             # --- self attention
             qkv_seg = G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])
-            if self.xa_bf is not None:
+            if self.xa_bf is not None and self.v_sa is not None:
+                # as below, and q, k leave as fp32 [M, 2D], v as bf16 [M, D] (split output): the fused
+                # self-attention + stylization kernel keeps 16 heads of K (fp32) and V (bf16) in LDS and writes
+                # the SA-out GEMM's bf16 A operand directly
+                G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv_ln"], out=self.qkv, ldo=3 * D, A=self.xa_bf, bias=lw["c2_qkv"],
+                       ln_stats=sa_, ln_c1=lw["c1_qkv"], softmax_cols=D, out2=self.v_sa, split_col=2 * D)
+            elif self.xa_bf is not None:
                 # A = bf16 copy of xa written by the producing GEMM; the LayerNorm is folded into this GEMM's
                 # epilogue (rstd * (acc - mean * c1) + c2): no normalisation pass, no extra launch
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv_ln"], out=self.qkv, A=self.xa_bf, bias=lw["c2_qkv"],
@@ -308,10 +320,18 @@ class DenoiserSession:
             else:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv, segs=[qkv_seg], seg_len=D,
                        bias=lw["b_qkv"], softmax_cols=D)
-            h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
-                   self.perm_sa, self.perm_sa.numel(), 1 if w.precision == "bf16" else 0)
+            fused_sa = self.xa_bf is not None and self.v_sa is not None
+            if fused_sa:
+                h.call("sa_stylize", self.qkv, 3 * D, self.v_sa, D, self.src_mask, lw["sa_sg"], lw["sa_sb"], ss[0], self.abf, D,
+                       R, T, D, self.perm_sa1, self.perm_sa1.numel())
+            else:
+                h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
+                       self.perm_sa, self.perm_sa.numel(), 1 if w.precision == "bf16" else 0)
             sa_seg = G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"], scale_shift=ss[0])
-            if self.abf is not None:
+            if fused_sa:
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
+                       out2=self.hcat[:, 3 * D:])
+            elif self.abf is not None:
                 # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
                 # pre-pass instead of once per column tile and wave pair inside the GEMM's A prologue
                 G.stylize(h, [sa_seg], D, M, self.abf)

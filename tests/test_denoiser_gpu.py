@@ -144,3 +144,28 @@ def test_sample_loop_graph_matches_eager_and_oracle(rg, setup):
     e = relerr(xe.cpu()[:, KEEP], ref[:, KEEP])
     print("50-step loop rel err vs fp32 oracle %.3e" % e)
     assert e <= 2e-2
+
+
+def test_fused_self_attention_stylization_matches_separate_kernels(rg, monkeypatch):
+    """RG_SA_FUSED=1 routes the self-attention block through rg_sa_stylize (16-wave kernel, V as bf16 from the
+    QKV GEMM's split output); it must agree with the default sa_attention + stylize path to bf16 accuracy."""
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    sch = rg.schedule.Schedule()
+    W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, sch, "cuda", precision="bf16")
+    B = 3
+    g = np.random.Generator(np.random.PCG64(3))
+    x = torch.from_numpy(g.standard_normal((B, 43, 512)).astype(np.float32)).cuda()
+    d = rg.synth.synth_batch(B, seed=1)
+    mask = torch.ones(B, 43)
+    mask[:, [10, 21, 32]] = 0
+    mask[1, 7:10] = 0
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RG_SA_FUSED", flag)
+        sess = rg.denoiser.DenoiserSession(W, B)
+        assert (sess.v_sa is not None) == (flag == "1")
+        sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, None)
+        outs.append(sess.forward(x, 17).clone())
+    e = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
+    print("fused vs separate self-attention path: rel diff %.3e" % e)
+    assert e <= 5e-3
