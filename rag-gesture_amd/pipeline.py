@@ -13,9 +13,9 @@ HIP extension; there is no CPU fallback.
 Differences that are deliberate and documented in DESIGN.md:
   * exemplar DDIM inversions run batched (the reference loops at batch 1);
   * clips are independent between VAE encode and VAE decode, and at 43 latent tokens per clip a
-    single kernel chain cannot fill 256 CUs (every kernel is latency-, not throughput-bound): the
-    batch is cut into `lanes` groups of clips, each with its own HIP stream, denoiser session and
-    captured graphs (inversion -> splice -> sampling), which the hardware queues run concurrently;
+    single kernel chain cannot fill 256 CUs (most kernels are latency-, not throughput-bound): the
+    batch is cut into `lanes` groups of clips, each with its own HIP stream (checked to sit on its own
+    hardware queue), denoiser session and captured graphs (inversion -> splice -> sampling);
   * randomness: by default torch's generator on the device; `inference_kwargs["noise_tape"]`
     (an object with draw(shape)) replays explicit noise in the reference's consumption order
      for parity tests.
@@ -131,7 +131,9 @@ class MotionDiffusion:
         self._graphs = {}
         self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
         self.profile_phases, self.phase_ms = False, {}
-        self.lanes = int(os.environ.get("RG_LANES", "1"))  # concurrent clip groups (streams) per forward
+        # concurrent clip groups per forward, each on its own hardware queue (measured on MI355X: 2 lanes
+        # 149.7 vs 156 ms guided B=16, 71.3 vs 73.0 ms base B=32; 3-4 lanes no better)
+        self.lanes = int(os.environ.get("RG_LANES", "2"))
         self._lane_streams = []
 
     # ------------------------------------------------------------------ weights
@@ -206,9 +208,47 @@ class MotionDiffusion:
             self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B)
         return self._sessions[key]
 
+    def _concurrent_streams(self, n):
+        """n HIP streams that really run concurrently.  ROCm multiplexes streams onto a few hardware queues
+        (4 by default) and two streams on the same queue serialise -- observed for the first two side streams of
+        a process, which made `lanes` a pure loss.  Candidates are therefore checked pairwise with a short spin
+        kernel on each (concurrent: ~1x the spin time, same queue: ~2x) and a mutually concurrent set is kept."""
+        spin = 2_000_000  # cycles (~1 ms): long against launch latency, short against anything else
+
+        def together(a, b):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for st in (a, b):
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(spin)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        def alone(a):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(a):
+                torch.cuda._sleep(spin)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        cands = [torch.cuda.Stream(device=self.device) for _ in range(4 * n + 4)]
+        alone(cands[0])  # warm-up
+        base = min(alone(cands[0]) for _ in range(3))
+        chosen = [cands[0]]
+        for c in cands[1:]:
+            if len(chosen) == n:
+                break
+            if all(min(together(c, o) for _ in range(2)) < 1.5 * base for o in chosen):
+                chosen.append(c)
+        return chosen  # fewer than n if the runtime offers fewer independent queues
+
     def _lane_plan(self, B):
         """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips."""
         n = max(1, min(int(self.lanes), B))
+        if n > 1 and len(self._lane_streams) < n:
+            self._lane_streams = self._concurrent_streams(n)
+            n = min(n, len(self._lane_streams))
         while len(self._lane_streams) < n:
             self._lane_streams.append(torch.cuda.Stream(device=self.device))
         cuts = [(B * i) // n for i in range(n + 1)]
