@@ -289,13 +289,8 @@ class MotionDiffusion:
         D = gre.vae_latent_dim
         eps_list = [tape.draw((B * 10, 1, D)) for _ in range(4)]
         f = lambda t: t.to(dev).float().contiguous()
-        with self._phase("vae_encode"):
-            motion, tr_rel = gre.encode_device_graphed(
-                f(kwargs["motion_upper"]), f(kwargs["motion_lower"]), f(kwargs["motion_face"]), f(kwargs["motion_hands"]),
-                f(kwargs["trans"]), f(kwargs["facial"]), f(kwargs["contact"]), [f(e) for e in eps_list])
-        kwargs["trans"].copy_(tr_rel.to(kwargs["trans"].device))  # the reference's in-place re-zeroing
         motion_mask = gre.latent_mask(kwargs["motion_mask"].float())
-        T = motion.shape[1]
+        T = motion_mask.shape[1]
         n_lat = (T - 3) // 4
         up_i, ha_i, fa_i, lt_i = (list(range(0, n_lat)), list(range(n_lat + 1, 2 * n_lat + 1)),
                                   list(range(2 * n_lat + 2, 3 * n_lat + 2)), list(range(3 * n_lat + 3, T)))
@@ -305,8 +300,8 @@ class MotionDiffusion:
         qmask[:, [(T - 3) // 4, 2 * (T - 3) // 4, 3 * (T - 3) // 4]] = 0
         query_masks = {c: qmask for c in denoiser.CONDS}
 
-        kwargs.update({"motion_mask": motion_mask, "text": kwargs["word"], "raw_text": kwargs.get("raw_word"),
-                       "text_times": kwargs.get("text_segments")})
+        # the conditioning projections (K/V of every layer) need the inputs only: they run on the lane streams
+        # while the main stream encodes the motion
         plan = self._lane_plan(B)
         main = torch.cuda.current_stream()
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
@@ -316,12 +311,41 @@ class MotionDiffusion:
                 with torch.cuda.stream(stream):
                     self._session(b1 - b0, "sample", lane).set_conditions(
                         word[b0:b1], audio[b0:b1], spk[b0:b1], motion_mask[b0:b1], {c: qmask[b0:b1] for c in denoiser.CONDS})
+        with self._phase("vae_encode"):
+            motion, tr_rel = gre.encode_device_graphed(
+                f(kwargs["motion_upper"]), f(kwargs["motion_lower"]), f(kwargs["motion_face"]), f(kwargs["motion_hands"]),
+                f(kwargs["trans"]), f(kwargs["facial"]), f(kwargs["contact"]), [f(e) for e in eps_list])
+        kwargs["trans"].copy_(tr_rel.to(kwargs["trans"].device))  # the reference's in-place re-zeroing
+        assert motion.shape[1] == T
+        kwargs.update({"motion_mask": motion_mask, "text": kwargs["word"], "raw_text": kwargs.get("raw_word"),
+                       "text_times": kwargs.get("text_segments")})
         retrieval_dict = kwargs.get("re_dict")
+        early_cond = {}   # lane -> number of exemplars whose conditions were already projected
+
+        def exemplar_conditions_early(ex, recs):
+            """Called by RetrievalDatabase.forward once the exemplars are known, before it VAE-encodes them: their
+            K/V projections (text / audio / speaker of the retrieved samples) go to the lane streams meanwhile."""
+            if not use_inversion or getattr(self, "profile_phases", False):
+                return
+            for lane, stream, b0, b1 in plan:
+                sel = [e for e, (b, _, _, placed) in enumerate(ex) if placed is not None and b0 <= b < b1]
+                if not sel:
+                    continue
+                stream.wait_stream(main)
+                with torch.cuda.stream(stream):
+                    st = lambda k: torch.stack([recs[e][k] for e in sel]).to(dev)
+                    esess = self._session(len(sel), "invert", lane)
+                    eqm = {c: torch.stack([qmask[ex[e][0]] for e in sel]) for c in denoiser.CONDS}
+                    esess.set_conditions(st("word").float(), st("audio").float(), st("speaker_id"),
+                                         gre.latent_mask(st("motion_mask").float()), eqm)
+                early_cond[lane] = len(sel)
+
         if retrieval_dict is None and self.model.database is not None:
             with self._phase("retrieval"):
                 retrieval_dict = self.model.database(kwargs, kwargs.get("motion_length"), dev, idx=kwargs.get("sample_name"),
                                                      retrieval_method=kwargs.get("retrieval_method", "discourse"),
-                                                     gesture_rep_encoder=gre, noise=tape)
+                                                     gesture_rep_encoder=gre, noise=tape,
+                                                     on_exemplars=exemplar_conditions_early)
         results = kwargs
         results["retrieval_dict"] = copy.copy(retrieval_dict)
 
@@ -382,9 +406,10 @@ class MotionDiffusion:
                         cat = lambda key: torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0)
                         esess = self._session(E, "invert", lane)
                         with self._phase("exemplar_conditions"):
-                            eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
-                            esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
-                                                 cat("retr_motion_mask").float(), eqm)
+                            if early_cond.get(lane) != E:   # not already projected while the exemplars were encoded
+                                eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
+                                esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
+                                                     cat("retr_motion_mask").float(), eqm)
                             x_e = cat("retr_motion_latent").float().contiguous()
                         with self._phase("inversion"):
                             (inv,) = self._graph_run(("invert", E, lane), dict(x=x_e), lambda s, esess=esess, E=E: (

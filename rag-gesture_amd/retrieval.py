@@ -393,7 +393,7 @@ class RetrievalDatabase:
         self._t_last = now
 
     def forward(self, conditions, lengths, device, idx=None, retrieval_method="gesture_type", gesture_rep_encoder=None,
-                noise=None):
+                noise=None, on_exemplars=None):
         """conditions: the model's kwargs dict (text_features, discourse, prominence, speaker_ids, ...)."""
         gre = gesture_rep_encoder
         dev = torch.device(device)
@@ -434,6 +434,10 @@ class RetrievalDatabase:
         tick("retrieval.search")
         # ---- fetch + VAE-encode every visited exemplar in one batch (noise in the reference's order)
         recs = [self.dataset[name] for _, _, name, _ in ex]
+        if on_exemplars is not None and ex:
+            # the caller may start work that needs the exemplars' conditioning only (their K/V projections)
+            # on other streams while this stream VAE-encodes their motion
+            on_exemplars(ex, recs)
         lat = None
         if ex:
             E = len(ex)
