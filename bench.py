@@ -142,6 +142,10 @@ def main():
     value = world * B * 150 * args.steps / dt
 
     if args.phases and rank == 0:
+        # phase walls need device syncs at phase boundaries, which serialise concurrent lanes: the breakdown is taken
+        # on a single lane (one warm-up step captures its graphs), the timed run above used model.lanes lanes
+        lanes_prod, model.lanes = model.lanes, 1
+        one_step()
         model.profile_phases, model.phase_ms = True, {}
         if guided:
             model.model.database.phase_ms = model.phase_ms
@@ -150,25 +154,32 @@ def main():
         model.profile_phases = False
         if guided:
             model.model.database.phase_ms = None
-        print("phase breakdown (ms, one synchronised step): " +
+        model.lanes = lanes_prod
+        print("phase breakdown (ms, one synchronised single-lane step; the timed run used %d lanes): " % lanes_prod +
               ", ".join("%s %.1f" % kv for kv in model.phase_ms.items()), file=sys.stderr)
 
     # ---- roofline of the dominant kernel (HIP events around every rg_gemm launch, one extra step)
     roofline = None
     if rank == 0:
         h = rg.capi.get_handle(local_rank)
-        model.use_graphs = False  # HIP events cannot be recorded inside graph replays: same launches, eager
-        one_step()
-        torch.cuda.synchronize()
-        h.lib.rg_profile_begin(h._h)
-        one_step()
-        model.use_graphs = True
-        n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-        # variant 1 = bf16-A GEMMs (gemm_dma_kernel<true,...> / gemm_bf16_big_kernel): every per-step denoiser
-        # GEMM and ~2/3 of the GPU time of a step
-        h.lib.rg_profile_end(h._h, 1, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
-        ach = fl.value / (ms.value * 1e-3) if ms.value > 0 else 0.0
-        # HBM-side bytes per launch from the committed PMC passes over the same kernels and shapes
+
+        def gemm_events():
+            """HIP events around every rg_gemm launch of one eager step (graph replays cannot hold events; the
+            launches are the same).  Returns (launches, total ms, total flops) of the bf16-A GEMMs = variant 1
+            (gemm_dma_kernel<true,...> / gemm_bf16_big_kernel: every per-step denoiser GEMM, ~2/3 of the GPU time)."""
+            model.use_graphs = False
+            one_step()
+            torch.cuda.synchronize()
+            h.lib.rg_profile_begin(h._h)
+            one_step()
+            model.use_graphs = True
+            n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            h.lib.rg_profile_end(h._h, 1, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+            return n.value, ms.value, fl.value
+
+        n, ms, fl = gemm_events()
+        ach = fl / (ms * 1e-3) if ms > 0 else 0.0
+        # HBM-side bytes per launch from the committed PMC passes over the same kernels
         # (profiles/r01e_pmc_gemm_traffic.txt explains how they were collected and corrected); null if absent
         traffic = None
         try:
@@ -179,9 +190,20 @@ def main():
             pass
         roofline = {"bound": "mfma", "kernel": "rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)",
                     "achieved": round(ach / 1e12, 3), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK, 5), "traffic": traffic, "launches": n.value,
-                    "avg_launch_us": round(ms.value * 1e3 / max(1, n.value), 2),
-                    "flops_per_launch_avg": round(fl.value / max(1, n.value))}
+                    "frac": round(ach / MFMA_BF16_PEAK, 5), "traffic": traffic, "launches": n,
+                    "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "flops_per_launch_avg": round(fl / max(1, n)),
+                    "lanes": model.lanes}
+        if model.lanes > 1:
+            # The timed run cuts the batch into concurrent lanes: its launches are 1/lanes of the batch each and
+            # overlap in time, so the per-launch figure above understates what the chip does.  The same kernels on
+            # one lane (whole batch per launch; the shapes of the PMC passes and of profiles/r01f_*):
+            lanes_prod, model.lanes = model.lanes, 1
+            n1, ms1, fl1 = gemm_events()
+            model.lanes = lanes_prod
+            a1 = fl1 / (ms1 * 1e-3) if ms1 > 0 else 0.0
+            roofline["single_lane"] = {"achieved": round(a1 / 1e12, 3), "frac": round(a1 / MFMA_BF16_PEAK, 5), "launches": n1,
+                                       "avg_launch_us": round(ms1 * 1e3 / max(1, n1), 2),
+                                       "flops_per_launch_avg": round(fl1 / max(1, n1))}
     if dist is not None:
         dist.barrier()
 
