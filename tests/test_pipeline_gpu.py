@@ -204,3 +204,27 @@ def test_outpaint_vs_oracle(rg, models, precision):
     e = relerr(out["prev_latentout"].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP])
     print("outpaint", precision, "final latent rel err %.3e" % e)
     assert e <= (1e-2 if precision == "fp32" else 3e-2)
+
+
+@pytest.mark.parametrize("rtag,ikw,need_re", RUNS[:2])
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_full_depth_end_to_end_vs_reference_golden(rg, golden_dir, rtag, ikw, need_re, precision):
+    """The configuration of the released model: 8 denoiser layers, encoder_decoder VAE stacks (29 blocks),
+    base and guided runs against the real reference's outputs (tests/golden/e2e_L8_encdec.npz, batch of one)."""
+    cfg = rg.synth.default_model_cfg(num_layers=8)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="encoder_decoder", num_layers=4, ff_size=512)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs), database=None, precision=precision)
+    model.load_state_dict({"model." + k: v for k, v in rg.synth.synth_full_state(0, cfg, vae_cfgs).items()})
+    g = np.load(os.path.join(golden_dir, "e2e_L8_encdec.npz"))
+    data = rg.synth.synth_batch(1, seed=4321)
+    if need_re:
+        data["re_dict"] = opipe.synthetic_re_dict(1, seed=77)
+    out = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=rg.synth.NoiseTape(2024))))
+    torch.cuda.synchronize()
+    lat, ref = out["prev_latentout"].cpu(), torch.from_numpy(g["%s_prev_latentout" % rtag])
+    e = relerr(lat[:, KEEP], ref[:, KEEP])
+    et = relerr(out["pred_transl"].cpu(), torch.from_numpy(g["%s_pred_transl" % rtag]))
+    eu = rot_relerr(out["pred_upper"].cpu(), torch.from_numpy(g["%s_pred_upper" % rtag]))
+    print("L8 encdec", rtag, precision, "latent %.3e transl %.3e upper(rot) %.3e" % (e, et, eu))
+    assert e <= (1e-2 if precision == "fp32" else 3e-2)
+    assert et <= 5e-2 and eu <= 5e-2
