@@ -134,7 +134,7 @@ class MotionDiffusion:
         # concurrent clip groups per forward, each on its own hardware queue (measured on MI355X: 2 lanes
         # 149.7 vs 156 ms guided B=16, 71.3 vs 73.0 ms base B=32; 3-4 lanes no better)
         self.lanes = int(os.environ.get("RG_LANES", "2"))
-        self._lane_streams = []
+        self._lane_streams, self._search_stream = [], None
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -235,20 +235,23 @@ class MotionDiffusion:
         cands = [torch.cuda.Stream(device=self.device) for _ in range(4 * n + 4)]
         alone(cands[0])  # warm-up
         base = min(alone(cands[0]) for _ in range(3))
-        chosen = [cands[0]]
-        for c in cands[1:]:
+        fixed = [torch.cuda.current_stream()]   # the caller's stream keeps working beside the lanes
+        chosen = []
+        for c in cands:
             if len(chosen) == n:
                 break
-            if all(min(together(c, o) for _ in range(2)) < 1.5 * base for o in chosen):
+            if all(min(together(c, o) for _ in range(2)) < 1.5 * base for o in fixed + chosen):
                 chosen.append(c)
         return chosen  # fewer than n if the runtime offers fewer independent queues
 
     def _lane_plan(self, B):
         """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips."""
         n = max(1, min(int(self.lanes), B))
-        if n > 1 and len(self._lane_streams) < n:
-            self._lane_streams = self._concurrent_streams(n)
-            n = min(n, len(self._lane_streams))
+        if len(self._lane_streams) < n:
+            # n lane streams + one more for the retrieval search, all on hardware queues of their own
+            found = self._concurrent_streams(n + 1)
+            self._lane_streams, self._search_stream = found[:n], (found[n] if len(found) > n else None)
+            n = max(1, min(n, len(self._lane_streams)))
         while len(self._lane_streams) < n:
             self._lane_streams.append(torch.cuda.Stream(device=self.device))
         cuts = [(B * i) // n for i in range(n + 1)]
@@ -285,6 +288,8 @@ class MotionDiffusion:
             assert use_inversion
 
         gre = self.model.gesture_rep_encoder
+        ev_inputs = torch.cuda.Event()
+        ev_inputs.record(torch.cuda.current_stream())   # everything the caller queued for the inputs
         B = kwargs["motion_upper"].shape[0]
         D = gre.vae_latent_dim
         eps_list = [tape.draw((B * 10, 1, D)) for _ in range(4)]
@@ -345,7 +350,9 @@ class MotionDiffusion:
                 retrieval_dict = self.model.database(kwargs, kwargs.get("motion_length"), dev, idx=kwargs.get("sample_name"),
                                                      retrieval_method=kwargs.get("retrieval_method", "discourse"),
                                                      gesture_rep_encoder=gre, noise=tape,
-                                                     on_exemplars=exemplar_conditions_early)
+                                                     on_exemplars=exemplar_conditions_early,
+                                                     search_stream=None if getattr(self, "profile_phases", False)
+                                                     else self._search_stream, inputs_ready=ev_inputs)
         results = kwargs
         results["retrieval_dict"] = copy.copy(retrieval_dict)
 

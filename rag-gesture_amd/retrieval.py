@@ -393,7 +393,7 @@ class RetrievalDatabase:
         self._t_last = now
 
     def forward(self, conditions, lengths, device, idx=None, retrieval_method="gesture_type", gesture_rep_encoder=None,
-                noise=None, on_exemplars=None):
+                noise=None, on_exemplars=None, search_stream=None, inputs_ready=None):
         """conditions: the model's kwargs dict (text_features, discourse, prominence, speaker_ids, ...)."""
         gre = gesture_rep_encoder
         dev = torch.device(device)
@@ -402,35 +402,43 @@ class RetrievalDatabase:
         T, D = 4 * L + 3, self.latent_dim
         tick = self._tick
         tick(None)
-        plans, ex = [], []
-        spks = [int(v) for v in conditions["speaker_ids"][:, 0].tolist()]
-        # every clip's DB sweeps are launched before the first host read-back: one synchronisation per batch
-        pending, queries = {}, []
-        if retrieval_method == "discourse":
+        # The DB sweeps, their read-back and the host-side ranking walk only need the query annotations: on a
+        # stream of their own (search_stream, waiting for `inputs_ready` only) they do not queue behind the
+        # caller's pending work on the current stream (the batch VAE encode), and the walk overlaps with it.
+        import contextlib
+        ctx = torch.cuda.stream(search_stream) if search_stream is not None else contextlib.nullcontext()
+        if search_stream is not None and inputs_ready is not None:
+            search_stream.wait_event(inputs_ready)
+        with ctx:
+            plans, ex = [], []
+            spks = [int(v) for v in conditions["speaker_ids"][:, 0].tolist()]
+            # every clip's DB sweeps are launched before the first host read-back: one synchronisation per batch
+            pending, queries = {}, []
+            if retrieval_method == "discourse":
+                for b in range(B):
+                    key = idx[b] if idx is not None else None
+                    if key is not None and key in self.test_indexes and retrieval_method in self.test_indexes[key]:
+                        continue
+                    qs = discourse_queries(conditions["discourse"][b], conditions["prominence"][b], spks[b])
+                    pending[b] = (len(queries), len(qs))
+                    queries += qs
+            swept = self.index.collect(self.index.sweep_async(queries)) if queries else []
+            # tie-break similarities of all clips: launched back to back, one read-back
+            order_b = sorted(pending)
+            begun = [discourse_retrieval_begin(self.index, conditions["discourse"][b], conditions["prominence"][b], spks[b],
+                                               conditions["text_features"][b],
+                                               swept[pending[b][0]:pending[b][0] + pending[b][1]]) for b in order_b]
+            sims = fetch_sims(begun)
+            ready = {b: discourse_retrieval_finish(self.index, p, sm) for b, p, sm in zip(order_b, begun, sims)}
             for b in range(B):
-                key = idx[b] if idx is not None else None
-                if key is not None and key in self.test_indexes and retrieval_method in self.test_indexes[key]:
-                    continue
-                qs = discourse_queries(conditions["discourse"][b], conditions["prominence"][b], spks[b])
-                pending[b] = (len(queries), len(qs))
-                queries += qs
-        swept = self.index.collect(self.index.sweep_async(queries)) if queries else []
-        # tie-break similarities of all clips: launched back to back, one read-back
-        order_b = sorted(pending)
-        begun = [discourse_retrieval_begin(self.index, conditions["discourse"][b], conditions["prominence"][b], spks[b],
-                                           conditions["text_features"][b],
-                                           swept[pending[b][0]:pending[b][0] + pending[b][1]]) for b in order_b]
-        sims = fetch_sims(begun)
-        ready = {b: discourse_retrieval_finish(self.index, p, sm) for b, p, sm in zip(order_b, begun, sims)}
-        for b in range(B):
-            spk = spks[b]
-            ri, rb, qb = self.retrieve(retrieval_method, conditions["text_features"][b], conditions["discourse"][b],
-                                       conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None,
-                                       ready=ready.get(b))
-            plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
-            plans.append((plan, rb, qb))
-            for qp, name, placed in plan:
-                ex.append((b, qp, name, placed))
+                spk = spks[b]
+                ri, rb, qb = self.retrieve(retrieval_method, conditions["text_features"][b], conditions["discourse"][b],
+                                           conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None,
+                                           ready=ready.get(b))
+                plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
+                plans.append((plan, rb, qb))
+                for qp, name, placed in plan:
+                    ex.append((b, qp, name, placed))
         tick("retrieval.search")
         # ---- fetch + VAE-encode every visited exemplar in one batch (noise in the reference's order)
         recs = [self.dataset[name] for _, _, name, _ in ex]
