@@ -134,7 +134,7 @@ class MotionDiffusion:
         # concurrent clip groups per forward, each on its own hardware queue (measured on MI355X: 2 lanes
         # 149.7 vs 156 ms guided B=16, 71.3 vs 73.0 ms base B=32; 3-4 lanes no better)
         self.lanes = int(os.environ.get("RG_LANES", "2"))
-        self._lane_streams, self._search_stream = [], None
+        self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -246,14 +246,16 @@ class MotionDiffusion:
 
     def _lane_plan(self, B):
         """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips."""
-        n = max(1, min(int(self.lanes), B))
-        if len(self._lane_streams) < n:
-            # n lane streams + one more for the retrieval search, all on hardware queues of their own
-            found = self._concurrent_streams(n + 1)
-            self._lane_streams, self._search_stream = found[:n], (found[n] if len(found) > n else None)
-            n = max(1, min(n, len(self._lane_streams)))
-        while len(self._lane_streams) < n:
-            self._lane_streams.append(torch.cuda.Stream(device=self.device))
+        want = max(1, int(self.lanes))
+        if self._lanes_calibrated != want:
+            # `want` lane streams + one more for the retrieval search, all on hardware queues of their own (the
+            # runtime has 4 by default: the caller's stream, two lanes and the search stream use them up)
+            found = self._concurrent_streams(want + 1)
+            self._lane_streams, self._search_stream = found[:want], (found[want] if len(found) > want else None)
+            if not self._lane_streams:
+                self._lane_streams = [torch.cuda.Stream(device=self.device)]
+            self._lanes_calibrated = want
+        n = max(1, min(want, B, len(self._lane_streams)))
         cuts = [(B * i) // n for i in range(n + 1)]
         return [(i, self._lane_streams[i], cuts[i], cuts[i + 1]) for i in range(n)]
 
