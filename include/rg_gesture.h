@@ -37,6 +37,8 @@ int rg_version(void);
 int rg_create(rg_handle** out, int device);
 void rg_destroy(rg_handle* h);
 const char* rg_last_error(rg_handle* h);
+/* Compute units of the handle's device (tile-shape policies: one workgroup per CU while a launch fits). */
+int rg_num_cus(rg_handle* h);
 
 /* ---------------------------------------------------------------- sampler (elementwise)
  * DDIM update with x0-prediction, eta = 0:
@@ -149,6 +151,8 @@ typedef struct rg_gemm_desc {
   int split_col;          //   out = rstd * (A W'^T - mean * c1) + bias  ==  LN(x) W^T + b   (mean/rstd over K columns)
                           // split_col > 0 (multiple of 128): output columns >= split_col go ONLY to out2 (bf16, column
                           // index - split_col), columns below it only to out: a GEMM with an fp32 and a bf16 consumer
+  int tile_n;             // 0 / 128: default tile width; 64: 64x64 tiles (bf16 A, aligned shapes only): more, smaller
+  int pad4_;              //   workgroups for single-round GEMMs; stats_out then holds N/64 partials per row
 } rg_gemm_desc;
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);

@@ -20,3 +20,5 @@ extern "C" int rg_create(rg_handle** out, int device) {
 extern "C" void rg_destroy(rg_handle* h) { delete h; }
 
 extern "C" const char* rg_last_error(rg_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int rg_num_cus(rg_handle* h) { return h ? h->num_cus : 0; }

@@ -451,7 +451,11 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   const bool fast_ok = reg_fast_eligible(d), dma_ok = rg_gemm_dma_eligible(d);
   const bool big_ok = rg_gemm_big_eligible(d);
   const int big_bn = big_ok ? (path == 4 ? (d->N >= 256 ? 256 : 128) : (path == 0 ? rg_gemm_big_width(d, h->num_cus) : 0)) : 0;
-  if (big_bn) {
+  if (d->tile_n == 64) {
+    RG_REQUIRE(h, d->a_is_bf16 && !d->W_lo && dma_ok && d->N % 64 == 0 && d->split_col == 0,
+               "tile_n = 64 needs a bf16 A operand, aligned shapes and N % 64 == 0");
+    rg_gemm_dma_launch(d, h->num_cus, stream);
+  } else if (big_bn) {
     rg_gemm_big_launch(d, big_bn, stream);
   } else if (fast_ok && path == 3) {
     if (d->a_is_bf16) launch<true, false, true>(d, grid, rg_stream(stream));

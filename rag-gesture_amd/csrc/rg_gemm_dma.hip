@@ -50,18 +50,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 // exposed because nothing else can issue on the SIMD.  With 8 waves (2x4 over the 64x128 tile, 32x32
 // per wave) each SIMD holds two waves that cover each other's DMA issue and LDS waits; the epilogue
 // is still run by the first 256 threads (32 columns per thread).
-template <bool A_BF16, bool SPLIT, int NS, int NW>
+// BN_ = tile width: 128, or 64 for single-round N = 512 GEMMs at small M.  There a workgroup is alone on its CU
+// and pulls its weight panel from the Infinity Cache at the per-CU rate (~33 GB/s: every XCD sees a panel once,
+// L2 reuse is nil at 1-2 M-tiles per XCD); 64-wide tiles put twice as many CUs on the same bytes.
+template <bool A_BF16, bool SPLIT, int NS, int NW, int BN_ = BN>
 __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p) {
   constexpr int NTH = NW * 64;
   constexpr int WN = NW / 2;            // waves along N (2 along M)
-  constexpr int TN = 4 / (NW / 4);      // 16-column MFMA tiles per wave: 4 (NW=4) or 2 (NW=8)
-  constexpr int CPW = 16 / NW;          // 1-KiB DMA chunks of a 16-chunk operand tile per wave
+  constexpr int TN = (BN_ / WN) / 16;   // 16-column MFMA tiles per wave: 4 (NW=4) or 2 (NW=8) at BN_ = 128
+  constexpr int CPW = 16 / NW;          // 1-KiB DMA chunks of a 16-chunk fp32 A tile per wave
+  constexpr int W_TILE_ = BN_ * ROW_BYTES;
+  constexpr int CPW_W = (BN_ / 8) / NW; // 1-KiB chunks of the W tile per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int A_STAGE = A_BF16 ? A_TILE : 2 * A_TILE;           // fp32 tile = 16 KiB
   constexpr int W_PLANES = SPLIT ? 2 : 1;
-  constexpr int STAGE = A_STAGE + W_PLANES * W_TILE;
+  constexpr int STAGE = A_STAGE + W_PLANES * W_TILE_;
   constexpr int ACH = A_BF16 ? (NW == 4 ? 2 : 1) : CPW;        // A chunks per wave
-  constexpr int PER_TILE = ACH + CPW * W_PLANES;                   // DMA instructions per wave per K-tile
+  constexpr int PER_TILE = ACH + CPW_W * W_PLANES;                 // DMA instructions per wave per K-tile
   float* sPar = reinterpret_cast<float*>(smem + NS * STAGE);     // [nseg][4][SEG_MAX]
   float* sRow = sPar + (A_BF16 ? 0 : p.nseg) * 4 * SEG_MAX;      // [RG_MAX_SEG][64][2] = (rstd, -mean*rstd)
   SegInfo* sSeg = reinterpret_cast<SegInfo*>(sRow + RG_MAX_SEG * BM * 2);
@@ -72,10 +77,10 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WN, wc = wave % WN;
-  const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
+  const int mt = (p.M + BM - 1) / BM, nt = (p.N + BN_ - 1) / BN_;
   int tile_m, tile_n;
   tile_of_block(blockIdx.x, mt, nt, tile_m, tile_n);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN_;
   const int nk = p.K / BK;
 
   auto a_row = [&](int r) {
@@ -87,9 +92,9 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
   // ---- per-lane DMA source rows (fixed for the whole kernel)
   // W: 16 chunks of 1 KiB (8 rows x 128 B); wave w issues chunks w, w+4, w+8, w+12.
   //    lane -> row = 8c + (lane>>3), physical 16-B slot lane&7 holds logical chunk slot ^ ((row>>1)&7)
-  unsigned w_off[CPW];
+  unsigned w_off[CPW_W];
 #pragma unroll
-  for (int i = 0; i < CPW; ++i) {
+  for (int i = 0; i < CPW_W; ++i) {
     const int row = (wave + NW * i) * 8 + (lane >> 3);
     const int lc = (lane & 7) ^ ((row >> 1) & 7);
     w_off[i] = (unsigned)(n0 + row) * (unsigned)p.ldw + lc * 8;   // bf16 elements; + kt*64 per tile
@@ -136,19 +141,19 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
                                          (lds_void*)(st + (wave + NW * i) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) {
+    for (int i = 0; i < CPW_W; ++i) {
       __builtin_amdgcn_global_load_lds((const void*)(Wb + (size_t)w_off[i] + k0),
                                        (lds_void*)(st + A_STAGE + (wave + NW * i) * 1024), 16, 0, 0);
       if constexpr (SPLIT)
         __builtin_amdgcn_global_load_lds((const void*)(Wl + (size_t)w_off[i] + k0),
-                                         (lds_void*)(st + A_STAGE + W_TILE + (wave + NW * i) * 1024), 16, 0, 0);
+                                         (lds_void*)(st + A_STAGE + W_TILE_ + (wave + NW * i) * 1024), 16, 0, 0);
     }
   };
 
   // residual values for the epilogue and the first operand tiles are requested up front: their
   // latency overlaps the table setup and the K loop instead of adding to it
   ResidualPrefetch pre;
-  if (tid < NT) prefetch_residual(p, tid, m0, n0, pre);
+  if (tid < NT) prefetch_residual(p, tid, m0, n0, pre, BN_);
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
     if (t < nk) issue(t, true);
@@ -209,7 +214,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
   auto compute = [&](int kt) {
     const unsigned char* st = smem + (kt % NS) * STAGE;
     const unsigned char* sW = st + A_STAGE;
-    const unsigned char* sWl = sW + W_TILE;
+    const unsigned char* sWl = sW + W_TILE_;
     int sidx = 0, ks0 = 0;
     if constexpr (!A_BF16) {
       sidx = (kt * BK) / p.seg_len;
@@ -331,7 +336,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
         sC[(wr * 32 + i * 16 + fq * 4 + e) * SC_LD + wc * (TN * 16) + j * 16 + frow] = acc[i][j][e];
   __syncthreads();
   RG_STAMP(61);
-  if (tid < NT) epilogue(p, sC, tid, m0, n0, tile_n, nt, &pre);
+  if (tid < NT) epilogue(p, sC, tid, m0, n0, tile_n, nt, &pre, BN_);
   RG_STAMP(62);
 }
 
@@ -355,6 +360,21 @@ void dma_launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
   }
   const size_t lds = dma_lds_bytes<A_BF16, SPLIT>(d->nseg, NS);
   hipLaunchKernelGGL((gemm_dma_kernel<A_BF16, SPLIT, NS, NW>), grid, dim3(NW * 64), lds, s, *d);
+}
+
+// 64x64 tiles, bf16 A, 4 waves (2x2, 32x32 each), 4-stage ring of 16 KiB; the epilogue tile keeps its 128-column stride
+void dma_launch_narrow(const rg_gemm_desc* d, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, 4, 4, 64>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    attr = true;
+  }
+  size_t lds = (size_t)4 * (A_TILE + 64 * ROW_BYTES);
+  const size_t epi = (size_t)BM * SC_LD * sizeof(float);
+  if (epi > lds) lds = epi;
+  const int mt = (d->M + BM - 1) / BM, nt = (d->N + 63) / 64;
+  hipLaunchKernelGGL((gemm_dma_kernel<true, false, 4, 4, 64>), dim3(mt * nt), dim3(256), lds, s, *d);
 }
 
 // ring depth for this descriptor (0: does not fit the 160 KiB LDS at all).  Grids with more
@@ -391,6 +411,10 @@ bool rg_gemm_dma_eligible(const rg_gemm_desc* d) {
 int g_dma_waves = 0;   // tuning knob (rg_set_gemm_waves): 0 = auto, or force 4 / 8 waves per workgroup
 
 void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream) {
+  if (d->tile_n == 64) {
+    dma_launch_narrow(d, rg_stream(stream));
+    return;
+  }
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + BN - 1) / BN;
   dim3 grid(mt * nt);
   const int ns = dma_depth(d, num_cus);

@@ -59,10 +59,11 @@ struct ResidualPrefetch {
   float r[32];
 };
 
-__device__ __forceinline__ void prefetch_residual(const rg_gemm_desc& p, int tid, int m0, int n0, ResidualPrefetch& pre) {
+__device__ __forceinline__ void prefetch_residual(const rg_gemm_desc& p, int tid, int m0, int n0, ResidualPrefetch& pre,
+                                                  int width = BN) {
   const int grow = m0 + (tid >> 2), gcol = n0 + (tid & 3) * 32;
   pre.valid = false;
-  if (p.residual && grow < p.M && gcol + 32 <= p.N && (p.ldr & 3) == 0) {
+  if (p.residual && grow < p.M && gcol + 32 <= p.N && gcol + 32 <= n0 + width && (p.ldr & 3) == 0) {
     const float* rp = p.residual + (size_t)grow * p.ldr + gcol;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -73,20 +74,23 @@ __device__ __forceinline__ void prefetch_residual(const rg_gemm_desc& p, int tid
   }
 }
 
+// `width` = columns of sC that belong to this tile (128, or 64 for the narrow-tile kernel: the threads of the
+// upper two column groups then only take part in the shuffles); nt / tile_n count tiles of that width.
 __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC, int tid, int m0, int n0, int tile_n,
-                                         int nt, const ResidualPrefetch* pre = nullptr) {
+                                         int nt, const ResidualPrefetch* pre = nullptr, int width = BN) {
   const int erow = tid >> 2;           // 0..63
   const int ecol = (tid & 3) * 32;     // 0,32,64,96 : one 32-column head per thread
   const int grow = m0 + erow;
   const int gcol = n0 + ecol;
   const bool row_ok = grow < p.M;
+  const int Nlim = min(p.N, n0 + width);   // first column that is not this tile's
   float v[32];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const float4 t = *reinterpret_cast<const float4*>(sC + erow * SC_LD + ecol + 4 * q);
     v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
   }
-  const bool full = (gcol + 32 <= p.N);
+  const bool full = (gcol + 32 <= Nlim);
   if (p.ln_stats) {   // LayerNorm of the A rows, folded: rstd * (acc - mean * c1[n]); the bias below carries beta
     const float* sp = p.ln_stats + (size_t)(row_ok ? grow : 0) * p.ln_nparts * 2;
     float su = 0.f, sq = 0.f;
@@ -101,7 +105,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
     const float rs = rsqrtf(var + 1e-5f);
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
-      const float c1 = (gcol + e < p.N) ? p.ln_c1[gcol + e] : 0.f;
+      const float c1 = (gcol + e < Nlim) ? p.ln_c1[gcol + e] : 0.f;
       v[e] = rs * (v[e] - mu * c1);
     }
   }
@@ -114,13 +118,13 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 32; ++e) v[e] += (gcol + e < p.N) ? p.bias[gcol + e] : 0.f;
+      for (int e = 0; e < 32; ++e) v[e] += (gcol + e < Nlim) ? p.bias[gcol + e] : 0.f;
     }
   }
   if (p.tbias && row_ok) {
     const float* tb = p.tbias + (size_t)(grow % p.tb_period) * p.N + gcol;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) v[e] += (gcol + e < p.N) ? tb[e] : 0.f;
+    for (int e = 0; e < 32; ++e) v[e] += (gcol + e < Nlim) ? tb[e] : 0.f;
   }
   if (gcol < p.softmax_cols) {  // this thread's 32 columns are exactly one head
     float mx = v[0];
@@ -153,14 +157,14 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 32; ++e) v[e] += (gcol + e < p.N) ? rp[e] : 0.f;
+      for (int e = 0; e < 32; ++e) v[e] += (gcol + e < Nlim) ? rp[e] : 0.f;
     }
   }
   if (p.stats_out) {
     float s = 0.f, ss = 0.f;
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
-      const float t = (gcol + e < p.N) ? v[e] : 0.f;
+      const float t = (gcol + e < Nlim) ? v[e] : 0.f;
       s += t; ss += t * t;
     }
     s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
@@ -175,7 +179,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
   // tile, so after a wave-level fence the wave streams them out with lanes running ALONG the row: every
   // wave-instruction writes whole contiguous rows (2 x 512 B fp32 or 4 x 256 B bf16) instead of 64
   // scattered 16-B pieces at a 128-B stride (measured 3 us -> 1 us per 64x128 tile).
-  const bool tile_full = (n0 + BN <= p.N);
+  const bool tile_full = (n0 + width <= p.N);
   // split output: this tile's columns go either to out (below split_col) or to out2 (bf16, from split_col on)
   const bool to_o2_only = p.split_col > 0 && n0 >= p.split_col;
   const bool want_main = !to_o2_only;
@@ -198,7 +202,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int r = wrow0 + 2 * i + rpar;
-        if (m0 + r < p.M)
+        if (m0 + r < p.M && c4 < width)
           *reinterpret_cast<float4*>(o + (size_t)(m0 + r) * p.ldo) = *reinterpret_cast<const float4*>(sC + r * SC_LD + c4);
       }
     }
@@ -207,7 +211,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = wrow0 + 4 * i + rq;
-        if (m0 + r < p.M) {
+        if (m0 + r < p.M && c8 < width) {
           const float4 x0 = *reinterpret_cast<const float4*>(sC + r * SC_LD + c8);
           const float4 x1 = *reinterpret_cast<const float4*>(sC + r * SC_LD + c8 + 4);
           const uint4 pk = make_uint4(pack2(x0.x, x0.y), pack2(x0.z, x0.w), pack2(x1.x, x1.y), pack2(x1.z, x1.w));
@@ -229,7 +233,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
                                                      pack2(v[8 * q + 4], v[8 * q + 5]), pack2(v[8 * q + 6], v[8 * q + 7]));
     } else {
 #pragma unroll
-      for (int e = 0; e < 32; ++e) if (gcol + e < p.N) o2[e] = f2bf(v[e]);
+      for (int e = 0; e < 32; ++e) if (gcol + e < Nlim) o2[e] = f2bf(v[e]);
     }
   }
   if (fast_f32 || fast_bf16 || !want_main) return;
@@ -242,7 +246,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
                                                     pack2(v[8 * q + 4], v[8 * q + 5]), pack2(v[8 * q + 6], v[8 * q + 7]));
     } else {
 #pragma unroll
-      for (int e = 0; e < 32; ++e) if (gcol + e < p.N) o[e] = f2bf(v[e]);
+      for (int e = 0; e < 32; ++e) if (gcol + e < Nlim) o[e] = f2bf(v[e]);
     }
   } else {
     float* o = reinterpret_cast<float*>(p.out) + (size_t)grow * p.ldo + gcol;
@@ -252,7 +256,7 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
         reinterpret_cast<float4*>(o)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 32; ++e) if (gcol + e < p.N) o[e] = v[e];
+      for (int e = 0; e < 32; ++e) if (gcol + e < Nlim) o[e] = v[e];
     }
   }
 }

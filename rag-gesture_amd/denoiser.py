@@ -204,12 +204,17 @@ class DenoiserSession:
         self.M = M = self.R * T
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
-        self.st_a, self.st_b, self.st_c = (f(M, D // G.STATS_COLS, 2) for _ in range(3))
+        # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide, or 64 wide
+        # where the producer runs 64x64 tiles, self.tn): allocated for the finer split, viewed per producer
+        self._st_a, self._st_b, self.st_c = f(M, D // 64, 2), f(M, D // 64, 2), f(M, D // G.STATS_COLS, 2)
+        parts128 = lambda t: t.view(-1)[:M * (D // G.STATS_COLS) * 2].view(M, D // G.STATS_COLS, 2)
+        self.st_a, self.st_b = parts128(self._st_a), parts128(self._st_b)
         self.qkv, self.q3 = f(M, 3 * D), f(M, 3 * D)
         self.y_sa, self.st_sa = f(M, D), f(M, D // 128, 2)
         self.y3, self.st3 = f(M, 3 * D), f(3, M, D // 128, 2)
         self.g = torch.empty(M, w.FF, device=dev, dtype=torch.bfloat16 if w.precision == "bf16" else torch.float32)
-        self.yf, self.st_f = f(M, D), f(M, D // G.STATS_COLS, 2)
+        self.yf, self._st_f = f(M, D), f(M, D // 64, 2)
+        self.st_f = parts128(self._st_f)
         self.head = f(M, D)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
         self.abf = self.xa_bf = self.v_sa = None
@@ -229,6 +234,14 @@ class DenoiserSession:
         self.a_pre_t = torch.empty(w.L, 3, B, w.H, 2, 32, 32, device=dev, dtype=torch.bfloat16)  # A^T as bf16 hi/lo
         self.src_mask = torch.ones(self.R, T, device=dev)
         self.qmask = torch.ones(3, self.R, T, device=dev)
+        # optional 64x64 GEMM tiles for the N = D launches while they still fit one round of workgroups (twice the
+        # CUs on the same weight bytes).  Measured: no gain (146.1 vs 143.2 ms guided, 71.6 vs 69.6 ms base): the
+        # fixed part of these launches, not the K loop, decides -- off unless RG_TILE64=1
+        self.tn = 0
+        if self.xa_bf is not None and os.environ.get("RG_TILE64", "0") == "1" and D % 64 == 0 and \
+                ((M + 63) // 64) * (D // 64) <= w.h.lib.rg_num_cus(w.h._h):
+            self.tn = 64
+            self.st_b, self.st_f = self._st_b, self._st_f
         ng = D // 128
         order = xcd_affine_order if os.environ.get("RG_XCD_AFFINE", "1") == "1" else \
             (lambda n, ipg, T_: np.arange(n * ipg, dtype=np.int32))
@@ -293,7 +306,9 @@ class DenoiserSession:
         [2B,T,D] (rows [0,B) conditional, [B,2B) classifier-free) in self.head."""
         w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
         xa, xb, xc = self.xa, self.xb, self.xc
-        sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c
+        sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c     # sa_: written by the embed GEMM (128-wide tiles)
+        sa_w = self._st_a if self.tn else self.st_a           # ... and by every FFN-out GEMM (self.tn-wide tiles)
+        tn = self.tn
         # h = joint_embed(x) + positional tables, duplicated for the two CFG branches
         G.gemm(h, M=M, N=D, K=D, W=w.w_embed, out=xa, segs=[G.Seg(x.view(B * T, D))], seg_len=D, a_row_mod=B * T,
                bias=w.b_embed, tbias=w.tbias, tb_period=T, stats_out=sa_, out2=self.xa_bf)
@@ -330,14 +345,14 @@ class DenoiserSession:
             sa_seg = G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"], scale_shift=ss[0])
             if fused_sa:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
-                       out2=self.hcat[:, 3 * D:])
+                       out2=self.hcat[:, 3 * D:], tile_n=tn)
             elif self.abf is not None:
                 # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
                 # pre-pass instead of once per column tile and wave pair inside the GEMM's A prologue
                 G.stylize(h, [sa_seg], D, M, self.abf)
                 # out2: bf16 copy of xb = 4th K-segment of the ca_mix GEMM's A operand
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
-                       out2=self.hcat[:, 3 * D:])
+                       out2=self.hcat[:, 3 * D:], tile_n=tn)
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, segs=[sa_seg], seg_len=D, bias=lw["b_sao"], residual=xa,
                        stats_out=sb_)
@@ -375,7 +390,7 @@ class DenoiserSession:
                     segs.append(G.Seg(xb))
                     # the SiLU prologue of the K = 2048 GEMM once per element instead of once per column tile
                     G.stylize(h, segs, D, M, self.hcat, m_cond=Mc, unc_nseg=3, unc_tab=lw["unc_tab"][step], qmask=self.qmask)
-                G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"], out2=self.abf)
+                G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"], out2=self.abf, tile_n=tn)
             else:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
                        segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
@@ -392,20 +407,22 @@ class DenoiserSession:
             else:
                 G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, segs=[G.Seg(xc)], seg_len=D, bias=lw["b_ff1"], act=1)
             if w.precision == "bf16":
-                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f)
+                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f,
+                       tile_n=tn)
             else:
                 G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, segs=[G.Seg(self.g)], seg_len=w.FF,
                        bias=lw["b_ff2"], stats_out=self.st_f)
             ff_seg = G.Seg(self.yf, mode=G.A_STYL, stats=self.st_f, gamma=lw["ff_sg"], beta=lw["ff_sb"], scale_shift=ss[4])
             if self.abf is not None:
                 G.stylize(h, [ff_seg], D, M, self.abf)
-                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_,
-                       out2=self.xa_bf)
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_w,
+                       out2=self.xa_bf, tile_n=tn)
+                sa_ = sa_w   # the next layer's QKV reads the statistics in this tile split
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, segs=[ff_seg], seg_len=D, bias=lw["b_ffo"], residual=xc,
                        stats_out=sa_)
         if self.xa_bf is not None:   # the last FFN-out epilogue left the bf16 copy of xa
-            G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, A=self.xa_bf, bias=w.b_out)
+            G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, A=self.xa_bf, bias=w.b_out, tile_n=tn)
         else:
             G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, segs=[G.Seg(xa)], seg_len=D, bias=w.b_out)
         return self.head

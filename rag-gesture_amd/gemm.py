@@ -25,10 +25,10 @@ class GemmDesc(ctypes.Structure):
                 ("bias", _vp), ("tbias", _vp), ("tb_period", ctypes.c_int), ("softmax_cols", ctypes.c_int),
                 ("residual", _vp), ("ldr", ctypes.c_int), ("out_bf16", ctypes.c_int), ("out", _vp),
                 ("ldo", ctypes.c_int), ("ldo2", ctypes.c_int), ("stats_out", _vp), ("W_lo", _vp), ("out2", _vp), ("ln_stats", _vp), ("ln_c1", _vp),
-                ("ln_nparts", ctypes.c_int), ("split_col", ctypes.c_int)]
+                ("ln_nparts", ctypes.c_int), ("split_col", ctypes.c_int), ("tile_n", ctypes.c_int), ("pad4_", ctypes.c_int)]
 
 
-assert ctypes.sizeof(ASegment) == 56 and ctypes.sizeof(GemmDesc) == 392
+assert ctypes.sizeof(ASegment) == 56 and ctypes.sizeof(GemmDesc) == 400
 
 
 def _p(t, dtype=None):
@@ -76,7 +76,7 @@ class Seg:
 
 def make_desc(*, M, N, K, W, out, A=None, segs=None, seg_len=None, bias=None, tbias=None, tb_period=0,
               residual=None, act=0, softmax_cols=0, stats_out=None, a_row_mod=0, gb_group=0, gb_stride=0,
-              ldo=None, ldr=None, out2=None, ln_stats=None, ln_c1=None, lda=None, split_col=0):
+              ldo=None, ldr=None, out2=None, ln_stats=None, ln_c1=None, lda=None, split_col=0, tile_n=0):
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     if A is not None:
@@ -112,6 +112,7 @@ def make_desc(*, M, N, K, W, out, A=None, segs=None, seg_len=None, bias=None, tb
     if ln_stats is not None:  # LayerNorm folded into the epilogue (A = bf16 copy of the un-normalised rows)
         d.ln_stats, d.ln_nparts, d.ln_c1 = _p(ln_stats, torch.float32), ln_stats.shape[-2], _p(ln_c1, torch.float32)
     d.split_col = split_col
+    d.tile_n = tile_n
     if out2 is not None:  # bf16 copy of the output for the next GEMM's A operand
         d.out2, d.ldo2 = _p(out2, torch.bfloat16), out2.stride(-2)
     return d

@@ -127,3 +127,27 @@ def test_styl_prologue_segments(rg, h):
            gb_group=512, gb_stride=512)
     ref3 = torch.cat([F.linear(bf(F.layer_norm(x, (D,), gam[c], bet[c])), bf(w3[c * D:(c + 1) * D])) for c in range(3)], -1)
     assert (out3.cpu() - ref3).abs().max() <= 3e-3
+
+
+@pytest.mark.parametrize("M,K", [(688, 512), (1376, 2048), (100, 1024)])
+def test_narrow_tiles_bf16_A_epilogue_features(rg, h, M, K):
+    """tile_n = 64 (64x64 tiles): bias, residual, partial statistics per 64 columns, bf16 copy, folded LayerNorm."""
+    G = rg.gemm
+    N = 512
+    a, w, b = _rand((M, K), 21), _rand((N, K), 22, 0.05), _rand((N,), 23)
+    res = _rand((M, N), 24)
+    out = torch.empty(M, N, device="cuda")
+    o2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    st = torch.zeros(M, N // 64, 2, device="cuda")
+    G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out, A=a.cuda().bfloat16(), bias=b.cuda(), residual=res.cuda(),
+           stats_out=st, out2=o2, tile_n=64)
+    ref = F.linear(bf(a), bf(w), b) + res
+    assert (out.cpu() - ref).abs().max() <= 3e-3 * max(1.0, ref.abs().max().item())
+    assert (o2.float().cpu() - out.cpu()).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item())
+    o = out.cpu().view(M, N // 64, 64)
+    assert (st.cpu()[..., 0] - o.sum(-1)).abs().max() <= 2e-3
+    assert (st.cpu()[..., 1] - (o * o).sum(-1)).abs().max() <= 2e-2
+    # same result as the default 64x128 tiles
+    out128 = torch.empty(M, N, device="cuda")
+    G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out128, A=a.cuda().bfloat16(), bias=b.cuda(), residual=res.cuda())
+    assert torch.equal(out128, out)
