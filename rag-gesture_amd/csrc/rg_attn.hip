@@ -501,20 +501,6 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
   if (s == 1) sg = a.seg[1];
   if (s == 2) sg = a.seg[2];
   if (s == 3) sg = a.seg[3];
-  float mu = 0.f, rs = 1.f;
-  if (sg.mode != RG_A_IDENT && !(row >= a.m_cond && s < a.unc_nseg)) {
-    const float* sp = sg.stats + (size_t)row * sg.nparts * 2;
-    float su = 0.f, sq = 0.f;
-    for (int q = 0; q < sg.nparts; ++q) {
-      su += sp[2 * q];
-      sq += sp[2 * q + 1];
-    }
-    const float inv = 1.0f / (float)a.seg_len;
-    mu = su * inv;
-    float var = sq * inv - mu * mu;
-    var = var < 0.f ? 0.f : var;
-    rs = rsqrtf(var + 1e-5f);
-  }
   unsigned short* dst = a.out + (size_t)row * a.ldo + s * a.seg_len;
   if (row >= a.m_cond && s < a.unc_nseg) {
     const int flag = (a.qmask && a.qmask[(size_t)s * a.M + row] == 0.f) ? 1 : 0;
@@ -523,19 +509,48 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
     return;
   }
   const float* src = sg.src + (size_t)row * sg.ld;
+  const bool norm = sg.mode != RG_A_IDENT, styl = sg.mode == RG_A_STYL;
+  float mu = 0.f, rs = 1.f;
+  bool have_stats = !norm;
   for (int k = lane * 8; k < a.seg_len; k += 512) {
+    // every load of the iteration is issued before the first value is needed: the row statistics (a second,
+    // dependent round trip otherwise) are requested together with the row itself
     const v4 x0 = *reinterpret_cast<const v4*>(src + k), x1 = *reinterpret_cast<const v4*>(src + k + 4);
+    v4 g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0, c0 = b0, c1 = b0, h0 = b0, h1 = b0;
+    if (norm) {
+      g0 = *reinterpret_cast<const v4*>(sg.gamma + k); g1 = *reinterpret_cast<const v4*>(sg.gamma + k + 4);
+      b0 = *reinterpret_cast<const v4*>(sg.beta + k); b1 = *reinterpret_cast<const v4*>(sg.beta + k + 4);
+    }
+    if (styl) {
+      c0 = *reinterpret_cast<const v4*>(sg.scale_shift + k); c1 = *reinterpret_cast<const v4*>(sg.scale_shift + k + 4);
+      h0 = *reinterpret_cast<const v4*>(sg.scale_shift + a.seg_len + k);
+      h1 = *reinterpret_cast<const v4*>(sg.scale_shift + a.seg_len + k + 4);
+    }
+    if (!have_stats) {
+      const float* sp = sg.stats + (size_t)row * sg.nparts * 2;
+      float su = 0.f, sq = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {   // nparts <= 8 (checked by the wrapper): all requests go out together
+        const float2 t = q < sg.nparts ? *reinterpret_cast<const float2*>(sp + 2 * q) : make_float2(0.f, 0.f);
+        su += t.x;
+        sq += t.y;
+      }
+      const float inv = 1.0f / (float)a.seg_len;
+      mu = su * inv;
+      float var = sq * inv - mu * mu;
+      var = var < 0.f ? 0.f : var;
+      rs = rsqrtf(var + 1e-5f);
+      have_stats = true;
+    }
     float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-    if (sg.mode != RG_A_IDENT) {
-      const v4 g0 = *reinterpret_cast<const v4*>(sg.gamma + k), g1 = *reinterpret_cast<const v4*>(sg.gamma + k + 4);
-      const v4 b0 = *reinterpret_cast<const v4*>(sg.beta + k), b1 = *reinterpret_cast<const v4*>(sg.beta + k + 4);
+    if (norm) {
       const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
       const float be[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (v[e] - mu) * rs * g[e] + be[e];
-      if (sg.mode == RG_A_STYL) {
-        const float* sc = sg.scale_shift + k;
-        const float* sh = sg.scale_shift + a.seg_len + k;
+      if (styl) {
+        const float sc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float t = v[e] * (1.0f + sc[e]) + sh[e];
@@ -1064,7 +1079,9 @@ extern "C" int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg,
   for (int s = 0; s < RG_MAX_SEG; ++s) a.seg[s] = segs_host[s < nseg ? s : 0];
   for (int s = 0; s < nseg; ++s) {
     RG_REQUIRE(h, a.seg[s].src && (a.seg[s].ld % 4) == 0, "segment source must be 16-B aligned rows");
-    if (a.seg[s].mode != RG_A_IDENT) RG_REQUIRE(h, a.seg[s].stats && a.seg[s].gamma && a.seg[s].beta, "LN/STYL needs stats");
+    if (a.seg[s].mode != RG_A_IDENT)
+      RG_REQUIRE(h, a.seg[s].stats && a.seg[s].gamma && a.seg[s].beta && a.seg[s].nparts >= 1 && a.seg[s].nparts <= 8,
+                 "LN/STYL needs stats (1..8 partial sums per row)");
     if (a.seg[s].mode == RG_A_STYL) RG_REQUIRE(h, a.seg[s].scale_shift, "STYL needs scale_shift");
   }
   a.nseg = nseg; a.seg_len = seg_len; a.M = M; a.ldo = ldo;
