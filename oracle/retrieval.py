@@ -241,3 +241,21 @@ def database_forward(P, vae_cfgs, db, dataset, conditions, own_names, tape, retr
                               retr_spkid=rec["speaker_id"].unsqueeze(0), retr_motion_mask=mask)
         retr_se.append(rs), query_se.append(qs), lats.append(ls)
     return dict(retr_startends=retr_se, query_startends=query_se, retr_uncropped_latents=lats)
+
+
+def parse_gesture_labels_from_llm_output(llm_output):
+    """reference: rag/llm_retrieval.py:131-165 (regex over the LLM's "(word, type)" list; beat labels and
+    duplicates dropped)."""
+    import re
+    labels = []
+    rx = r"[\"\']*([\w \-\']+\w)[\"\']*\,\s*[\"\']*(?P<gesttype>b*eat|m*etaphoric|iconic|deictic)"
+    for m in re.finditer(rx, llm_output, re.MULTILINE):
+        t = m.group("gesttype")
+        name = "metaphoric" if "etaphoric" in t else "beat" if "eat" in t else "iconic" if "iconic" in t else "deictic"
+        labels.append({"word": m.group(1).strip(), "name": name})
+    labels = [g for g in labels if g["name"] != "beat"]
+    out = []
+    for g in labels:
+        if g not in out:
+            out.append(g)
+    return out

@@ -15,6 +15,9 @@ the caller (`metadata=` or `dataset.retrieval_samples`); `lmdb` is not available
 """
 import copy
 import ctypes
+import json
+import os
+import re
 
 import numpy as np
 import torch
@@ -513,3 +516,59 @@ class RetrievalDatabase:
                     raw_facial=raw_facial.view(B, self.num_retrieval, self.max_seq_len, -1),
                     raw_sample_names=names_out, raw_type2words=type2words, raw_latent_mask=raw_latent_mask,
                     retr_startends=retr_se, query_startends=query_se, retr_uncropped_latents=retr_lats)
+
+
+# ---------------------------------------------------------------------------------------------- LLM guidance (host side)
+_LLM_LABEL_RX = re.compile(r"[\"\']*([\w \-\']+\w)[\"\']*\,\s*[\"\']*(?P<gesttype>b*eat|m*etaphoric|iconic|deictic)", re.MULTILINE)
+
+
+def parse_gesture_labels_from_llm_output(llm_output):
+    """rag/llm_retrieval.py:131-165: the "(word, type)" pairs of an LLM answer -> [{"word", "name"}], beat labels and
+    duplicates (pairs repeated in the model's explanation) dropped.  Same regular expression as the reference."""
+    labels = []
+    for m in _LLM_LABEL_RX.finditer(llm_output):
+        t = m.group("gesttype")
+        if "etaphoric" in t:
+            name = "metaphoric"
+        elif "eat" in t:
+            name = "beat"
+        elif "iconic" in t:
+            name = "iconic"
+        else:
+            name = "deictic"
+        labels.append({"word": m.group(1).strip(), "name": name})
+    out = []
+    for g in labels:
+        if g["name"] != "beat" and g not in out:
+            out.append(g)
+    return out
+
+
+class LLMResponseCache:
+    """Response cache for the LLM call of the llm retrieval method (rag/llm_retrieval.py:72-96 calls the API for
+    every window of every clip; BASELINE config 5 runs on cached calls).  `call(text) -> str` is supplied by the
+    user (there is no network code here); answers are keyed by the exact prompt text and persisted as JSON."""
+
+    def __init__(self, path=None, call=None):
+        self.path, self.call, self.hits, self.misses = path, call, 0, 0
+        self.data = {}
+        if path is not None and os.path.exists(path):
+            with open(path, "r", encoding="utf-8") as f:
+                self.data = json.load(f)
+
+    def get(self, text):
+        if text in self.data:
+            self.hits += 1
+            return self.data[text]
+        if self.call is None:
+            raise KeyError("no cached LLM answer for this text and no `call` to produce one")
+        self.misses += 1
+        self.data[text] = self.call(text)
+        if self.path is not None:
+            with open(self.path, "w", encoding="utf-8") as f:
+                json.dump(self.data, f, ensure_ascii=False, indent=0)
+        return self.data[text]
+
+    def labels(self, text):
+        """parse(get(text)); the empty text short-circuits like llm_retrieval (:180-181)."""
+        return [] if text.strip() == "" else parse_gesture_labels_from_llm_output(self.get(text))

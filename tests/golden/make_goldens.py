@@ -160,6 +160,7 @@ def main():
 
     # ---- (ii-b) caller-side packing / long-form helpers ---------------------
     run_packing_goldens(ns)
+    run_llm_parser_goldens(ns)
     if "--packing-only" in sys.argv:
         return
 
@@ -259,6 +260,33 @@ def run_packing_goldens(ns):
         e(o_pred, pred), e(opk.interp_motion(pred, 2), poses30), e(opk.interp_features(facial, 2), facial30),
         e(o_long[0], long_m), e(o_long[1], long_f), e(o_long[2], long_t), e(opk.interp_motion(o_long[0], 2), long30),
         opk.window_bounds(sample_len)[:2] == (starts, ends)))
+
+
+LLM_OUTPUTS = [
+    "[('hello', 'beat'), ('world', 'iconic')]",
+    "[(\"over there\", \"deictic\"), (\"huge\", \"metaphoric\")]",
+    "Here are the words:\n[('grow', 'metaphoric'), ('this', 'deictic')]\nExplanation: ('grow', 'metaphoric') because growth is abstract.",
+    "1. \"spiral staircase\", iconic\n2. 'you', deictic\n3. so, beat",
+    "[('up-and-down', 'iconic'), (\"don't\", 'metaphoric')]",
+    "I could not find any gesture words.",
+    "[('big', 'Metaphoric'), ('round', 'etaphoric'), ('tap', 'eat')]",
+    "",
+]
+
+
+def run_llm_parser_goldens(ns):
+    """rag/llm_retrieval.py:131-165 on answers in the formats the prompt asks for (and a few it does not)."""
+    import json
+    llm = importlib.import_module("mogen.models.transformers.rag.llm_retrieval")
+    from oracle import retrieval as oret
+    res = []
+    for txt in LLM_OUTPUTS:
+        ref = llm.parse_gesture_labels_from_llm_output(txt)
+        assert oret.parse_gesture_labels_from_llm_output(txt) == ref, txt
+        res.append(dict(llm_output=txt, labels=ref))
+    with open(os.path.join(HERE, "llm_parser.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("llm parser oracle == reference on %d answers" % len(res))
 
 
 class _FakeDataset:

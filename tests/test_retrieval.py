@@ -146,3 +146,30 @@ def test_retrieval_database_forward_vs_reference(rg, golden_dir):
     # the raw_motion_latents template carries upper+hands rows only (raggesture.py:856-857)
     rml = re["raw_motion_latents"]
     assert rml.shape == (2, 1, 43, 512) and rml[:, :, 22:].abs().max() == 0
+
+
+def test_llm_output_parser_and_response_cache(rg, golden_dir, tmp_path):
+    """rag/llm_retrieval.py:131-165 (parser) against answers parsed by the real reference function; the response
+    cache replays answers without calling out."""
+    import json
+    from oracle import retrieval as oret
+    cases = json.load(open(os.path.join(golden_dir, "llm_parser.json")))
+    assert len(cases) >= 8
+    for c in cases:
+        assert oret.parse_gesture_labels_from_llm_output(c["llm_output"]) == c["labels"]
+        assert rg.retrieval.parse_gesture_labels_from_llm_output(c["llm_output"]) == c["labels"]
+    calls = []
+
+    def fake_llm(text):
+        calls.append(text)
+        return "[('%s', 'iconic'), ('so', 'beat')]" % text.split()[0]
+
+    path = str(tmp_path / "llm_cache.json")
+    cache = rg.retrieval.LLMResponseCache(path, call=fake_llm)
+    assert cache.labels("round table talk") == [{"word": "round", "name": "iconic"}]
+    assert cache.labels("round table talk") == [{"word": "round", "name": "iconic"}] and calls == ["round table talk"]
+    assert cache.labels("   ") == [] and (cache.hits, cache.misses) == (1, 1)
+    replay = rg.retrieval.LLMResponseCache(path)          # a new process: cached answers only
+    assert replay.labels("round table talk") == [{"word": "round", "name": "iconic"}]
+    with pytest.raises(KeyError):
+        replay.get("never asked")
