@@ -57,8 +57,12 @@ def build_db_dicts(samples):
         idx_2_sense[n] = [spk] + [(d[1], d[0]) for d in smp["discourse"]]
         idx_2_discbounds[n] = [(d[1], d[0], d[4], d[5], d[6], d[7]) for d in smp["discourse"]]
         idx_2_prominence[n] = map_conns_to_prominence([d[0] for d in smp["discourse"]], smp["prominence"])
-    return dict(idx_2_text=idx_2_text, idx_2_sense=idx_2_sense, idx_2_discbounds=idx_2_discbounds,
-                idx_2_prominence=idx_2_prominence)
+    out = dict(idx_2_text=idx_2_text, idx_2_sense=idx_2_sense, idx_2_discbounds=idx_2_discbounds,
+               idx_2_prominence=idx_2_prominence)
+    if all("gesture_labels" in smp for smp in samples):   # raggesture.py:262
+        out["idx_2_gesture_labels"] = {smp["sample_name"]: [int(smp["speaker_id"])] + list(smp["gesture_labels"])
+                                       for smp in samples}
+    return out
 
 
 def sort_sidx_by_textsimilarity(smp_indexes, encoded_text, feature_cache):
@@ -259,3 +263,59 @@ def parse_gesture_labels_from_llm_output(llm_output):
         if g not in out:
             out.append(g)
     return out
+
+
+def gesture_type_retrieval(gesture_labels, speaker_id, db_labels, encoded_text, db_text, word_similarity):
+    """reference: rag/gesture_type_retrieval.py:8-176.  db_labels: name -> [speaker_id, {name, word, start, end}, ...]
+    (raggesture.py:262), db_text: idx_2_text, word_similarity(a, b): the reference's get_word_similarity_score
+    (rag/utils.py:239-272, a fasttext / word2vec model with a fuzzy-ratio fallback -- injected here).
+    Returns (sample_indexes, d_bounds, query_gest_bounds)."""
+    gesture_labels = [g for g in gesture_labels if g["name"] != "beat"]
+    d_bounds, sample_indexes, query_bounds = {}, {}, {}
+    if len(gesture_labels) == 0:
+        return sample_indexes, d_bounds, query_bounds
+    query_bounds = {i: (g["word"].lower(), g["name"], g["start"], g["end"]) for i, g in enumerate(gesture_labels)}
+    for qi, g in enumerate(gesture_labels):
+        q_type, q_word = g["name"], g["word"]
+        score, rel_bounds = {}, {}
+        for name, rec in db_labels.items():
+            score[name] = 0
+            spk = rec[0]
+            labels = [x for x in rec[1:] if x["name"] != "beat"]
+            types = [x["name"] for x in labels]
+            words = [x["word"] for x in labels]
+            if q_type in types:
+                score[name] += 2
+                rel = [k for k, t in enumerate(types) if t == q_type]
+                rel_words = [words[k] for k in rel]
+                if spk == speaker_id:
+                    score[name] += 2
+                if q_word in rel_words:
+                    score[name] += 5
+                    top = rel[rel_words.index(q_word)]
+                else:
+                    sims = [word_similarity(w, q_word) for w in rel_words]
+                    best = max(range(len(sims)), key=lambda k: (sims[k], -k))   # np.argmax: first maximum
+                    top = rel[best]
+                    score[name] += 3 / (1 + 2 * sims[best])
+                rel_bounds[name] = labels[top]
+        order = sorted(score, key=score.get, reverse=True)
+        tiers = {}
+        for name in order:
+            tiers.setdefault(score[name], [])
+            if score[name] > 0:
+                tiers[score[name]].append(name)
+        ranked = []
+        for sc in sorted(tiers.keys(), reverse=True):
+            tier = tiers[sc]
+            if len(tier) > 1:
+                tier = sort_sidx_by_textsimilarity(tier, encoded_text, db_text)
+            ranked += tier
+            if len(ranked) >= 10:
+                break
+        sample_indexes[qi] = ranked[:10]
+        d_bounds[qi] = {}
+        for name in ranked[:10]:
+            b = rel_bounds[name]
+            d_bounds[qi][name] = (b["word"], b["name"], round(b["start"], 3), round(b["end"], 3))
+    return sample_indexes, d_bounds, query_bounds

@@ -67,6 +67,57 @@ __global__ void __launch_bounds__(256) discourse_scores_kernel(
   top_out[e] = top;
 }
 
+// rag/gesture_type_retrieval.py:41-117 for one query label (type, word): per DB entry, over its non-beat labels of
+// the query type: +2 type present, +2 same speaker, +5 exact word (top = first label with that word) or
+// +3/(1+2*max similarity) (top = first label of maximal similarity); word codes index the similarity vector the
+// host computed for this query word (get_word_similarity_score against every DB word), float64 like the
+// reference's Python floats.  top_out = index within the entry's non-beat labels, -1 if the type is absent.
+__global__ void __launch_bounds__(256) gesture_scores_kernel(const int* __restrict__ spk, const int* __restrict__ lab_off,
+                                                            const int* __restrict__ lab_type, const int* __restrict__ lab_word,
+                                                            const double* __restrict__ word_sim, int n_entries, int q_type,
+                                                            int q_word, int q_spk, int sim_f32,
+                                                            double* __restrict__ score_out, int* __restrict__ top_out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_entries) return;
+  const int r0 = lab_off[e], r1 = lab_off[e + 1];
+  int exact = -1, best = -1;
+  double best_sim = 0.0;
+  bool any = false;
+  for (int r = r0; r < r1; ++r) {
+    if (lab_type[r] != q_type) continue;
+    any = true;
+    const int w = lab_word[r];
+    if (exact < 0 && q_word >= 0 && w == q_word) exact = r;
+    const double sv = word_sim[w];
+    if (best < 0 || sv > best_sim) {   // np.argmax: first maximum
+      best = r;
+      best_sim = sv;
+    }
+  }
+  double score = 0.0;
+  int top = -1;
+  if (any) {
+    score += 2.0;
+    if (spk[e] == q_spk) score += 2.0;
+    if (exact >= 0) {
+      score += 5.0;
+      top = exact - r0;
+    } else {
+      // a similarity model that returns numpy float32 (gensim) makes the reference's whole score float32
+      // (NEP 50: int + np.float32 -> float32); python floats keep it float64
+      if (sim_f32) {
+        const float s = (float)best_sim;
+        score = (double)((float)score + 3.0f / (1.0f + 2.0f * s));
+      } else {
+        score += 3.0 / (1.0 + 2.0 * best_sim);
+      }
+      top = best - r0;
+    }
+  }
+  score_out[e] = score;
+  top_out[e] = top;
+}
+
 __global__ void __launch_bounds__(256) text_diag_sim_kernel(const float* __restrict__ q, int Lq,
                                                            const float* __restrict__ feats,
                                                            const int64_t* __restrict__ feat_off,
@@ -252,6 +303,17 @@ extern "C" int rg_text_diag_sim(rg_handle* h, const float* q, int Lq, const floa
   RG_REQUIRE(h, n_cand > 0 && Lq > 0 && dim % 4 == 0, "bad shape");
   hipLaunchKernelGGL(text_diag_sim_kernel, dim3(n_cand), dim3(256), 0, rg_stream(stream), q, Lq, feats, feat_off,
                      cand, dim, out);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_gesture_scores(rg_handle* h, const int* spk, const int* lab_off, const int* lab_type, const int* lab_word,
+                                 const double* word_sim, int n_entries, int q_type, int q_word, int q_spk,
+                                 int sim_f32, double* score_out, int* top_out, void* stream) {
+  RG_REQUIRE(h, spk && lab_off && lab_type && lab_word && word_sim && score_out && top_out, "null pointer");
+  RG_REQUIRE(h, n_entries > 0, "empty database");
+  hipLaunchKernelGGL(gesture_scores_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, rg_stream(stream), spk, lab_off,
+                     lab_type, lab_word, word_sim, n_entries, q_type, q_word, q_spk, sim_f32, score_out, top_out);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

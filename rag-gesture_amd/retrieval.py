@@ -68,8 +68,12 @@ def build_db_dicts(samples):
         idx_2_sense[n] = [spk] + [(d[1], d[0]) for d in smp["discourse"]]
         idx_2_discbounds[n] = [(d[1], d[0], d[4], d[5], d[6], d[7]) for d in smp["discourse"]]
         idx_2_prominence[n] = map_conns_to_prominence([d[0] for d in smp["discourse"]], smp["prominence"])
-    return dict(idx_2_text=idx_2_text, idx_2_sense=idx_2_sense, idx_2_discbounds=idx_2_discbounds,
-                idx_2_prominence=idx_2_prominence)
+    out = dict(idx_2_text=idx_2_text, idx_2_sense=idx_2_sense, idx_2_discbounds=idx_2_discbounds,
+               idx_2_prominence=idx_2_prominence)
+    if all("gesture_labels" in smp for smp in samples):   # raggesture.py:262
+        out["idx_2_gesture_labels"] = {smp["sample_name"]: [int(smp["speaker_id"])] + list(smp["gesture_labels"])
+                                       for smp in samples}
+    return out
 
 
 class DiscourseIndex:
@@ -190,6 +194,43 @@ def discourse_queries(discourse, prominence, speaker_id):
     return [(d[1], d[0], speaker_id, None if q_prom[i] is None else q_prom[i][1]) for i, d in enumerate(discourse)]
 
 
+def _cut_tiers(index, q_dev, survivor, sims):
+    """Only the top tiers are ever visited by the reference's ranking walk (it stops once it holds 10 entries): the
+    device kept the entries whose score reaches the 10th largest one (all ties included); order them like
+    sorted(..., reverse=True) (stable among equals), cut the leading score tiers and launch the tie-break
+    similarity of every multi-member tier (appended to `sims`).  Returns (tiers [(entries, sims slot)], top)."""
+    keep, kscore, ktop = survivor
+    top = dict(zip(keep.tolist(), ktop.tolist()))
+    o = np.argsort(-kscore, kind="stable")
+    order, oscore = keep[o].tolist(), kscore[o].tolist()
+    tiers, i, n = [], 0, 0
+    while i < len(order) and n < 10:
+        sc = oscore[i]
+        if not sc > 0:
+            break
+        j = i
+        while j < len(order) and oscore[j] == sc:
+            j += 1
+        tier = [int(e) for e in order[i:j]]
+        slot = None
+        if len(tier) > 1:
+            slot = len(sims)
+            sims.append(index.sims_async(q_dev, tier))
+        tiers.append((tier, slot))
+        n += len(tier)
+        i = j
+    return tiers, top
+
+
+def _walk_tiers(tiers, sims_host):
+    ranked = []
+    for tier, slot in tiers:
+        if slot is not None:
+            tier = [tier[k] for k in np.argsort(-sims_host[slot], kind="stable")]
+        ranked += tier
+    return ranked[:10]
+
+
 def discourse_retrieval_begin(index, discourse, prominence, speaker_id, encoded_text, survivors=None):
     """First half of discourse_retrieval: orders the survivors of every query relation, cuts the leading score
     tiers the reference's ranking walk can reach (it stops once it holds 10 entries) and LAUNCHES the
@@ -203,29 +244,7 @@ def discourse_retrieval_begin(index, discourse, prominence, speaker_id, encoded_
     if survivors is None:
         survivors = index.collect(index.sweep_async(discourse_queries(discourse, prominence, speaker_id)))
     for qi in range(len(discourse)):
-        # Only the top tiers are ever visited: the device kept the entries whose score reaches the 10th largest
-        # one (all ties included); order them like sorted(..., reverse=True) (stable among equals).
-        keep, kscore, ktop = survivors[qi]
-        top = dict(zip(keep.tolist(), ktop.tolist()))
-        o = np.argsort(-kscore, kind="stable")
-        order, oscore = keep[o].tolist(), kscore[o].tolist()
-        tiers, i, n = [], 0, 0
-        while i < len(order) and n < 10:
-            sc = oscore[i]
-            if not sc > 0:
-                break
-            j = i
-            while j < len(order) and oscore[j] == sc:
-                j += 1
-            tier = [int(e) for e in order[i:j]]
-            slot = None
-            if len(tier) > 1:
-                slot = len(pend["sims"])
-                pend["sims"].append(index.sims_async(q_dev, tier))
-            tiers.append((tier, slot))
-            n += len(tier)
-            i = j
-        pend["queries"].append((tiers, top))
+        pend["queries"].append(_cut_tiers(index, q_dev, survivors[qi], pend["sims"]))
     return pend
 
 
@@ -237,12 +256,7 @@ def discourse_retrieval_finish(index, pend, sims_host):
         return sample_indexes, d_bounds, query_bounds
     query_bounds = {i: (d[0].lower(), d[1], d[6], d[7]) for i, d in enumerate(discourse)}
     for qi, (tiers, top) in enumerate(pend["queries"]):
-        ranked = []
-        for tier, slot in tiers:
-            if slot is not None:
-                tier = [tier[k] for k in np.argsort(-sims_host[slot], kind="stable")]
-            ranked += tier
-        ranked = ranked[:10]
+        ranked = _walk_tiers(tiers, sims_host)
         sample_indexes[qi] = [index.names[e] for e in ranked]
         d_bounds[qi] = {}
         for e in ranked:
@@ -274,6 +288,86 @@ def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text, 
     (batched over clips); None = sweep here."""
     pend = discourse_retrieval_begin(index, discourse, prominence, speaker_id, encoded_text, survivors)
     return discourse_retrieval_finish(index, pend, fetch_sims([pend])[0])
+
+
+class GestureTypeIndex:
+    """Device copy of the DB's semantic gesture labels (raggesture.py:262 idx_2_gesture_labels, beat labels dropped
+    like gesture_type_retrieval.py:57-59 does): CSR over entries with integer-coded types and words.  Shares the
+    entry order, names and text-feature table (tie-break) with a DiscourseIndex."""
+
+    def __init__(self, db, base):
+        self.base, self.dev, self.h, self.n = base, base.dev, base.h, base.n
+        self.type_code, self.word_code, self.labels = {}, {}, []
+        spk, off, lt, lw = [], [0], [], []
+        for n in base.names:
+            rec = db["idx_2_gesture_labels"][n]
+            spk.append(int(rec[0]))
+            labs = [g for g in rec[1:] if g["name"] != "beat"]
+            self.labels.append(labs)
+            for g in labs:
+                lt.append(self.type_code.setdefault(g["name"], len(self.type_code)))
+                lw.append(self.word_code.setdefault(g["word"], len(self.word_code)))
+            off.append(len(lt))
+        i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=self.dev)
+        self.spk, self.lab_off, self.lab_type, self.lab_word = i32(spk), i32(off), i32(lt or [0]), i32(lw or [0])
+        self.vocab = list(self.word_code.keys())
+
+    def sweep(self, queries, word_similarity):
+        """[(type, word, speaker_id)] -> per query (entry idx ascending, score, top label index) of the entries that
+        can be visited; the word-similarity vector of each query word is computed here (host: the similarity model
+        is the caller's), the scores and the selection on the device."""
+        lib, vp = self.h.lib, ctypes.c_void_p
+        Q, n = len(queries), self.n
+        nws = lib.rg_select_workspace_doubles(n)
+        score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
+        top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
+        ws = torch.empty(Q, nws, dtype=torch.float64, device=self.dev)
+        cursor = torch.zeros(Q, dtype=torch.int32, device=self.dev)
+        o_idx = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
+        o_top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
+        o_score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
+        raw = [[word_similarity(w, q[1]) for w in self.vocab] or [0.0] for q in queries]
+        f32 = [int(any(isinstance(v, np.float32) for v in row)) for row in raw]
+        sims = torch.tensor([[float(v) for v in row] for row in raw], dtype=torch.float64, device=self.dev)
+        s = torch.cuda.current_stream().cuda_stream
+        for q, (q_type, q_word, speaker_id) in enumerate(queries):
+            rc = lib.rg_gesture_scores(self.h._h, vp(self.spk.data_ptr()), vp(self.lab_off.data_ptr()),
+                                       vp(self.lab_type.data_ptr()), vp(self.lab_word.data_ptr()), vp(sims[q].data_ptr()), n,
+                                       self.type_code.get(q_type, -2), self.word_code.get(q_word, -1), int(speaker_id), f32[q],
+                                       vp(score[q].data_ptr()), vp(top[q].data_ptr()), vp(s))
+            if rc == 0:
+                rc = lib.rg_select_top_scores(self.h._h, vp(score[q].data_ptr()), vp(top[q].data_ptr()), n,
+                                              vp(ws[q].data_ptr()), vp(cursor[q:].data_ptr()), n, vp(o_idx[q].data_ptr()),
+                                              vp(o_top[q].data_ptr()), vp(o_score[q].data_ptr()), vp(s))
+            if rc != 0:
+                raise capi.RgError("gesture-type sweep failed: %s" % lib.rg_last_error(self.h._h).decode())
+        return DiscourseIndex.collect(dict(cursor=cursor, idx=o_idx, top=o_top, score=o_score))
+
+
+def gesture_type_retrieval(gindex, gesture_labels, speaker_id, encoded_text, word_similarity):
+    """Same contract as rag/gesture_type_retrieval.py:8-176 (sample_indexes, d_bounds, query_gest_bounds); the DB
+    sweep, the candidate selection and the tie-break text similarity run on the GPU, `word_similarity(db_word,
+    query_word)` is the reference's get_word_similarity_score (an external embedding model: supplied by the caller)."""
+    gesture_labels = [g for g in gesture_labels if g["name"] != "beat"]
+    d_bounds, sample_indexes, query_bounds = {}, {}, {}
+    if len(gesture_labels) == 0:
+        return sample_indexes, d_bounds, query_bounds
+    query_bounds = {i: (g["word"].lower(), g["name"], g["start"], g["end"]) for i, g in enumerate(gesture_labels)}
+    base = gindex.base
+    q_dev = encoded_text.to(base.dev).float().contiguous()
+    survivors = gindex.sweep([(g["name"], g["word"], speaker_id) for g in gesture_labels], word_similarity)
+    sims, cut = [], []
+    for qi in range(len(gesture_labels)):
+        cut.append(_cut_tiers(base, q_dev, survivors[qi], sims))
+    sims_host = [t.cpu().numpy() for t in sims]
+    for qi, (tiers, top) in enumerate(cut):
+        ranked = _walk_tiers(tiers, sims_host)
+        sample_indexes[qi] = [base.names[e] for e in ranked]
+        d_bounds[qi] = {}
+        for e in ranked:
+            b = gindex.labels[e][int(top[e])]
+            d_bounds[qi][base.names[e]] = (b["word"], b["name"], round(b["start"], 3), round(b["end"], 3))
+    return sample_indexes, d_bounds, query_bounds
 
 
 def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="discourse", fps=15, chunk=15,
@@ -342,7 +436,7 @@ def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="d
 
 
 class RetrievalDatabase:
-    """Drop-in for raggesture.py:157-884 `RetrievalDatabase` (inference, `discourse` method).
+    """Drop-in for raggesture.py:157-884 `RetrievalDatabase` (inference; `discourse` and `gesture_type` methods).
 
     `dataset[name]` must return the per-sample dict the reference reads (motion, motion_upper/lower/
     face/hands, facial, trans, contact, motion_mask, word, audio, speaker_id).  DB metadata comes
@@ -350,7 +444,8 @@ class RetrievalDatabase:
     `dataset.retrieval_samples` (raw records, see build_db_dicts)."""
 
     def __init__(self, num_retrieval=None, topk=None, latent_dim=512, text_latent_dim=768, max_seq_len=150,
-                 motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", **_cfg):
+                 motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", word_similarity=None,
+                 **_cfg):
         if metadata is None:
             samples = getattr(dataset, "retrieval_samples", None)
             if samples is None:
@@ -362,19 +457,32 @@ class RetrievalDatabase:
         self.max_seq_len, self.motion_fps, self.motion_framechunksize = max_seq_len, motion_fps, motion_framechunksize
         self.latent_dim, self.text_latent_dim = latent_dim, text_latent_dim
         self.index = DiscourseIndex(metadata, device)
+        # gesture_type method: needs idx_2_gesture_labels in the metadata and the word-similarity model of
+        # rag/utils.py:239-272 (external: `word_similarity(db_word, query_word) -> float`)
+        self.gesture_index = GestureTypeIndex(metadata, self.index) if "idx_2_gesture_labels" in metadata else None
+        self.word_similarity = word_similarity
         self.test_indexes, self.test_dbounds, self.test_qbounds = {}, {}, {}
         self.phase_ms = None  # dict: MotionDiffusion's phase profiler also collects the sub-phases here
 
-    def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None, ready=None):
+    def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None, ready=None,
+                 gesture_labels=None):
         """raggesture.py:313-477 (eval branch, first-call behaviour; results cached per idx)."""
-        if retr_method != "discourse":
-            raise NotImplementedError("only the discourse retrieval method is built (llm / gesture_type: next)")
+        if retr_method not in ("discourse", "gesture_type"):
+            raise NotImplementedError("the llm retrieval method is not built (discourse and gesture_type are)")
         if idx is not None and idx in self.test_indexes and retr_method in self.test_indexes[idx]:
             si, db_b, qb = (self.test_indexes[idx][retr_method], self.test_dbounds[idx][retr_method],
                             self.test_qbounds[idx][retr_method])
         else:
-            si, db_b, qb = ready if ready is not None else discourse_retrieval(self.index, discourse, prominence,
-                                                                                  speaker_id, text_features)
+            if ready is not None:
+                si, db_b, qb = ready
+            elif retr_method == "gesture_type":
+                if self.gesture_index is None or self.word_similarity is None:
+                    raise capi.RgError("gesture_type retrieval needs idx_2_gesture_labels in the DB metadata and a "
+                                       "word_similarity callable (rag/utils.py:239 get_word_similarity_score)")
+                si, db_b, qb = gesture_type_retrieval(self.gesture_index, gesture_labels, speaker_id, text_features,
+                                                      self.word_similarity)
+            else:
+                si, db_b, qb = discourse_retrieval(self.index, discourse, prominence, speaker_id, text_features)
             self.test_indexes.setdefault(idx, {})[retr_method] = si
             self.test_dbounds.setdefault(idx, {})[retr_method] = db_b
             self.test_qbounds.setdefault(idx, {})[retr_method] = qb
@@ -437,7 +545,8 @@ class RetrievalDatabase:
                 spk = spks[b]
                 ri, rb, qb = self.retrieve(retrieval_method, conditions["text_features"][b], conditions["discourse"][b],
                                            conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None,
-                                           ready=ready.get(b))
+                                           ready=ready.get(b),
+                                           gesture_labels=(conditions.get("gesture_labels") or [None] * B)[b])
                 plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
                 plans.append((plan, rb, qb))
                 for qp, name, placed in plan:

@@ -302,6 +302,34 @@ def connective_vocab(n=50):
     return out[:n]
 
 
+GESTURE_TYPES = ("beat", "iconic", "metaphoric", "deictic")
+GESTURE_WORDS = ("round", "big", "this", "that one", "over there", "grow", "tiny", "spiral staircase", "you", "up", "down",
+                 "together", "apart", "huge", "little bit")
+
+
+def synth_word_similarity(a, b):
+    """Deterministic stand-in for the reference's get_word_similarity_score (a fasttext / word2vec model,
+    rag/utils.py:239-272): a symmetric pseudo-similarity in [0, 1) from the crc32 of the sorted word pair."""
+    x, y = sorted((a, b))
+    return (zlib.crc32((x + "|" + y).encode()) % 10007) / 10007.0
+
+
+def synth_gesture_query(seed, n_labels=2):
+    g = np.random.Generator(np.random.PCG64(seed + 31337))
+    out, t = [], 0.4
+    for k in range(n_labels):
+        st = t + float(g.uniform(0.2, 2.5))
+        en = st + float(g.uniform(0.3, 1.0))
+        t = en
+        name = GESTURE_TYPES[1 + int(g.integers(0, 3))] if k else "iconic"
+        word = GESTURE_WORDS[int(g.integers(0, len(GESTURE_WORDS)))] if k else "round"
+        if k == 2 or (k and seed % 2 == 0):     # words absent from the DB: the word-similarity branch decides
+            word = ("gigantic", "very small", "Round")[(seed + k) % 3]
+        out.append(dict(name=name, word=word, start=st, end=en))
+    out.insert(1, dict(name="beat", word="so", start=0.1, end=0.3))   # beat labels are ignored by the method
+    return out
+
+
 def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, tie_groups=True, feat_device=None):
     """Raw per-sample records with the fields the reference's DB builder reads
     (raggesture.py:244-293): sample_name, speaker_id, discourse (8-tuples
@@ -339,6 +367,20 @@ def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, t
         L = int(g.integers(8, 49))
         feat = L if feat_device is not None else torch.from_numpy(g.standard_normal((L, feat_dim)).astype(np.float32))
         recs.append(dict(sample_name=name, speaker_id=spk, discourse=disc, prominence=prom, text_feature=feat))
+    # semantic gesture labels (beatx_dataset gesture_labels: name / word / start / end), from a generator of their own
+    # so that the fields above (and the goldens pinned on them) do not move
+    gl = np.random.Generator(np.random.PCG64(seed + 777))
+    for i, r in enumerate(recs):
+        labels, t = [], 0.1
+        for _ in range(int(gl.integers(0, 4))):
+            st = t + float(gl.uniform(0.0, 2.0))
+            en = st + float(gl.uniform(0.2, 1.2))
+            t = en
+            labels.append(dict(name=GESTURE_TYPES[int(gl.integers(0, len(GESTURE_TYPES)))],
+                               word=GESTURE_WORDS[int(gl.integers(0, len(GESTURE_WORDS)))], start=st, end=en))
+        if tie_groups and i % 7 == 0:   # forced ties: same type, same word, same speaker as many other entries
+            labels = [dict(name="iconic", word="round", start=1.0, end=1.6)]
+        r["gesture_labels"] = labels
     if feat_device is not None:
         # benchmark-sized DBs: draw all token features with one device-side generator call
         tot = sum(r["text_feature"] for r in recs)

@@ -161,6 +161,7 @@ def main():
     # ---- (ii-b) caller-side packing / long-form helpers ---------------------
     run_packing_goldens(ns)
     run_llm_parser_goldens(ns)
+    run_gesture_type_goldens(ns)
     if "--packing-only" in sys.argv:
         return
 
@@ -287,6 +288,48 @@ def run_llm_parser_goldens(ns):
     with open(os.path.join(HERE, "llm_parser.json"), "w") as f:
         json.dump(res, f, indent=1)
     print("llm parser oracle == reference on %d answers" % len(res))
+
+
+def f32_word_similarity(a, b):
+    """Same stand-in, returned as numpy float32 like gensim's .similarity() does (the reference's scores then live
+    in float32: NEP 50)."""
+    return np.float32(synth.synth_word_similarity(a, b))
+
+
+def run_gesture_type_goldens(ns):
+    """rag/gesture_type_retrieval.py:8-176 on a synthetic labelled DB; the external word-embedding model behind
+    get_word_similarity_score is replaced by synth.synth_word_similarity (python float) and by its float32 form."""
+    import json
+    from oracle import retrieval as oret
+    gt = importlib.import_module("mogen.models.transformers.rag.gesture_type_retrieval")
+    samples = synth.synth_retrieval_samples(200, seed=2025)
+    db_text = {s["sample_name"]: (s["text_feature"], s["speaker_id"]) for s in samples}
+    db_labels = {s["sample_name"]: [s["speaker_id"]] + s["gesture_labels"] for s in samples}   # raggesture.py:262
+    assert oret.build_db_dicts(samples)["idx_2_gesture_labels"] == db_labels
+    gold = {"queries": []}
+    saved = gt.get_word_similarity_score
+    try:
+        for simname, sim in (("f64", synth.synth_word_similarity), ("f32", f32_word_similarity)):
+            gt.get_word_similarity_score = sim
+            for qseed in (11, 12, 13, 14):
+                q = synth.synth_query(qseed)
+                labels = synth.synth_gesture_query(qseed, n_labels=2 + qseed % 2) if qseed != 14 else \
+                    [dict(name="beat", word="and", start=0.2, end=0.5)]
+                si, db_b, qb = gt.gesture_type_retrieval(text=None, gesture_labels=labels, speaker_id=q["speaker_id"],
+                                                         db_idx_2_gesture_labels=db_labels,
+                                                         encoded_text=q["text_features"], text_feat_cache=db_text)
+                osi, odb, oqb = oret.gesture_type_retrieval(labels, q["speaker_id"], db_labels, q["text_features"], db_text, sim)
+                assert osi == si and odb == db_b and oqb == qb, "oracle gesture_type retrieval != reference"
+                gold["queries"].append(dict(seed=qseed, sim=simname, labels=labels,
+                                            sample_indexes={str(k): v for k, v in si.items()},
+                                            d_bounds={str(k): {n: list(b) for n, b in v.items()} for k, v in db_b.items()},
+                                            query_bounds={str(k): list(v) for k, v in qb.items()}))
+    finally:
+        gt.get_word_similarity_score = saved
+    with open(os.path.join(HERE, "gesture_type.json"), "w") as f:
+        json.dump(gold, f, indent=1)
+    print("gesture_type_retrieval oracle == reference on %d queries; result sizes:" % len(gold["queries"]),
+          [[len(v) for v in q["sample_indexes"].values()] for q in gold["queries"]])
 
 
 class _FakeDataset:

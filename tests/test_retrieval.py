@@ -173,3 +173,91 @@ def test_llm_output_parser_and_response_cache(rg, golden_dir, tmp_path):
     assert replay.labels("round table talk") == [{"word": "round", "name": "iconic"}]
     with pytest.raises(KeyError):
         replay.get("never asked")
+
+
+# ------------------------------------------------------------------ gesture_type retrieval
+def _gesture_golden(golden_dir):
+    with open(os.path.join(golden_dir, "gesture_type.json")) as f:
+        return json.load(f)["queries"]
+
+
+def _f32_sim(rg):
+    return lambda a, b: np.float32(rg.synth.synth_word_similarity(a, b))
+
+
+def test_oracle_gesture_type_retrieval_matches_reference(rg, golden_dir):
+    """oracle/retrieval.py::gesture_type_retrieval against the real reference's outputs (make_goldens.py), with the
+    word-similarity model replaced by the same deterministic stand-in on both sides (python float and float32)."""
+    smp = _db(rg)
+    db = oret.build_db_dicts(smp)
+    assert "idx_2_gesture_labels" in db and len(db["idx_2_gesture_labels"]) == len(smp)
+    for q in _gesture_golden(golden_dir):
+        sim = rg.synth.synth_word_similarity if q["sim"] == "f64" else _f32_sim(rg)
+        qq = rg.synth.synth_query(q["seed"])
+        si, dbb, qb = oret.gesture_type_retrieval(q["labels"], qq["speaker_id"], db["idx_2_gesture_labels"],
+                                                  qq["text_features"], db["idx_2_text"], sim)
+        gsi, gdb, gqb = _unpack(q)
+        assert si == gsi and dbb == gdb and qb == gqb
+    # only beat labels / no labels: three empty dicts (gesture_type_retrieval.py:26-27)
+    assert oret.gesture_type_retrieval([], 1, db["idx_2_gesture_labels"], None, db["idx_2_text"], None) == ({}, {}, {})
+
+
+@pytest.mark.gpu
+def test_hip_gesture_type_matches_reference_golden(rg, golden_dir):
+    meta = rg.retrieval.build_db_dicts(_db(rg))
+    gindex = rg.retrieval.GestureTypeIndex(meta, rg.retrieval.DiscourseIndex(meta, "cuda"))
+    for q in _gesture_golden(golden_dir):
+        sim = rg.synth.synth_word_similarity if q["sim"] == "f64" else _f32_sim(rg)
+        qq = rg.synth.synth_query(q["seed"])
+        si, dbb, qb = rg.retrieval.gesture_type_retrieval(gindex, q["labels"], qq["speaker_id"], qq["text_features"], sim)
+        gsi, gdb, gqb = _unpack(q)
+        assert si == gsi, "gesture_type retrieval indices differ from the reference"
+        assert dbb == gdb and qb == gqb
+
+
+@pytest.mark.gpu
+def test_hip_gesture_type_matches_oracle_large_db(rg):
+    """4096-entry DB: device scores (float64 and the float32 variant) give the oracle's ranking exactly."""
+    smp = rg.synth.synth_retrieval_samples(4096, seed=7)
+    db = oret.build_db_dicts(smp)
+    meta = rg.retrieval.build_db_dicts(smp)
+    gindex = rg.retrieval.GestureTypeIndex(meta, rg.retrieval.DiscourseIndex(meta, "cuda"))
+    for seed in range(100, 110):
+        qq = rg.synth.synth_query(seed)
+        labels = rg.synth.synth_gesture_query(seed, n_labels=3)
+        for sim in (rg.synth.synth_word_similarity, _f32_sim(rg)):
+            want = oret.gesture_type_retrieval(labels, qq["speaker_id"], db["idx_2_gesture_labels"], qq["text_features"],
+                                               db["idx_2_text"], sim)
+            got = rg.retrieval.gesture_type_retrieval(gindex, labels, qq["speaker_id"], qq["text_features"], sim)
+            assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+
+
+@pytest.mark.gpu
+def test_retrieval_database_gesture_type_method(rg):
+    """RetrievalDatabase.forward(retrieval_method="gesture_type"): exemplar choice and placement equal the oracle's
+    retrieval + placement arithmetic (reduced padding for labels longer than 0.9 s, raggesture.py:628-636)."""
+    smp = _db(rg)
+    odb = oret.build_db_dicts(smp)
+    names = [x["sample_name"] for x in smp]
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    P = {}
+    for i, part in enumerate(rg.synth.PARTS):
+        P.update(rg.synth.synth_vae_state(101 + i, vae_cfgs[part], prefix="gesture_rep_encoder.%s_vae." % part))
+    vae = rg.vae.GestureRepEncoder(P, vae_cfgs, "cuda", "fp32")
+    rdb = rg.retrieval.RetrievalDatabase(num_retrieval=1, dataset=_FakeDataset(rg, smp), device="cuda",
+                                         word_similarity=rg.synth.synth_word_similarity)
+    B = 2
+    qs = [rg.synth.synth_query(21), rg.synth.synth_query(22)]
+    labels = [rg.synth.synth_gesture_query(21, 3), rg.synth.synth_gesture_query(22, 2)]
+    cond = dict(text_features=[q["text_features"] for q in qs], discourse=[q["discourse"] for q in qs],
+                prominence=[q["prominence"] for q in qs], gesture_labels=labels,
+                speaker_ids=torch.tensor([[q["speaker_id"]] * 150 for q in qs]))
+    re = rdb(cond, [150] * B, "cuda", idx=["clip_a", names[7]], retrieval_method="gesture_type", gesture_rep_encoder=vae)
+    for b in range(B):
+        si, dbb, qb = oret.gesture_type_retrieval(labels[b], qs[b]["speaker_id"], odb["idx_2_gesture_labels"],
+                                                  qs[b]["text_features"], odb["idx_2_text"], rg.synth.synth_word_similarity)
+        own = ["clip_a", names[7]][b]
+        ri = {k: [s for s in v if s != own][:1] for k, v in si.items()}
+        plan = oret.place_exemplars(ri, dbb, qb, "gesture_type")
+        assert {k: tuple(v[1]) for k, v in plan.items()} == {k: tuple(v) for k, v in re["retr_startends"][b].items()}
+        assert {k: tuple(v[2]) for k, v in plan.items()} == {k: tuple(v) for k, v in re["query_startends"][b].items()}
