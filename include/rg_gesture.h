@@ -331,16 +331,19 @@ int rg_discourse_scores(rg_handle* h, const int* spk, const int* rel_off, const 
                         int q_spk, double q_prom, double* score_out, int* top_out, void* stream);
 
 /* Score of every DB entry for ONE query gesture label (type, word) of the gesture_type retrieval method
- * (rag/gesture_type_retrieval.py:41-117), float64: over the entry's non-beat labels of the query type (CSR lab_off /
- * lab_type / lab_word, words integer coded): +2 type present, +2 same speaker, +5 exact word or
- * +3/(1+2*max_r word_sim[lab_word[r]]); word_sim[v] = get_word_similarity_score(DB word v, query word) computed by
- * the caller; q_word = -1 if the query word is not a DB word.  sim_f32 != 0: the similarity model returns numpy
- * float32 (gensim does), which makes the reference's score arithmetic float32; 0: python floats, float64.
+ * (rag/gesture_type_retrieval.py:41-117) and of the llm method (rag/llm_retrieval.py:278-419), float64: over the
+ * entry's non-beat labels of the query type (CSR lab_off / lab_type / lab_word, words integer coded): +2 type present,
+ * +spk_bonus same speaker (2 for gesture_type, 1 for llm), +5 exact word or +3/(1+2*max_r word_sim[lab_word[r]]);
+ * word_sim[v] = get_word_similarity_score(DB word v, query word) computed by the caller; q_word = -1 if the query
+ * word is not a DB word.  llm only: lab_prom (NaN = unknown; NULL for gesture_type) and q_prom (NaN = unknown) add
+ * the mean of 4/(1+2|lab_prom - q_prom|) and move the reported label to the one of smallest difference.
+ * sim_f32 != 0: the similarity model returns numpy float32 and NumPy >= 2 promotion applies, which makes the
+ * reference's score arithmetic float32 from the similarity term on; 0: float64 (python floats, or NumPy < 1.24).
  * top_out = index (within the entry's non-beat labels) of the label whose bounds are reported, -1 if the type is
  * absent. */
 int rg_gesture_scores(rg_handle* h, const int* spk, const int* lab_off, const int* lab_type, const int* lab_word,
-                      const double* word_sim, int n_entries, int q_type, int q_word, int q_spk, int sim_f32,
-                      double* score_out, int* top_out, void* stream);
+                      const double* lab_prom, const double* word_sim, int n_entries, int q_type, int q_word, int q_spk,
+                      double spk_bonus, double q_prom, int sim_f32, double* score_out, int* top_out, void* stream);
 
 /* Candidate selection for the ranking walk of rag/discourse_retrieval.py:224-300: the reference sorts
  * all scores and visits entries until it holds 10, so only entries with score >= the 10th largest

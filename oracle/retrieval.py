@@ -62,6 +62,8 @@ def build_db_dicts(samples):
     if all("gesture_labels" in smp for smp in samples):   # raggesture.py:262
         out["idx_2_gesture_labels"] = {smp["sample_name"]: [int(smp["speaker_id"])] + list(smp["gesture_labels"])
                                        for smp in samples}
+        out["idx_2_gestprom"] = {smp["sample_name"]: map_conns_to_prominence([g["word"] for g in smp["gesture_labels"]],
+                                                                             smp["prominence"]) for smp in samples}  # :270-272
     return out
 
 
@@ -298,6 +300,117 @@ def gesture_type_retrieval(gesture_labels, speaker_id, db_labels, encoded_text, 
                     best = max(range(len(sims)), key=lambda k: (sims[k], -k))   # np.argmax: first maximum
                     top = rel[best]
                     score[name] += 3 / (1 + 2 * sims[best])
+                rel_bounds[name] = labels[top]
+        order = sorted(score, key=score.get, reverse=True)
+        tiers = {}
+        for name in order:
+            tiers.setdefault(score[name], [])
+            if score[name] > 0:
+                tiers[score[name]].append(name)
+        ranked = []
+        for sc in sorted(tiers.keys(), reverse=True):
+            tier = tiers[sc]
+            if len(tier) > 1:
+                tier = sort_sidx_by_textsimilarity(tier, encoded_text, db_text)
+            ranked += tier
+            if len(ranked) >= 10:
+                break
+        sample_indexes[qi] = ranked[:10]
+        d_bounds[qi] = {}
+        for name in ranked[:10]:
+            b = rel_bounds[name]
+            d_bounds[qi][name] = (b["word"], b["name"], round(b["start"], 3), round(b["end"], 3))
+    return sample_indexes, d_bounds, query_bounds
+
+
+def llm_query_bounds(gesture_labels, text_times):
+    """reference: rag/llm_retrieval.py:191-262 -- align the LLM's (word, type) labels with the word timings of the
+    clip.  text_times: [((start, end), word), ...].  Returns ({k: (word, type, start, end)} keyed 0.. in order of
+    first occurrence in the text, types, words)."""
+    q_types = [g["name"] for g in gesture_labels]
+    q_words = [_clean_str(g["word"].lower()) for g in gesture_labels]
+    bounds = {}
+    residual = copy.deepcopy(q_words)
+    for t_time in text_times:
+        t_word = _clean_str(t_time[1].lower())
+        t_start, t_end = t_time[0][0], t_time[0][1]
+        for qi, q_word in enumerate(q_words):
+            if residual[qi] is None:
+                continue
+            q_word = q_word.lower()
+            if q_word == t_word or t_word in q_word.split():
+                bounds.setdefault(qi, []).append((q_word, q_types[qi], t_start, t_end))
+                if q_word == t_word or t_word == q_word.split()[-1]:
+                    residual[qi] = None
+                break
+    for qi, bs in bounds.items():
+        if len(bs) > 1:
+            bounds[qi] = (bs[0][0], bs[0][1], min(b[2] for b in bs), max(b[3] for b in bs))
+        else:
+            bounds[qi] = bs[0]
+    bounds = {k: v for k, v in enumerate(bounds.values())}
+    return bounds, [bounds[i][1] for i in sorted(bounds)], [bounds[i][0] for i in sorted(bounds)]
+
+
+def _clean_str(s):
+    return "".join([c for c in s if c.isalnum() or c.isspace()])
+
+
+def llm_retrieval(text, text_times, speaker_id, prominence, db_labels, db_gestprom, encoded_text, db_text,
+                  word_similarity, llm_output):
+    """reference: rag/llm_retrieval.py:166-466.  db_gestprom: name -> {label idx: (word, prominence) | None}
+    (raggesture.py:270-272, over ALL labels of the sample, beat included); llm_output(text) -> str stands for
+    get_llm_output (the GPT call, :69-96); word_similarity as in gesture_type_retrieval."""
+    d_bounds, sample_indexes, query_bounds = {}, {}, {}
+    if text.strip() == "":
+        return sample_indexes, d_bounds, query_bounds
+    gesture_labels = parse_gesture_labels_from_llm_output(llm_output(text))
+    if len(gesture_labels) == 0:
+        return sample_indexes, d_bounds, query_bounds
+    query_bounds, q_types, q_words = llm_query_bounds(gesture_labels, text_times)
+    if len(query_bounds) == 0:
+        return sample_indexes, d_bounds, query_bounds
+    q_prom = map_conns_to_prominence(q_words, prominence)
+    for i in range(len(q_words)):
+        q_prom[i] = None if q_prom[i] is None else (q_types[i], *q_prom[i])
+    for qi, (q_type, q_word) in enumerate(zip(q_types, q_words)):
+        score, rel_bounds = {}, {}
+        for name, rec in db_labels.items():
+            score[name] = 0
+            spk, all_labels = rec[0], rec[1:]
+            if len(all_labels) == 0:
+                continue
+            labels = [g for g in all_labels if g["name"] != "beat"]
+            proms = [db_gestprom[name][gi] for gi, g in enumerate(all_labels) if g["name"] != "beat"]
+            types = [x["name"] for x in labels]
+            words = [x["word"] for x in labels]
+            if len(types) == 0:
+                continue
+            if q_type in types:
+                score[name] += 2
+                rel = [k for k, t in enumerate(types) if t == q_type]
+                rel_words = [words[k] for k in rel]
+                if spk == speaker_id:
+                    score[name] += 1
+                if q_word in rel_words:
+                    score[name] += 5
+                    top = rel[rel_words.index(q_word)]
+                else:
+                    sims = [word_similarity(w, q_word) for w in rel_words]
+                    best = max(range(len(sims)), key=lambda k: (sims[k], -k))   # np.argmax: first maximum
+                    top = rel[best]
+                    score[name] += 3 / (1 + 2 * sims[best])
+                total, count, diffs = 0, 0, {}
+                for k in rel:
+                    if proms[k] is None or q_prom[qi] is None:
+                        continue
+                    diff = abs(proms[k][1] - q_prom[qi][-1])
+                    diffs[k] = diff
+                    total += 4 / (1 + 2 * diff)
+                    count += 1
+                if count > 0:
+                    score[name] += total / count
+                    top = sorted(diffs, key=diffs.get)[0]
                 rel_bounds[name] = labels[top]
         order = sorted(score, key=score.get, reverse=True)
         tiers = {}

@@ -74,9 +74,11 @@ __global__ void __launch_bounds__(256) discourse_scores_kernel(
 // reference's Python floats.  top_out = index within the entry's non-beat labels, -1 if the type is absent.
 __global__ void __launch_bounds__(256) gesture_scores_kernel(const int* __restrict__ spk, const int* __restrict__ lab_off,
                                                             const int* __restrict__ lab_type, const int* __restrict__ lab_word,
+                                                            const double* __restrict__ lab_prom,
                                                             const double* __restrict__ word_sim, int n_entries, int q_type,
-                                                            int q_word, int q_spk, int sim_f32,
-                                                            double* __restrict__ score_out, int* __restrict__ top_out) {
+                                                            int q_word, int q_spk, double spk_bonus, double q_prom,
+                                                            int sim_f32, double* __restrict__ score_out,
+                                                            int* __restrict__ top_out) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n_entries) return;
   const int r0 = lab_off[e], r1 = lab_off[e + 1];
@@ -97,21 +99,47 @@ __global__ void __launch_bounds__(256) gesture_scores_kernel(const int* __restri
   double score = 0.0;
   int top = -1;
   if (any) {
+    bool f32 = false;
     score += 2.0;
-    if (spk[e] == q_spk) score += 2.0;
+    if (spk[e] == q_spk) score += spk_bonus;
     if (exact >= 0) {
       score += 5.0;
       top = exact - r0;
     } else {
-      // a similarity model that returns numpy float32 (gensim) makes the reference's whole score float32
-      // (NEP 50: int + np.float32 -> float32); python floats keep it float64
+      // a similarity model that returns numpy float32 (gensim) makes the reference's score float32 from here on
+      // under NumPy >= 2 (NEP 50: python scalar (+|*|/) np.float32 -> float32); python floats, and float32 scalars
+      // under the reference's pinned NumPy < 1.24 (scalar-scalar promotion), keep it float64
       if (sim_f32) {
         const float s = (float)best_sim;
         score = (double)((float)score + 3.0f / (1.0f + 2.0f * s));
+        f32 = true;
       } else {
         score += 3.0 / (1.0 + 2.0 * best_sim);
       }
       top = best - r0;
+    }
+    // llm method only (rag/llm_retrieval.py:385-417): mean of 4/(1+2|prominence difference|) over the labels of
+    // the query type with a known prominence; the label of smallest difference (first minimum) is reported
+    if (lab_prom != nullptr && q_prom == q_prom) {
+      double sum = 0.0, bestd = 0.0;
+      int cnt = 0, best_r = -1;
+      for (int r = r0; r < r1; ++r) {
+        if (lab_type[r] != q_type) continue;
+        const double p = lab_prom[r];
+        if (p != p) continue;
+        const double diff = fabs(p - q_prom);
+        sum += 4.0 / (1.0 + 2.0 * diff);
+        if (best_r < 0 || diff < bestd) {
+          bestd = diff;
+          best_r = r;
+        }
+        ++cnt;
+      }
+      if (cnt > 0) {
+        const double ps = sum / (double)cnt;
+        score = f32 ? (double)((float)score + (float)ps) : score + ps;
+        top = best_r - r0;
+      }
     }
   }
   score_out[e] = score;
@@ -308,12 +336,14 @@ extern "C" int rg_text_diag_sim(rg_handle* h, const float* q, int Lq, const floa
 }
 
 extern "C" int rg_gesture_scores(rg_handle* h, const int* spk, const int* lab_off, const int* lab_type, const int* lab_word,
-                                 const double* word_sim, int n_entries, int q_type, int q_word, int q_spk,
-                                 int sim_f32, double* score_out, int* top_out, void* stream) {
+                                 const double* lab_prom, const double* word_sim, int n_entries, int q_type, int q_word,
+                                 int q_spk, double spk_bonus, double q_prom, int sim_f32, double* score_out, int* top_out,
+                                 void* stream) {
   RG_REQUIRE(h, spk && lab_off && lab_type && lab_word && word_sim && score_out && top_out, "null pointer");
   RG_REQUIRE(h, n_entries > 0, "empty database");
   hipLaunchKernelGGL(gesture_scores_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, rg_stream(stream), spk, lab_off,
-                     lab_type, lab_word, word_sim, n_entries, q_type, q_word, q_spk, sim_f32, score_out, top_out);
+                     lab_type, lab_word, lab_prom, word_sim, n_entries, q_type, q_word, q_spk, spk_bonus, q_prom, sim_f32,
+                     score_out, top_out);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

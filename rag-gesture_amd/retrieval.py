@@ -73,6 +73,10 @@ def build_db_dicts(samples):
     if all("gesture_labels" in smp for smp in samples):   # raggesture.py:262
         out["idx_2_gesture_labels"] = {smp["sample_name"]: [int(smp["speaker_id"])] + list(smp["gesture_labels"])
                                        for smp in samples}
+        out["idx_2_gestprom"] = {}                        # raggesture.py:270-272 (llm method)
+        for smp in samples:
+            words = [g["word"] for g in smp["gesture_labels"]]
+            out["idx_2_gestprom"][smp["sample_name"]] = map_conns_to_prominence(words, smp["prominence"]) if words else {}
     return out
 
 
@@ -290,6 +294,9 @@ def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text, 
     return discourse_retrieval_finish(index, pend, fetch_sims([pend])[0])
 
 
+_NEP50 = int(np.__version__.split(".")[0]) >= 2
+
+
 class GestureTypeIndex:
     """Device copy of the DB's semantic gesture labels (raggesture.py:262 idx_2_gesture_labels, beat labels dropped
     like gesture_type_retrieval.py:57-59 does): CSR over entries with integer-coded types and words.  Shares the
@@ -298,7 +305,8 @@ class GestureTypeIndex:
     def __init__(self, db, base):
         self.base, self.dev, self.h, self.n = base, base.dev, base.h, base.n
         self.type_code, self.word_code, self.labels = {}, {}, []
-        spk, off, lt, lw = [], [0], [], []
+        spk, off, lt, lw, lp = [], [0], [], [], []
+        gestprom = db.get("idx_2_gestprom")
         for n in base.names:
             rec = db["idx_2_gesture_labels"][n]
             spk.append(int(rec[0]))
@@ -308,12 +316,18 @@ class GestureTypeIndex:
                 lt.append(self.type_code.setdefault(g["name"], len(self.type_code)))
                 lw.append(self.word_code.setdefault(g["word"], len(self.word_code)))
             off.append(len(lt))
+            if gestprom is not None:      # aligned with ALL labels of the sample (beat included), llm_retrieval.py:293-299
+                for gi, g in enumerate(rec[1:]):
+                    if g["name"] != "beat":
+                        pv = gestprom[n][gi]
+                        lp.append(float("nan") if pv is None else float(pv[1]))
         i32 = lambda a: torch.tensor(a, dtype=torch.int32, device=self.dev)
         self.spk, self.lab_off, self.lab_type, self.lab_word = i32(spk), i32(off), i32(lt or [0]), i32(lw or [0])
+        self.lab_prom = None if gestprom is None else torch.tensor(lp or [0.0], dtype=torch.float64, device=self.dev)
         self.vocab = list(self.word_code.keys())
 
-    def sweep(self, queries, word_similarity):
-        """[(type, word, speaker_id)] -> per query (entry idx ascending, score, top label index) of the entries that
+    def sweep(self, queries, word_similarity, spk_bonus=2.0, proms=None):
+        """[(type, word, speaker_id)] (+ per-query prominence, None = unknown: the llm method) -> per query (entry idx ascending, score, top label index) of the entries that
         can be visited; the word-similarity vector of each query word is computed here (host: the similarity model
         is the caller's), the scores and the selection on the device."""
         lib, vp = self.h.lib, ctypes.c_void_p
@@ -327,14 +341,22 @@ class GestureTypeIndex:
         o_top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
         o_score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
         raw = [[word_similarity(w, q[1]) for w in self.vocab] or [0.0] for q in queries]
-        f32 = [int(any(isinstance(v, np.float32) for v in row)) for row in raw]
+        # float32 similarities make the reference's score float32 only under NumPy >= 2 promotion rules (NEP 50); the
+        # reference pins numpy < 1.24, where scalar-scalar arithmetic promotes to float64: follow the installed numpy
+        f32 = [int(_NEP50 and any(isinstance(v, np.float32) for v in row)) for row in raw]
+        if proms is not None and self.lab_prom is None:
+            raise capi.RgError("llm retrieval needs idx_2_gestprom in the DB metadata (raggesture.py:270-272)")
+        nan = float("nan")
         sims = torch.tensor([[float(v) for v in row] for row in raw], dtype=torch.float64, device=self.dev)
         s = torch.cuda.current_stream().cuda_stream
         for q, (q_type, q_word, speaker_id) in enumerate(queries):
             rc = lib.rg_gesture_scores(self.h._h, vp(self.spk.data_ptr()), vp(self.lab_off.data_ptr()),
-                                       vp(self.lab_type.data_ptr()), vp(self.lab_word.data_ptr()), vp(sims[q].data_ptr()), n,
-                                       self.type_code.get(q_type, -2), self.word_code.get(q_word, -1), int(speaker_id), f32[q],
-                                       vp(score[q].data_ptr()), vp(top[q].data_ptr()), vp(s))
+                                       vp(self.lab_type.data_ptr()), vp(self.lab_word.data_ptr()),
+                                       vp(self.lab_prom.data_ptr()) if proms is not None else vp(None),
+                                       vp(sims[q].data_ptr()), n, self.type_code.get(q_type, -2),
+                                       self.word_code.get(q_word, -1), int(speaker_id), ctypes.c_double(spk_bonus),
+                                       ctypes.c_double(nan if proms is None or proms[q] is None else float(proms[q])),
+                                       f32[q], vp(score[q].data_ptr()), vp(top[q].data_ptr()), vp(s))
             if rc == 0:
                 rc = lib.rg_select_top_scores(self.h._h, vp(score[q].data_ptr()), vp(top[q].data_ptr()), n,
                                               vp(ws[q].data_ptr()), vp(cursor[q:].data_ptr()), n, vp(o_idx[q].data_ptr()),
@@ -353,13 +375,67 @@ def gesture_type_retrieval(gindex, gesture_labels, speaker_id, encoded_text, wor
     if len(gesture_labels) == 0:
         return sample_indexes, d_bounds, query_bounds
     query_bounds = {i: (g["word"].lower(), g["name"], g["start"], g["end"]) for i, g in enumerate(gesture_labels)}
+    sample_indexes, d_bounds = _gesture_ranked(gindex, [(g["name"], g["word"], speaker_id) for g in gesture_labels],
+                                               encoded_text, word_similarity, 2.0, None)
+    return sample_indexes, d_bounds, query_bounds
+
+
+def _clean_str(s):
+    return "".join([c for c in s if c.isalnum() or c.isspace()])
+
+
+def llm_query_bounds(gesture_labels, text_times):
+    """rag/llm_retrieval.py:191-262: align the LLM's (word, type) labels with the clip's word timings
+    [((start, end), word), ...]; multi-word labels span their words, a label is closed by its last word, the result is
+    keyed 0.. in order of first occurrence in the text."""
+    q_types = [g["name"] for g in gesture_labels]
+    q_words = [_clean_str(g["word"].lower()) for g in gesture_labels]
+    open_, spans = [True] * len(q_words), {}
+    for (t_start, t_end), t_word in ((t[0], t[1]) for t in text_times):
+        t_word = _clean_str(t_word.lower())
+        for qi, q_word in enumerate(q_words):
+            if not open_[qi]:
+                continue
+            parts = q_word.split()
+            if q_word == t_word or t_word in parts:
+                spans.setdefault(qi, []).append((t_start, t_end))
+                if q_word == t_word or t_word == parts[-1]:
+                    open_[qi] = False
+                break
+    return {k: (q_words[qi], q_types[qi], min(a for a, _ in sp), max(b for _, b in sp))
+            for k, (qi, sp) in enumerate(spans.items())}
+
+
+def llm_retrieval(gindex, text, text_times, speaker_id, prominence, encoded_text, word_similarity, llm_output):
+    """Same contract as rag/llm_retrieval.py:166-466; `llm_output(text) -> str` replaces get_llm_output (the GPT
+    call: use LLMResponseCache.get), the label alignment is host string work, the DB sweep (type / speaker / word /
+    prominence score), selection and tie-break run on the GPU."""
+    if text.strip() == "":
+        return {}, {}, {}
+    labels = parse_gesture_labels_from_llm_output(llm_output(text))
+    if len(labels) == 0:
+        return {}, {}, {}
+    query_bounds = llm_query_bounds(labels, text_times)
+    if len(query_bounds) == 0:
+        return {}, {}, {}
+    nq = len(query_bounds)
+    q_types, q_words = [query_bounds[i][1] for i in range(nq)], [query_bounds[i][0] for i in range(nq)]
+    q_prom = map_conns_to_prominence(q_words, prominence)
+    proms = [None if q_prom[i] is None else q_prom[i][-1] for i in range(nq)]
+    si, db_b = _gesture_ranked(gindex, [(t, w, speaker_id) for t, w in zip(q_types, q_words)], encoded_text,
+                               word_similarity, 1.0, proms)
+    return si, db_b, query_bounds
+
+
+def _gesture_ranked(gindex, queries, encoded_text, word_similarity, spk_bonus, proms):
     base = gindex.base
     q_dev = encoded_text.to(base.dev).float().contiguous()
-    survivors = gindex.sweep([(g["name"], g["word"], speaker_id) for g in gesture_labels], word_similarity)
+    survivors = gindex.sweep(queries, word_similarity, spk_bonus, proms)
     sims, cut = [], []
-    for qi in range(len(gesture_labels)):
+    for qi in range(len(queries)):
         cut.append(_cut_tiers(base, q_dev, survivors[qi], sims))
     sims_host = [t.cpu().numpy() for t in sims]
+    sample_indexes, d_bounds = {}, {}
     for qi, (tiers, top) in enumerate(cut):
         ranked = _walk_tiers(tiers, sims_host)
         sample_indexes[qi] = [base.names[e] for e in ranked]
@@ -367,7 +443,7 @@ def gesture_type_retrieval(gindex, gesture_labels, speaker_id, encoded_text, wor
         for e in ranked:
             b = gindex.labels[e][int(top[e])]
             d_bounds[qi][base.names[e]] = (b["word"], b["name"], round(b["start"], 3), round(b["end"], 3))
-    return sample_indexes, d_bounds, query_bounds
+    return sample_indexes, d_bounds
 
 
 def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="discourse", fps=15, chunk=15,
@@ -445,7 +521,7 @@ class RetrievalDatabase:
 
     def __init__(self, num_retrieval=None, topk=None, latent_dim=512, text_latent_dim=768, max_seq_len=150,
                  motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", word_similarity=None,
-                 **_cfg):
+                 llm_output=None, **_cfg):
         if metadata is None:
             samples = getattr(dataset, "retrieval_samples", None)
             if samples is None:
@@ -461,26 +537,35 @@ class RetrievalDatabase:
         # rag/utils.py:239-272 (external: `word_similarity(db_word, query_word) -> float`)
         self.gesture_index = GestureTypeIndex(metadata, self.index) if "idx_2_gesture_labels" in metadata else None
         self.word_similarity = word_similarity
+        # llm method: `llm_output(text) -> str` stands for get_llm_output (rag/llm_retrieval.py:69-96, the GPT call);
+        # an LLMResponseCache (cached answers, BASELINE config 5) or any callable
+        self.llm_output = llm_output.get if isinstance(llm_output, LLMResponseCache) else llm_output
         self.test_indexes, self.test_dbounds, self.test_qbounds = {}, {}, {}
         self.phase_ms = None  # dict: MotionDiffusion's phase profiler also collects the sub-phases here
 
     def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None, ready=None,
-                 gesture_labels=None):
+                 gesture_labels=None, text=None, text_times=None):
         """raggesture.py:313-477 (eval branch, first-call behaviour; results cached per idx)."""
-        if retr_method not in ("discourse", "gesture_type"):
-            raise NotImplementedError("the llm retrieval method is not built (discourse and gesture_type are)")
+        if retr_method not in ("discourse", "gesture_type", "llm"):
+            raise NotImplementedError("retrieval method %r (the reference's `prosody` raises too, raggesture.py:431)" % retr_method)
         if idx is not None and idx in self.test_indexes and retr_method in self.test_indexes[idx]:
             si, db_b, qb = (self.test_indexes[idx][retr_method], self.test_dbounds[idx][retr_method],
                             self.test_qbounds[idx][retr_method])
         else:
             if ready is not None:
                 si, db_b, qb = ready
-            elif retr_method == "gesture_type":
+            elif retr_method in ("gesture_type", "llm"):
                 if self.gesture_index is None or self.word_similarity is None:
-                    raise capi.RgError("gesture_type retrieval needs idx_2_gesture_labels in the DB metadata and a "
-                                       "word_similarity callable (rag/utils.py:239 get_word_similarity_score)")
-                si, db_b, qb = gesture_type_retrieval(self.gesture_index, gesture_labels, speaker_id, text_features,
-                                                      self.word_similarity)
+                    raise capi.RgError("%s retrieval needs idx_2_gesture_labels in the DB metadata and a "
+                                       "word_similarity callable (rag/utils.py:239 get_word_similarity_score)" % retr_method)
+                if retr_method == "gesture_type":
+                    si, db_b, qb = gesture_type_retrieval(self.gesture_index, gesture_labels, speaker_id, text_features,
+                                                          self.word_similarity)
+                else:
+                    if self.llm_output is None:
+                        raise capi.RgError("llm retrieval needs `llm_output=` (an LLMResponseCache or a callable text -> answer)")
+                    si, db_b, qb = llm_retrieval(self.gesture_index, text, text_times, speaker_id, prominence, text_features,
+                                                 self.word_similarity, self.llm_output)
             else:
                 si, db_b, qb = discourse_retrieval(self.index, discourse, prominence, speaker_id, text_features)
             self.test_indexes.setdefault(idx, {})[retr_method] = si
@@ -546,7 +631,9 @@ class RetrievalDatabase:
                 ri, rb, qb = self.retrieve(retrieval_method, conditions["text_features"][b], conditions["discourse"][b],
                                            conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None,
                                            ready=ready.get(b),
-                                           gesture_labels=(conditions.get("gesture_labels") or [None] * B)[b])
+                                           gesture_labels=(conditions.get("gesture_labels") or [None] * B)[b],
+                                           text=(conditions.get("text") or [None] * B)[b],
+                                           text_times=(conditions.get("text_times") or [None] * B)[b])
                 plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
                 plans.append((plan, rb, qb))
                 for qp, name, placed in plan:

@@ -330,6 +330,43 @@ def synth_gesture_query(seed, n_labels=2):
     return out
 
 
+LLM_FILLERS = ("well", "i", "think", "the", "was", "really", "and", "then", "we", "went", "it", "is", "like", "a", "of")
+
+
+def synth_llm_query(seed):
+    """One clip for the llm retrieval method: transcript words with timings ((start, end), word) as
+    beatx_dataset's text_times, word prominence, and a canned LLM answer naming two of its gesture words."""
+    g = np.random.Generator(np.random.PCG64(seed + 4242))
+    picks = [GESTURE_WORDS[int(k)] for k in g.choice(len(GESTURE_WORDS), size=3, replace=False)]
+    if seed % 2:
+        picks[0] = "round"
+    words = []
+    for p in picks:
+        words += [LLM_FILLERS[int(g.integers(0, len(LLM_FILLERS)))] for _ in range(int(g.integers(1, 4)))]
+        words += p.split()
+    words += [LLM_FILLERS[int(g.integers(0, len(LLM_FILLERS)))], picks[0].split()[0]]     # a repeated word
+    times, prom, t = [], [], 0.2
+    for w in words:
+        st = t + float(g.uniform(0.0, 0.2))
+        en = st + float(g.uniform(0.15, 0.5))
+        t = en
+        shown = w.capitalize() + "," if g.uniform() < 0.2 else w           # punctuation / case are stripped by the method
+        times.append(((st, en), shown))
+        if g.uniform() < 0.8:
+            prom.append((w, st, en, float(g.uniform(0, 3))))
+    types = [GESTURE_TYPES[1 + int(g.integers(0, 3))] for _ in picks]
+    fmt = seed % 3
+    if fmt == 0:
+        ans = "[(\"%s\", \"%s\"), (\"%s\", \"%s\")]" % (picks[0], types[0], picks[1].title(), types[1])
+    elif fmt == 1:
+        ans = "1. '%s', %s\n2. '%s', %s\n3. 'unicorn', metaphoric" % (picks[1], types[1], picks[0], types[0])
+    else:
+        ans = "(%s, %s), (%s, beat), (%s, %s)" % (picks[2], types[2], words[0], picks[0], types[0])
+    q = synth_query(seed)
+    return dict(text=" ".join(w for _, w in times), text_times=times, prominence=prom, llm_output=ans,
+                speaker_id=q["speaker_id"], text_features=q["text_features"])
+
+
 def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, tie_groups=True, feat_device=None):
     """Raw per-sample records with the fields the reference's DB builder reads
     (raggesture.py:244-293): sample_name, speaker_id, discourse (8-tuples
@@ -370,6 +407,7 @@ def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, t
     # semantic gesture labels (beatx_dataset gesture_labels: name / word / start / end), from a generator of their own
     # so that the fields above (and the goldens pinned on them) do not move
     gl = np.random.Generator(np.random.PCG64(seed + 777))
+    gp = np.random.Generator(np.random.PCG64(seed + 778))
     for i, r in enumerate(recs):
         labels, t = [], 0.1
         for _ in range(int(gl.integers(0, 4))):
@@ -381,6 +419,16 @@ def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, t
         if tie_groups and i % 7 == 0:   # forced ties: same type, same word, same speaker as many other entries
             labels = [dict(name="iconic", word="round", start=1.0, end=1.6)]
         r["gesture_labels"] = labels
+        # prominence of most gesture words (idx_2_gestprom, raggesture.py:270-272); appended behind the connectives'
+        # records: no gesture word is a word of a connective, so idx_2_prominence does not move
+        if not (tie_groups and i % 7 == 0):
+            for lab in labels:
+                if gp.uniform() < 0.7:
+                    words = lab["word"].split()
+                    dur = (lab["end"] - lab["start"]) / len(words)
+                    for wi, w in enumerate(words):
+                        r["prominence"].append((w, lab["start"] + wi * dur, lab["start"] + (wi + 1) * dur,
+                                                float(gp.uniform(0, 3))))
     if feat_device is not None:
         # benchmark-sized DBs: draw all token features with one device-side generator call
         tot = sum(r["text_feature"] for r in recs)

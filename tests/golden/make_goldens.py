@@ -162,6 +162,7 @@ def main():
     run_packing_goldens(ns)
     run_llm_parser_goldens(ns)
     run_gesture_type_goldens(ns)
+    run_llm_retrieval_goldens(ns)
     if "--packing-only" in sys.argv:
         return
 
@@ -329,6 +330,51 @@ def run_gesture_type_goldens(ns):
     with open(os.path.join(HERE, "gesture_type.json"), "w") as f:
         json.dump(gold, f, indent=1)
     print("gesture_type_retrieval oracle == reference on %d queries; result sizes:" % len(gold["queries"]),
+          [[len(v) for v in q["sample_indexes"].values()] for q in gold["queries"]])
+
+
+def run_llm_retrieval_goldens(ns):
+    """rag/llm_retrieval.py:166-466 with get_llm_output replaced by the clip's canned answer (no network) and the
+    word-similarity model by the deterministic stand-in; DB dicts built with the reference's own
+    map_conns_to_prominence (raggesture.py:262-272)."""
+    import json
+    from oracle import retrieval as oret
+    llm = importlib.import_module("mogen.models.transformers.rag.llm_retrieval")
+    samples = synth.synth_retrieval_samples(200, seed=2025)
+    db_text = {s["sample_name"]: (s["text_feature"], s["speaker_id"]) for s in samples}
+    db_labels = {s["sample_name"]: [s["speaker_id"]] + s["gesture_labels"] for s in samples}
+    db_gestprom = {s["sample_name"]: ns.rag_utils.map_conns_to_prominence([g["word"] for g in s["gesture_labels"]],
+                                                                          s["prominence"]) for s in samples}
+    mine = oret.build_db_dicts(samples)
+    assert mine["idx_2_gestprom"] == db_gestprom
+    assert sum(v is not None for d in db_gestprom.values() for v in d.values()) > 100
+    gold = {"queries": []}
+    saved = llm.get_word_similarity_score, llm.get_llm_output
+    try:
+        for simname, sim in (("f64", synth.synth_word_similarity), ("f32", f32_word_similarity)):
+            llm.get_word_similarity_score = sim
+            for qseed in (1, 2, 3, 4, 5, 6):
+                q = synth.synth_llm_query(qseed)
+                answer = {q["text"]: q["llm_output"], "nothing here": "I cannot find any gesture words."}
+                llm.get_llm_output = lambda t: answer[t]
+                for text in ((q["text"], "   ") if qseed == 1 else (q["text"],)):
+                    si, db_b, qb = llm.llm_retrieval(text=text, text_times=q["text_times"], speaker_id=q["speaker_id"],
+                                                     prominence=q["prominence"], db_idx_2_gesture_labels=db_labels,
+                                                     db_idx_2_prominence=db_gestprom, encoded_text=q["text_features"],
+                                                     text_feat_cache=db_text)
+                    osi, odb, oqb = oret.llm_retrieval(text, q["text_times"], q["speaker_id"], q["prominence"], db_labels,
+                                                       mine["idx_2_gestprom"], q["text_features"], db_text, sim,
+                                                       lambda t: answer[t])
+                    assert osi == si and odb == db_b and oqb == qb, "oracle llm retrieval != reference"
+                    gold["queries"].append(dict(seed=qseed, sim=simname, text=text,
+                                                sample_indexes={str(k): v for k, v in si.items()},
+                                                d_bounds={str(k): {n: list(b) for n, b in v.items()} for k, v in db_b.items()},
+                                                query_bounds={str(k): list(v) for k, v in qb.items()}))
+    finally:
+        llm.get_word_similarity_score, llm.get_llm_output = saved
+    with open(os.path.join(HERE, "llm_retrieval.json"), "w") as f:
+        json.dump(gold, f, indent=1)
+    print("llm_retrieval oracle == reference on %d queries; result sizes:" % len(gold["queries"]),
           [[len(v) for v in q["sample_indexes"].values()] for q in gold["queries"]])
 
 

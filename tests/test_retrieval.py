@@ -233,7 +233,7 @@ def test_hip_gesture_type_matches_oracle_large_db(rg):
 
 
 @pytest.mark.gpu
-def test_retrieval_database_gesture_type_method(rg):
+def test_retrieval_database_gesture_type_and_llm_methods(rg):
     """RetrievalDatabase.forward(retrieval_method="gesture_type"): exemplar choice and placement equal the oracle's
     retrieval + placement arithmetic (reduced padding for labels longer than 0.9 s, raggesture.py:628-636)."""
     smp = _db(rg)
@@ -261,3 +261,80 @@ def test_retrieval_database_gesture_type_method(rg):
         plan = oret.place_exemplars(ri, dbb, qb, "gesture_type")
         assert {k: tuple(v[1]) for k, v in plan.items()} == {k: tuple(v) for k, v in re["retr_startends"][b].items()}
         assert {k: tuple(v[2]) for k, v in plan.items()} == {k: tuple(v) for k, v in re["query_startends"][b].items()}
+    # llm method through the same front door: cached answers, text / text_times from the conditions
+    lq = [rg.synth.synth_llm_query(31), rg.synth.synth_llm_query(32)]
+    cache = rg.retrieval.LLMResponseCache()
+    for q in lq:
+        cache.data[q["text"]] = q["llm_output"]
+    rdb = rg.retrieval.RetrievalDatabase(num_retrieval=1, dataset=_FakeDataset(rg, smp), device="cuda",
+                                         word_similarity=rg.synth.synth_word_similarity, llm_output=cache)
+    cond = dict(text_features=[q["text_features"] for q in lq], discourse=[[], []], prominence=[q["prominence"] for q in lq],
+                text=[q["text"] for q in lq], text_times=[q["text_times"] for q in lq], gesture_labels=[[], []],
+                speaker_ids=torch.tensor([[q["speaker_id"]] * 150 for q in lq]))
+    re = rdb(cond, [150] * B, "cuda", idx=["clip_a", "clip_b"], retrieval_method="llm", gesture_rep_encoder=vae)
+    assert cache.hits == 2 and cache.misses == 0
+    for b in range(B):
+        q = lq[b]
+        si, dbb, qb = oret.llm_retrieval(q["text"], q["text_times"], q["speaker_id"], q["prominence"],
+                                         odb["idx_2_gesture_labels"], odb["idx_2_gestprom"], q["text_features"],
+                                         odb["idx_2_text"], rg.synth.synth_word_similarity, cache.get)
+        plan = oret.place_exemplars({k: v[:1] for k, v in si.items()}, dbb, qb, "llm")
+        assert len(plan) > 0
+        assert {k: tuple(v[1]) for k, v in plan.items()} == {k: tuple(v) for k, v in re["retr_startends"][b].items()}
+        assert {k: tuple(v[2]) for k, v in plan.items()} == {k: tuple(v) for k, v in re["query_startends"][b].items()}
+
+
+# ------------------------------------------------------------------ llm retrieval
+def _llm_golden(golden_dir):
+    with open(os.path.join(golden_dir, "llm_retrieval.json")) as f:
+        return json.load(f)["queries"]
+
+
+def test_oracle_llm_retrieval_matches_reference(rg, golden_dir):
+    """oracle/retrieval.py::llm_retrieval against the real reference function (get_llm_output replaced by the clip's
+    canned answer, get_word_similarity_score by the deterministic stand-in; see make_goldens.py)."""
+    smp = _db(rg)
+    db = oret.build_db_dicts(smp)
+    for q in _llm_golden(golden_dir):
+        sim = rg.synth.synth_word_similarity if q["sim"] == "f64" else _f32_sim(rg)
+        qq = rg.synth.synth_llm_query(q["seed"])
+        si, dbb, qb = oret.llm_retrieval(q["text"], qq["text_times"], qq["speaker_id"], qq["prominence"],
+                                         db["idx_2_gesture_labels"], db["idx_2_gestprom"], qq["text_features"],
+                                         db["idx_2_text"], sim, lambda t: qq["llm_output"])
+        gsi, gdb, gqb = _unpack(q)
+        assert si == gsi and dbb == gdb and qb == gqb
+    # product host logic: label alignment == oracle's
+    for seed in range(1, 40):
+        qq = rg.synth.synth_llm_query(seed)
+        labs = oret.parse_gesture_labels_from_llm_output(qq["llm_output"])
+        assert rg.retrieval.llm_query_bounds(labs, qq["text_times"]) == oret.llm_query_bounds(labs, qq["text_times"])[0]
+    assert rg.retrieval.build_db_dicts(smp)["idx_2_gestprom"] == db["idx_2_gestprom"]
+
+
+@pytest.mark.gpu
+def test_hip_llm_retrieval_matches_reference_golden_and_oracle(rg, golden_dir):
+    meta = rg.retrieval.build_db_dicts(_db(rg))
+    gindex = rg.retrieval.GestureTypeIndex(meta, rg.retrieval.DiscourseIndex(meta, "cuda"))
+    for q in _llm_golden(golden_dir):
+        sim = rg.synth.synth_word_similarity if q["sim"] == "f64" else _f32_sim(rg)
+        qq = rg.synth.synth_llm_query(q["seed"])
+        si, dbb, qb = rg.retrieval.llm_retrieval(gindex, q["text"], qq["text_times"], qq["speaker_id"], qq["prominence"],
+                                                 qq["text_features"], sim, lambda t: qq["llm_output"])
+        gsi, gdb, gqb = _unpack(q)
+        assert si == gsi, "llm retrieval indices differ from the reference"
+        assert dbb == gdb and qb == gqb
+    # larger DB against the oracle, answers served from a response cache
+    smp = rg.synth.synth_retrieval_samples(4096, seed=7)
+    db, meta = oret.build_db_dicts(smp), rg.retrieval.build_db_dicts(smp)
+    gindex = rg.retrieval.GestureTypeIndex(meta, rg.retrieval.DiscourseIndex(meta, "cuda"))
+    cache = rg.retrieval.LLMResponseCache(call=None)
+    for seed in range(100, 110):
+        qq = rg.synth.synth_llm_query(seed)
+        cache.data[qq["text"]] = qq["llm_output"]
+        for sim in (rg.synth.synth_word_similarity, _f32_sim(rg)):
+            want = oret.llm_retrieval(qq["text"], qq["text_times"], qq["speaker_id"], qq["prominence"],
+                                      db["idx_2_gesture_labels"], db["idx_2_gestprom"], qq["text_features"],
+                                      db["idx_2_text"], sim, cache.get)
+            got = rg.retrieval.llm_retrieval(gindex, qq["text"], qq["text_times"], qq["speaker_id"], qq["prominence"],
+                                             qq["text_features"], sim, cache.get)
+            assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
