@@ -58,9 +58,12 @@ def map_conns_to_prominence(conn_list, prominence_list):
     return relevant
 
 
-def build_db_dicts(samples):
-    """raggesture.py:255-276: DB dicts from per-sample records (sample_name, speaker_id, discourse,
-    prominence, text_feature), in iteration order."""
+def build_db_dicts(samples, stratified_db_creation=False, stratification_interval=15):
+    """raggesture.py:244-276: DB dicts from per-sample records (sample_name, speaker_id, discourse,
+    prominence, text_feature[, gesture_labels]), in iteration order; with stratified_db_creation only the windows
+    whose in-sequence index (the number behind "/" in sample_name) is a multiple of the interval are kept (:250-255)."""
+    if stratified_db_creation:
+        samples = [smp for smp in samples if int(smp["sample_name"].split("/")[1]) % stratification_interval == 0]
     idx_2_text, idx_2_sense, idx_2_discbounds, idx_2_prominence = {}, {}, {}, {}
     for smp in samples:
         n, spk = smp["sample_name"], int(smp["speaker_id"])
@@ -521,13 +524,13 @@ class RetrievalDatabase:
 
     def __init__(self, num_retrieval=None, topk=None, latent_dim=512, text_latent_dim=768, max_seq_len=150,
                  motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", word_similarity=None,
-                 llm_output=None, **_cfg):
+                 llm_output=None, stratified_db_creation=False, stratification_interval=15, **_cfg):
         if metadata is None:
             samples = getattr(dataset, "retrieval_samples", None)
             if samples is None:
                 raise capi.RgError("RetrievalDatabase needs `metadata=` or `dataset.retrieval_samples` "
                                    "(the reference's LMDB caches cannot be read here: lmdb is not installed)")
-            metadata = build_db_dicts(samples)
+            metadata = build_db_dicts(samples, stratified_db_creation, stratification_interval)
         self.dataset = dataset
         self.num_retrieval, self.topk = num_retrieval or 1, topk
         self.max_seq_len, self.motion_fps, self.motion_framechunksize = max_seq_len, motion_fps, motion_framechunksize

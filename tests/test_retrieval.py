@@ -44,6 +44,11 @@ def test_product_host_logic_matches_oracle(rg):
     a, b = oret.build_db_dicts(smp), rg.retrieval.build_db_dicts(smp)
     assert a["idx_2_prominence"] == b["idx_2_prominence"] and a["idx_2_sense"] == b["idx_2_sense"]
     assert a["idx_2_discbounds"] == b["idx_2_discbounds"]
+    # stratified DB creation (raggesture.py:250-255): windows whose in-sequence index is a multiple of the interval
+    c = rg.retrieval.build_db_dicts(smp, stratified_db_creation=True, stratification_interval=30)
+    keep = [x["sample_name"] for x in smp if int(x["sample_name"].split("/")[1]) % 30 == 0]
+    assert 0 < len(keep) < len(smp) and list(c["idx_2_sense"]) == keep
+    assert all(c["idx_2_prominence"][n] == a["idx_2_prominence"][n] for n in keep)
     g = np.random.Generator(np.random.PCG64(5))
     for _ in range(300):
         ri, rb, qb = {}, {}, {}
