@@ -42,7 +42,19 @@ __device__ int g_dbg_mode = 0;   // bit0: skip MFMA/fragment reads, bit1: skip i
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N <= 63, "vmcnt is a 6-bit counter");
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// wait until at most `younger` tiles (PT DMA instructions each) issued after the current one are still in flight
+template <int PT, int MAXY>
+__device__ __forceinline__ void wait_tiles(int younger) {
+  if constexpr (MAXY <= 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (younger >= MAXY) wait_vmcnt<MAXY * PT>();
+    else wait_tiles<PT, MAXY - 1>(younger);
+  }
 }
 
 // NW = waves per workgroup.  With 4 waves (one per SIMD) a K-tile costs ~1500 cycles although its
@@ -309,10 +321,8 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
   //      -> issue tile t+NS-1 into stage (t-1) % NS -> MFMAs of tile t.
   RG_STAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
-    const int younger = min(NS - 2, nk - 1 - kt);   // tiles issued after tile kt and still allowed in flight
-    if (NS >= 4 && younger >= 2) wait_vmcnt<2 * PER_TILE>();
-    else if (NS >= 3 && younger == 1) wait_vmcnt<PER_TILE>();
-    else wait_vmcnt<0>();
+    const int younger = min(NS - 2, nk - 1 - kt);   // tiles issued after tile kt and still in flight
+    wait_tiles<PER_TILE, NS - 2>(younger);
     __builtin_amdgcn_s_barrier();
 #ifdef RG_STAMPS_LOOP
     if (kt < 40) RG_STAMP(2 + kt);
@@ -363,19 +373,25 @@ void dma_launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
 }
 
 // 64x64 tiles, bf16 A, 4 waves (2x2, 32x32 each), 4-stage ring of 16 KiB; the epilogue tile keeps its 128-column stride
-void dma_launch_narrow(const rg_gemm_desc* d, hipStream_t s) {
+template <int NS>
+void dma_launch_narrow_ns(const rg_gemm_desc* d, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, 4, 4, 64>,
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, NS, 4, 64>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     attr = true;
   }
-  size_t lds = (size_t)4 * (A_TILE + 64 * ROW_BYTES);
+  size_t lds = (size_t)NS * (A_TILE + 64 * ROW_BYTES);
   const size_t epi = (size_t)BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + 63) / 64;
-  hipLaunchKernelGGL((gemm_dma_kernel<true, false, 4, 4, 64>), dim3(mt * nt), dim3(256), lds, s, *d);
+  hipLaunchKernelGGL((gemm_dma_kernel<true, false, NS, 4, 64>), dim3(mt * nt), dim3(256), lds, s, *d);
 }
+
+// Ring depth: 4.  Measured (M = 688..2064, K = 512..2048, graph-replayed chains on rotating operands): a 6-stage
+// 64x128 ring / 8-stage 64x64 ring (a K = 512 panel requested whole before the first MFMA) is 7-10 % SLOWER --
+// the K loop runs at the per-CU LDS-DMA intake (~72 GB/s, 0.34 us per 24.5 KB K-tile), not at the prefetch depth.
+void dma_launch_narrow(const rg_gemm_desc* d, hipStream_t s) { dma_launch_narrow_ns<4>(d, s); }
 
 // ring depth for this descriptor (0: does not fit the 160 KiB LDS at all).  Grids with more
 // workgroups than CUs use a 2-stage ring (<= 80 KiB) so two workgroups share a CU and hide each
