@@ -580,6 +580,18 @@ class RetrievalDatabase:
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
 
+    @staticmethod
+    def _clip_text(conditions, b):
+        """The transcript the llm method prompts with.  The reference hands llm_retrieval conditions["text"]
+        (raggesture.py:501), which MotionDiffusion fills with the frame-aligned word EMBEDDINGS
+        (diffusion_architecture.py:190) -- `text.strip()` cannot run on those; the transcript string is what
+        the same dict carries as "raw_text" (:191), so a non-string "text" falls back to it."""
+        for key in ("text", "raw_text"):
+            v = conditions.get(key)
+            if v is not None and not torch.is_tensor(v) and len(v) > b and isinstance(v[b], str):
+                return v[b]
+        return None
+
     def _tick(self, name):
         """Sub-phase wall times (with device syncs) when a profiler dict is attached; else a no-op."""
         if self.phase_ms is None:
@@ -635,7 +647,7 @@ class RetrievalDatabase:
                                            conditions["prominence"][b], spk, idx=idx[b] if idx is not None else None,
                                            ready=ready.get(b),
                                            gesture_labels=(conditions.get("gesture_labels") or [None] * B)[b],
-                                           text=(conditions.get("text") or [None] * B)[b],
+                                           text=self._clip_text(conditions, b),
                                            text_times=(conditions.get("text_times") or [None] * B)[b])
                 plan = place_exemplars(ri, rb, qb, retrieval_method, self.motion_fps, chunk, self.max_seq_len)
                 plans.append((plan, rb, qb))
