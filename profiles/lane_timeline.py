@@ -1,0 +1,73 @@
+"""Diagnostic: host and device timeline of the graph replays of one guided bench step (lanes, inversion / sampling).
+For every _graph_run call: host time at call and at return (graph launch cost), device start/end from events on the
+stream the graph is replayed on, all relative to the start of the step."""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+rg = importlib.import_module("rag-gesture_amd")
+dev = torch.device("cuda", 0)
+B = 16
+GI = [2] * 25 + [0] * 25
+cfg = rg.synth.default_model_cfg(num_layers=8)
+vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+database = rg.synth.SyntheticDataset(int(os.environ.get("DB", "32768")), seed=2025, device=dev, feat_device=dev)
+model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=database, device=dev)
+model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+model.eval()
+if "LANES" in os.environ:
+    model.lanes = int(os.environ["LANES"])
+data = rg.synth.synth_batch(B, seed=1234, device=dev)
+qs = [rg.synth.synth_query(i) for i in range(B)]
+data["discourse"] = [q["discourse"] for q in qs]
+data["prominence"] = [q["prominence"] for q in qs]
+data["text_features"] = [q["text_features"].to(dev) for q in qs]
+data["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
+trans0 = data["trans"].clone()
+log = []
+orig = model._graph_run
+t_step = [0.0]
+ev_step = [None]
+
+
+def traced(key, inputs, fn):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    h0 = time.perf_counter()
+    e0.record()
+    out = orig(key, inputs, fn)
+    e1.record()
+    log.append((key, (h0 - t_step[0]) * 1e3, (time.perf_counter() - t_step[0]) * 1e3, e0, e1))
+    return out
+
+
+def one_step(trace=False):
+    d = dict(data)
+    d["trans"] = trans0.clone()
+    model.model.database.test_indexes.clear()
+    ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    if trace:
+        log.clear()
+        torch.cuda.synchronize()
+        ev_step[0] = torch.cuda.Event(enable_timing=True)
+        ev_step[0].record()
+        t_step[0] = time.perf_counter()
+    out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
+    t_host = (time.perf_counter() - t_step[0]) * 1e3
+    torch.cuda.synchronize()
+    return t_host, (time.perf_counter() - t_step[0]) * 1e3
+
+
+one_step()
+one_step()
+model._graph_run = traced
+model.model.gesture_rep_encoder.graph_runner = traced
+for rep in range(2):
+    t_host, t_all = one_step(trace=True)
+    print("step: host returns from forward at %.1f ms, device done at %.1f ms (lanes=%d)" % (t_host, t_all, model.lanes))
+    for key, h0, h1, e0, e1 in log:
+        print("   %-44s host call %6.1f -> %6.1f ms | device %6.1f -> %6.1f ms (%.1f)" % (
+            str(key)[:44], h0, h1, ev_step[0].elapsed_time(e0), ev_step[0].elapsed_time(e1), e0.elapsed_time(e1)))

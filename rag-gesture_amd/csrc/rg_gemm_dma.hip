@@ -391,6 +391,8 @@ void dma_launch_narrow_ns(const rg_gemm_desc* d, hipStream_t s) {
 // Ring depth: 4.  Measured (M = 688..2064, K = 512..2048, graph-replayed chains on rotating operands): a 6-stage
 // 64x128 ring / 8-stage 64x64 ring (a K = 512 panel requested whole before the first MFMA) is 7-10 % SLOWER --
 // the K loop runs at the per-CU LDS-DMA intake (~72 GB/s, 0.34 us per 24.5 KB K-tile), not at the prefetch depth.
+// Same for two K-tiles per barrier (ring of 2 / 3 stage pairs: +4..12 % / +-0 %) and for L2-hot operands (-0.5 us per
+// launch at most): neither the barrier count nor the cache level of the source sets the per-tile time.
 void dma_launch_narrow(const rg_gemm_desc* d, hipStream_t s) { dma_launch_narrow_ns<4>(d, s); }
 
 // ring depth for this descriptor (0: does not fit the 160 KiB LDS at all).  Grids with more
