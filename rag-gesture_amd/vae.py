@@ -276,6 +276,26 @@ class GestureRepEncoder:
         self.vae_latent_dim = vae_cfgs["upper"]["latent_dim"]
         self.frame_chunk_size = vae_cfgs["upper"]["frame_chunk_size"]
         self.uj = self.lj = self.fj = self.hj = self.tj = None
+        # the four body-part VAEs are independent launch chains of small kernels: each runs on a stream of its own
+        # (forked from / joined into the caller's stream, also inside a graph capture) -- RG_VAE_STREAMS=0: one chain
+        self.part_streams = ([torch.cuda.Stream(device=self.dev) for _ in PARTS]
+                             if os.environ.get("RG_VAE_STREAMS", "1") != "0" else None)
+
+    def _fan_out(self, jobs):
+        """Run the per-part jobs (callables) concurrently: job i on part stream i, all ordered after the work already
+        queued on the current stream, which in turn waits for all of them.  Tensors that cross the fork or the join
+        are allocated on the current stream by the caller; everything a job allocates stays on its stream."""
+        if self.part_streams is None:
+            for job in jobs:
+                job()
+            return
+        cur = torch.cuda.current_stream()
+        for st, job in zip(self.part_streams, jobs):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                job()
+        for st in self.part_streams[:len(jobs)]:
+            cur.wait_stream(st)
 
     def _aa6d(self, aa, out, col_off, joints):
         B, n, c = aa.shape
@@ -334,8 +354,9 @@ class GestureRepEncoder:
         n_lat = n // self.frame_chunk_size
         T, D = 4 * n_lat + 3, self.vae_latent_dim
         latent = torch.zeros(B, T, D, device=dev)  # separator rows stay zero
-        for i, (part, feats) in enumerate((("upper", in_up), ("hands", in_ha), ("face", in_fa), ("lowertrans", in_lt))):
-            self.vaes[part].encode_to_latent(feats, eps_list[i], latent, i * (n_lat + 1))
+        self._fan_out([lambda i=i, part=part, feats=feats: self.vaes[part].encode_to_latent(
+            feats, eps_list[i], latent, i * (n_lat + 1))
+            for i, (part, feats) in enumerate((("upper", in_up), ("hands", in_ha), ("face", in_fa), ("lowertrans", in_lt)))])
         return latent, tr_rel
 
     def decode(self, z_output):
@@ -343,26 +364,33 @@ class GestureRepEncoder:
         B, T, D = z_output.shape
         n_lat = (T - 3) // 4
         z = z_output.contiguous()
-        dec = {part: self.vaes[part].decode_latent(z, i * (n_lat + 1), n_lat) for i, part in enumerate(PARTS)}
         F_ = self.vaes["upper"].frames
         rows = B * F_
+        new = lambda width: torch.empty(B, F_, width, device=self.dev)   # outputs: allocated before the fork
+        upper, hands, face, lower = new(self.uj * 3), new(self.hj * 3), new(self.fj * 3), new(self.lj * 3)
+        n_exp = self.vaes["face"].nfeats - self.fj * 6
+        n_con = self.vaes["lowertrans"].nfeats - self.lj * 6 - self.tj
+        exps, transl, contact = new(n_exp), new(self.tj), new(n_con)
 
-        def aa(src, col_off, joints):
-            out = torch.empty(B, F_, joints * 3, device=self.dev)
-            self.h.call("6d_to_aa", src, src.shape[-1], col_off, out, joints * 3, rows, joints)
-            return out
+        def aa(src, out, joints):
+            self.h.call("6d_to_aa", src, src.shape[-1], 0, out, joints * 3, rows, joints)
 
-        def cols(src, c0, nc):
-            out = torch.empty(B, F_, nc, device=self.dev)
-            self.h.call("copy_cols", src, src.shape[-1], c0, out, nc, 0, rows, nc, 0, 0)
-            return out
+        def cols(src, c0, out):
+            self.h.call("copy_cols", src, src.shape[-1], c0, out, out.shape[-1], 0, rows, out.shape[-1], 0, 0)
 
-        upper = aa(dec["upper"], 0, self.uj)
-        hands = aa(dec["hands"], 0, self.hj)
-        face = aa(dec["face"], 0, self.fj)
-        exps = cols(dec["face"], self.fj * 6, dec["face"].shape[-1] - self.fj * 6)
-        lt = dec["lowertrans"]
-        lower = aa(lt, 0, self.lj)
-        transl = cols(lt, self.lj * 6, self.tj)
-        contact = cols(lt, self.lj * 6 + self.tj, lt.shape[-1] - self.lj * 6 - self.tj)
+        def job(i, part):
+            d = self.vaes[part].decode_latent(z, i * (n_lat + 1), n_lat)
+            if part == "upper":
+                aa(d, upper, self.uj)
+            elif part == "hands":
+                aa(d, hands, self.hj)
+            elif part == "face":
+                aa(d, face, self.fj)
+                cols(d, self.fj * 6, exps)
+            else:
+                aa(d, lower, self.lj)
+                cols(d, self.lj * 6, transl)
+                cols(d, self.lj * 6 + self.tj, contact)
+
+        self._fan_out([lambda i=i, part=part: job(i, part) for i, part in enumerate(PARTS)])
         return upper, lower, face, hands, transl, exps, contact
