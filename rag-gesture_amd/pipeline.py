@@ -208,6 +208,24 @@ class MotionDiffusion:
             self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B)
         return self._sessions[key]
 
+    def _set_conditions(self, B, role, lane, word, audio, speaker_ids, motion_mask, query_masks):
+        """DenoiserSession.set_conditions through the graph cache: its ~55 launches (pre-projections, per-layer K/V
+        GEMMs and reductions) cost the host ~1.2 ms when issued one by one, and the exemplars' call sits between
+        their VAE encode and the inversion loop, where the device would wait for it."""
+        sess, dev = self._session(B, role, lane), self.model.weights.dev
+        ins = dict(word=word.to(dev).float(), audio=audio.to(dev).float(), spk=speaker_ids.to(dev).long(),
+                   mask=motion_mask.to(dev).float())
+        for c in denoiser.CONDS:
+            ins["q_" + c] = query_masks[c].to(dev).float()
+
+        def run(st):
+            sess.set_conditions(st["word"], st["audio"], st["spk"], st["mask"], {c: st["q_" + c] for c in denoiser.CONDS})
+            return ()
+
+        self._graph_run(("cond", B, role, lane, tuple(ins["word"].shape), tuple(ins["audio"].shape),
+                         tuple(ins["spk"].shape)), ins, run)
+        return sess
+
     def _concurrent_streams(self, n):
         """n HIP streams that really run concurrently.  ROCm multiplexes streams onto a few hardware queues
         (4 by default) and two streams on the same queue serialise -- observed for the first two side streams of
@@ -316,8 +334,8 @@ class MotionDiffusion:
             for lane, stream, b0, b1 in plan:
                 stream.wait_stream(main)
                 with torch.cuda.stream(stream):
-                    self._session(b1 - b0, "sample", lane).set_conditions(
-                        word[b0:b1], audio[b0:b1], spk[b0:b1], motion_mask[b0:b1], {c: qmask[b0:b1] for c in denoiser.CONDS})
+                    self._set_conditions(b1 - b0, "sample", lane, word[b0:b1], audio[b0:b1], spk[b0:b1],
+                                         motion_mask[b0:b1], {c: qmask[b0:b1] for c in denoiser.CONDS})
         with self._phase("vae_encode"):
             motion, tr_rel = gre.encode_device_graphed(
                 f(kwargs["motion_upper"]), f(kwargs["motion_lower"]), f(kwargs["motion_face"]), f(kwargs["motion_hands"]),
@@ -329,7 +347,7 @@ class MotionDiffusion:
         retrieval_dict = kwargs.get("re_dict")
         early_cond = {}   # lane -> number of exemplars whose conditions were already projected
 
-        def exemplar_conditions_early(ex, recs):
+        def exemplar_conditions_early(ex, recs, fork):
             """Called by RetrievalDatabase.forward once the exemplars are known, before it VAE-encodes them: their
             K/V projections (text / audio / speaker of the retrieved samples) go to the lane streams meanwhile."""
             if not use_inversion or getattr(self, "profile_phases", False):
@@ -338,12 +356,11 @@ class MotionDiffusion:
                 sel = [e for e, (b, _, _, placed) in enumerate(ex) if placed is not None and b0 <= b < b1]
                 if not sel:
                     continue
-                stream.wait_stream(main)
+                stream.wait_event(fork)   # main's state before the exemplar VAE encode was queued
                 with torch.cuda.stream(stream):
                     st = lambda k: torch.stack([recs[e][k] for e in sel]).to(dev)
-                    esess = self._session(len(sel), "invert", lane)
                     eqm = {c: torch.stack([qmask[ex[e][0]] for e in sel]) for c in denoiser.CONDS}
-                    esess.set_conditions(st("word").float(), st("audio").float(), st("speaker_id"),
+                    self._set_conditions(len(sel), "invert", lane, st("word"), st("audio"), st("speaker_id"),
                                          gre.latent_mask(st("motion_mask").float()), eqm)
                 early_cond[lane] = len(sel)
 
@@ -388,14 +405,18 @@ class MotionDiffusion:
         if need_noise:
             # the reference draws randn_like(in_seq) then randn_like(x) on every step (the latter is
             # multiplied by sigma = 0); keep the tape aligned
-            inseq_noise = torch.empty(S, B, T, D, device=dev)
             first = S - 1
             cur_has = in_seq is not None
-            for i in range(S - 1, -1, -1):
-                has = cur_has if i == first or not use_insertion_guidance else True
-                if has:
-                    inseq_noise[i].copy_(tape.draw((B, T, D)).to(dev))
-                tape.draw((B, T, D)) if not isinstance(tape, _TorchNoise) else None
+            if isinstance(tape, _TorchNoise):
+                # generator noise: which draw lands on which step is immaterial -> one launch for all steps
+                inseq_noise = tape.draw((S, B, T, D))
+            else:
+                inseq_noise = torch.empty(S, B, T, D, device=dev)
+                for i in range(S - 1, -1, -1):
+                    has = cur_has if i == first or not use_insertion_guidance else True
+                    if has:
+                        inseq_noise[i].copy_(tape.draw((B, T, D)).to(dev))
+                    tape.draw((B, T, D))
         elif not isinstance(tape, _TorchNoise):
             for _ in range(S):
                 tape.draw((B, T, D))
@@ -417,8 +438,8 @@ class MotionDiffusion:
                         with self._phase("exemplar_conditions"):
                             if early_cond.get(lane) != E:   # not already projected while the exemplars were encoded
                                 eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
-                                esess.set_conditions(cat("retr_text").float(), cat("retr_audio").float(), cat("retr_spkid"),
-                                                     cat("retr_motion_mask").float(), eqm)
+                                self._set_conditions(E, "invert", lane, cat("retr_text"), cat("retr_audio"), cat("retr_spkid"),
+                                                     cat("retr_motion_mask"), eqm)
                             x_e = cat("retr_motion_latent").float().contiguous()
                         with self._phase("inversion"):
                             (inv,) = self._graph_run(("invert", E, lane), dict(x=x_e), lambda s, esess=esess, E=E: (
@@ -434,6 +455,12 @@ class MotionDiffusion:
                     if use_insertion_guidance and use_prev_latent and prev_latent is not None:
                         for idx in (up_i, ha_i, fa_i, lt_i):
                             invl[:, b0:b1, idx[0], :] = 0
+        # second pass: the sampling loops.  Every lane's inversion is queued before the first sampling graph is
+        # launched (a graph launch costs the host ~1.5 ms: lane 1 would otherwise start 3 ms behind lane 0)
+        for lane, stream, b0, b1 in plan:
+            Bl = b1 - b0
+            sess = self._session(Bl, "sample", lane)
+            with torch.cuda.stream(stream):
                 sl = lambda t, dim: None if t is None else (t[b0:b1] if dim == 0 else t[:, b0:b1])
                 loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(inseq_noise, 1), invl=sl(invl, 1))
                 with self._phase("sampling"):

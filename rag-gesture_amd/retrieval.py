@@ -656,10 +656,6 @@ class RetrievalDatabase:
         tick("retrieval.search")
         # ---- fetch + VAE-encode every visited exemplar in one batch (noise in the reference's order)
         recs = [self.dataset[name] for _, _, name, _ in ex]
-        if on_exemplars is not None and ex:
-            # the caller may start work that needs the exemplars' conditioning only (their K/V projections)
-            # on other streams while this stream VAE-encodes their motion
-            on_exemplars(ex, recs)
         lat = None
         if ex:
             E = len(ex)
@@ -670,8 +666,15 @@ class RetrievalDatabase:
                 eps_list = [torch.cat([e[p].to(dev) for e in eps], dim=0) for p in range(4)]
             else:
                 eps_list = [torch.randn(E * L, 1, D, device=dev) for _ in range(4)]  # generator noise: order is immaterial
+            fork = torch.cuda.Event()     # work started by on_exemplars orders itself after this point, not after the encode
+            fork.record()
             lat, _ = gre.encode(stack("motion_upper"), stack("motion_lower"), stack("motion_face"), stack("motion_hands"),
                                 stack("trans"), stack("facial"), stack("contact"), stack("motion_mask"), eps_list)
+        if on_exemplars is not None and ex:
+            # the caller may start work that needs the exemplars' conditioning only (their K/V projections) on other
+            # streams while this stream VAE-encodes their motion; the encode (one graph launch) is queued first so
+            # that the device is not left waiting for the host to issue the projections' launches
+            on_exemplars(ex, recs, fork)
         tick("retrieval.exemplar_encode")
         retr_se, query_se, retr_lats, names_out, type2words = ([{} for _ in range(B)] for _ in range(5))
         zero_motion = torch.zeros(B, T, D, device=dev)
@@ -682,7 +685,7 @@ class RetrievalDatabase:
         # all row copies of the exemplar canvases are gathered into index lists and issued as one gather/scatter
         # per tensor (a guided batch has ~50 exemplars x 7 small copies otherwise); later spans overwrite earlier
         # ones exactly as the reference's sequential slice assignments do (index_copy_ with unique keys)
-        lat_copy, frame_copy = {}, {}
+        lat_dst, lat_src, frame_dst, frame_src = [], [], [], []
         lmask = gre.latent_mask(torch.stack([r["motion_mask"] for r in recs])) if ex else None
         for e, (b, qp, name, placed) in enumerate(ex):
             if placed is None:
@@ -694,22 +697,28 @@ class RetrievalDatabase:
                                     retr_audio=rec["audio"].unsqueeze(0).to(dev),
                                     retr_spkid=rec["speaker_id"].unsqueeze(0).to(dev),
                                     retr_motion_mask=lmask[e:e + 1])
+            span = np.arange(s1 - s0)
             for part in range(4):
                 o = part * (L + 1)
-                for i in range(s1 - s0):
-                    lat_copy[b * T + o + s0 + i] = e * T + o + r0 + i
-            f0, g0 = s0 * chunk, r0 * chunk
-            for i in range((s1 - s0) * chunk):
-                frame_copy[b * self.max_seq_len + f0 + i] = e * self.max_seq_len + g0 + i
+                lat_dst.append(b * T + o + s0 + span)
+                lat_src.append(e * T + o + r0 + span)
+            frames = np.arange((s1 - s0) * chunk)
+            frame_dst.append(b * self.max_seq_len + s0 * chunk + frames)
+            frame_src.append(e * self.max_seq_len + r0 * chunk + frames)
             q_word, q_type = qb[qp][0], qb[qp][1]
             r_word, r_type = rb[qp][name][0], rb[qp][name][1]
             type2words[b][qp] = (q_word, q_type, r_word, r_type)
             names_out[b][q_word] = name
-        if lat_copy:
-            idx = lambda d: (torch.tensor(list(d.keys()), device=dev), torch.tensor(list(d.values()), device=dev))
-            dst, src = idx(lat_copy)
+        if lat_dst:
+            def idx(dst, src):
+                # a row written twice keeps its LAST source (sequential slice assignment); index_copy_ needs unique keys
+                dst, src = np.concatenate(dst), np.concatenate(src)
+                _, last = np.unique(dst[::-1], return_index=True)
+                keep = len(dst) - 1 - last
+                return torch.from_numpy(dst[keep]).to(dev), torch.from_numpy(src[keep]).to(dev)
+            dst, src = idx(lat_dst, lat_src)
             zero_motion.view(B * T, D).index_copy_(0, dst, lat.reshape(E * T, D).index_select(0, src))
-            dst, src = idx(frame_copy)
+            dst, src = idx(frame_dst, frame_src)
             for canvas, key in ((raw_motion, "motion"), (raw_trans, "trans"), (raw_facial, "facial")):
                 allrec = torch.stack([r[key] for r in recs]).to(dev).float()
                 canvas.view(B * self.max_seq_len, -1).index_copy_(0, dst, allrec.view(E * self.max_seq_len, -1).index_select(0, src))
