@@ -330,6 +330,13 @@ int rg_discourse_scores(rg_handle* h, const int* spk, const int* rel_off, const 
                         const int* rel_conn, const double* rel_prom, int n_entries, int q_sense, int q_conn,
                         int q_spk, double q_prom, double* score_out, int* top_out, void* stream);
 
+/* rg_discourse_scores for all queries of a batch in ONE launch: params[q] = (sense code, connective code, speaker id,
+ * query prominence or NaN) as four doubles (the integer codes are exact); score_out / top_out are
+ * [n_queries][n_entries].  Replaces the per-query loop over raggesture.py:498-511 -> discourse_retrieval. */
+int rg_discourse_scores_batched(rg_handle* h, const int* spk, const int* rel_off, const int* rel_sense,
+                                const int* rel_conn, const double* rel_prom, int n_entries, const double* params,
+                                int n_queries, double* score_out, int* top_out, void* stream);
+
 /* Score of every DB entry for ONE query gesture label (type, word) of the gesture_type retrieval method
  * (rag/gesture_type_retrieval.py:41-117) and of the llm method (rag/llm_retrieval.py:278-419), float64: over the
  * entry's non-beat labels of the query type (CSR lab_off / lab_type / lab_word, words integer coded): +2 type present,
@@ -354,6 +361,11 @@ int rg_gesture_scores(rg_handle* h, const int* spk, const int* lab_off, const in
 int rg_select_top_scores(rg_handle* h, const double* score, const int* top, int n_entries, double* workspace,
                          int* cursor, int cap, int* out_idx, int* out_top, double* out_score, void* stream);
 int rg_select_workspace_doubles(int n_entries);
+/* The same for n_queries score rows at once (three launches in all): score / top [n_queries][n_entries], workspace
+ * [n_queries][rg_select_workspace_doubles(n)], cursor [n_queries], out_* [n_queries][cap]. */
+int rg_select_top_scores_batched(rg_handle* h, const double* score, const int* top, int n_entries, int n_queries,
+                                 double* workspace, int* cursor, int cap, int* out_idx, int* out_top,
+                                 double* out_score, void* stream);
 
 /* Tie-break similarity (rag/utils.py:109-121): out[j] = mean_{i < min(Lq, L_c)} q[i,:].feats_c[i,:]
  * for candidate entries c = cand[j]; feats is the ragged [sum L, dim] fp32 token-feature table with

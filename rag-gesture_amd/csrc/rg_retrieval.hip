@@ -15,12 +15,10 @@
 
 namespace {
 
-__global__ void __launch_bounds__(256) discourse_scores_kernel(
-    const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
-    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int n_entries, int q_sense, int q_conn,
+__device__ __forceinline__ void discourse_score_entry(
+    const int e, const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
+    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int q_sense, int q_conn,
     int q_spk, double q_prom, double* __restrict__ score_out, int* __restrict__ top_out) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= n_entries) return;
   const int r0 = rel_off[e], r1 = rel_off[e + 1];
   double score = 0.0;
   int top = -1;
@@ -65,6 +63,30 @@ __global__ void __launch_bounds__(256) discourse_scores_kernel(
   }
   score_out[e] = score;
   top_out[e] = top;
+}
+
+
+__global__ void __launch_bounds__(256) discourse_scores_kernel(
+    const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
+    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int n_entries, int q_sense, int q_conn,
+    int q_spk, double q_prom, double* __restrict__ score_out, int* __restrict__ top_out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_entries) return;
+  discourse_score_entry(e, spk, rel_off, rel_sense, rel_conn, rel_prom, q_sense, q_conn, q_spk, q_prom, score_out, top_out);
+}
+
+// all queries of a batch in one launch: blockIdx.y = query; params[q] = (sense, connective, speaker, prominence) as
+// doubles (the integer codes are exact), outputs [n_queries][n_entries]
+__global__ void __launch_bounds__(256) discourse_scores_batched_kernel(
+    const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
+    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int n_entries,
+    const double* __restrict__ params, double* __restrict__ score_out, int* __restrict__ top_out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_entries) return;
+  const double* qp = params + 4 * blockIdx.y;
+  const size_t o = (size_t)blockIdx.y * n_entries;
+  discourse_score_entry(e, spk, rel_off, rel_sense, rel_conn, rel_prom, (int)qp[0], (int)qp[1], (int)qp[2], qp[3],
+                        score_out + o, top_out + o);
 }
 
 // rag/gesture_type_retrieval.py:41-117 for one query label (type, word): per DB entry, over its non-beat labels of
@@ -223,9 +245,13 @@ __device__ __forceinline__ void block_top_rounds(double (&v)[SEL_IPT], double* r
   }
 }
 
+// blockIdx.y = query of a batched selection (strides in elements; 0 for a single query)
 __global__ void __launch_bounds__(256) topk_local_kernel(const double* __restrict__ score, int n,
-                                                        double* __restrict__ block_tops) {
+                                                        double* __restrict__ block_tops, size_t score_stride,
+                                                        size_t ws_stride) {
   __shared__ double red[4];
+  score += blockIdx.y * score_stride;
+  block_tops += blockIdx.y * ws_stride;
   const int per_block = 256 * SEL_IPT;
   double v[SEL_IPT], tops[SEL_K];
 #pragma unroll
@@ -240,8 +266,11 @@ __global__ void __launch_bounds__(256) topk_local_kernel(const double* __restric
 
 __global__ void __launch_bounds__(256) topk_merge_kernel(const double* __restrict__ block_tops, int n_lists,
                                                         int n_entries, double* __restrict__ threshold,
-                                                        int* __restrict__ cursor) {
+                                                        int* __restrict__ cursor, size_t ws_stride) {
   __shared__ double red[4];
+  block_tops += blockIdx.y * ws_stride;
+  threshold += blockIdx.y * ws_stride;
+  cursor += blockIdx.y;
   // the 10th largest score lies among the per-block top-10 lists; fold them 1024 at a time
   double carry[SEL_K];
   for (int r = 0; r < SEL_K; ++r) carry[r] = -1.0;
@@ -275,9 +304,17 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(const double* __restric
 __global__ void __launch_bounds__(256) compact_kernel(const double* __restrict__ score, const int* __restrict__ top,
                                                      int n, const double* __restrict__ threshold,
                                                      int* __restrict__ cursor, int cap, int* __restrict__ out_idx,
-                                                     int* __restrict__ out_top, double* __restrict__ out_score) {
+                                                     int* __restrict__ out_top, double* __restrict__ out_score,
+                                                     size_t score_stride, size_t ws_stride) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  score += blockIdx.y * score_stride;
+  top += blockIdx.y * score_stride;
+  threshold += blockIdx.y * ws_stride;
+  cursor += blockIdx.y;
+  out_idx += (size_t)blockIdx.y * cap;
+  out_top += (size_t)blockIdx.y * cap;
+  out_score += (size_t)blockIdx.y * cap;
   const double s = score[e];
   if (s >= *threshold && s > 0.0) {
     const int pos = atomicAdd(cursor, 1);
@@ -291,21 +328,37 @@ __global__ void __launch_bounds__(256) compact_kernel(const double* __restrict__
 
 }  // namespace
 
+static int select_launch(rg_handle* h, const double* score, const int* top, int n_entries, int n_queries,
+                         double* workspace, int* cursor, int cap, int* out_idx, int* out_top, double* out_score,
+                         void* stream) {
+  const int nb = (n_entries + 256 * SEL_IPT - 1) / (256 * SEL_IPT);
+  const size_t ws_stride = (size_t)nb * SEL_K + 1, sc_stride = (size_t)n_entries;
+  hipStream_t s = rg_stream(stream);
+  // workspace per query: [nb * 10] per-block tops, then the threshold
+  hipLaunchKernelGGL(topk_local_kernel, dim3(nb, n_queries), dim3(256), 0, s, score, n_entries, workspace, sc_stride,
+                     ws_stride);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(1, n_queries), dim3(256), 0, s, workspace, nb, n_entries,
+                     workspace + nb * SEL_K, cursor, ws_stride);
+  hipLaunchKernelGGL(compact_kernel, dim3((n_entries + 255) / 256, n_queries), dim3(256), 0, s, score, top, n_entries,
+                     workspace + nb * SEL_K, cursor, cap, out_idx, out_top, out_score, sc_stride, ws_stride);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
 extern "C" int rg_select_top_scores(rg_handle* h, const double* score, const int* top, int n_entries,
                                     double* workspace, int* cursor, int cap, int* out_idx, int* out_top,
                                     double* out_score, void* stream) {
   RG_REQUIRE(h, score && top && workspace && cursor && out_idx && out_top && out_score, "null pointer");
   RG_REQUIRE(h, n_entries > 0 && cap > 0, "bad shape");
-  const int nb = (n_entries + 256 * SEL_IPT - 1) / (256 * SEL_IPT);
-  hipStream_t s = rg_stream(stream);
-  // workspace: [nb * 10] per-block tops, then the threshold
-  hipLaunchKernelGGL(topk_local_kernel, dim3(nb), dim3(256), 0, s, score, n_entries, workspace);
-  hipLaunchKernelGGL(topk_merge_kernel, dim3(1), dim3(256), 0, s, workspace, nb, n_entries, workspace + nb * SEL_K,
-                     cursor);
-  hipLaunchKernelGGL(compact_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, s, score, top, n_entries,
-                     workspace + nb * SEL_K, cursor, cap, out_idx, out_top, out_score);
-  RG_CHECK_LAUNCH(h);
-  return RG_OK;
+  return select_launch(h, score, top, n_entries, 1, workspace, cursor, cap, out_idx, out_top, out_score, stream);
+}
+
+extern "C" int rg_select_top_scores_batched(rg_handle* h, const double* score, const int* top, int n_entries,
+                                            int n_queries, double* workspace, int* cursor, int cap, int* out_idx,
+                                            int* out_top, double* out_score, void* stream) {
+  RG_REQUIRE(h, score && top && workspace && cursor && out_idx && out_top && out_score, "null pointer");
+  RG_REQUIRE(h, n_entries > 0 && cap > 0 && n_queries > 0 && n_queries <= 65535, "bad shape");
+  return select_launch(h, score, top, n_entries, n_queries, workspace, cursor, cap, out_idx, out_top, out_score, stream);
 }
 
 extern "C" int rg_select_workspace_doubles(int n_entries) {
@@ -321,6 +374,18 @@ extern "C" int rg_discourse_scores(rg_handle* h, const int* spk, const int* rel_
   hipLaunchKernelGGL(discourse_scores_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, rg_stream(stream), spk,
                      rel_off, rel_sense, rel_conn, rel_prom, n_entries, q_sense, q_conn, q_spk, q_prom, score_out,
                      top_out);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_discourse_scores_batched(rg_handle* h, const int* spk, const int* rel_off, const int* rel_sense,
+                                           const int* rel_conn, const double* rel_prom, int n_entries,
+                                           const double* params, int n_queries, double* score_out, int* top_out,
+                                           void* stream) {
+  RG_REQUIRE(h, spk && rel_off && rel_sense && rel_conn && rel_prom && params && score_out && top_out, "null pointer");
+  RG_REQUIRE(h, n_entries > 0 && n_queries > 0 && n_queries <= 65535, "bad shape");
+  hipLaunchKernelGGL(discourse_scores_batched_kernel, dim3((n_entries + 255) / 256, n_queries), dim3(256), 0,
+                     rg_stream(stream), spk, rel_off, rel_sense, rel_conn, rel_prom, n_entries, params, score_out, top_out);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

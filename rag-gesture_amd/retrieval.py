@@ -146,21 +146,22 @@ class DiscourseIndex:
         o_top = torch.empty(Q, cap, dtype=torch.int32, device=self.dev)
         o_score = torch.empty(Q, cap, dtype=torch.float64, device=self.dev)
         s = torch.cuda.current_stream().cuda_stream
-        for q, (sense, conn, speaker_id, q_prom) in enumerate(queries):
-            rc = lib.rg_discourse_scores(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
-                                         vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
-                                         vp(self.rel_prom.data_ptr()), n, self.sense_code.get(sense, -2),
-                                         self.conn_code.get(conn, -1), int(speaker_id),
-                                         ctypes.c_double(float("nan") if q_prom is None else float(q_prom)),
-                                         vp(score[q].data_ptr()), vp(top[q].data_ptr()), vp(s))
-            if rc == 0:
-                rc = lib.rg_select_top_scores(self.h._h, vp(score[q].data_ptr()), vp(top[q].data_ptr()), n,
-                                              vp(ws[q].data_ptr()), vp(cursor[q:].data_ptr()), cap,
-                                              vp(o_idx[q].data_ptr()), vp(o_top[q].data_ptr()),
-                                              vp(o_score[q].data_ptr()), vp(s))
-            if rc != 0:
-                raise capi.RgError("retrieval sweep failed: %s" % lib.rg_last_error(self.h._h).decode())
-        return dict(cursor=cursor, idx=o_idx, top=o_top, score=o_score, keep=(score, top, ws))
+        nan = float("nan")
+        params = torch.tensor([[float(self.sense_code.get(sense, -2)), float(self.conn_code.get(conn, -1)), float(int(spk)),
+                                nan if q_prom is None else float(q_prom)] for sense, conn, spk, q_prom in queries],
+                              dtype=torch.float64).to(self.dev, non_blocking=True)
+        # one sweep launch and one three-launch selection for the whole batch of queries
+        rc = lib.rg_discourse_scores_batched(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
+                                             vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
+                                             vp(self.rel_prom.data_ptr()), n, vp(params.data_ptr()), Q,
+                                             vp(score.data_ptr()), vp(top.data_ptr()), vp(s))
+        if rc == 0:
+            rc = lib.rg_select_top_scores_batched(self.h._h, vp(score.data_ptr()), vp(top.data_ptr()), n, Q,
+                                                  vp(ws.data_ptr()), vp(cursor.data_ptr()), cap, vp(o_idx.data_ptr()),
+                                                  vp(o_top.data_ptr()), vp(o_score.data_ptr()), vp(s))
+        if rc != 0:
+            raise capi.RgError("retrieval sweep failed: %s" % lib.rg_last_error(self.h._h).decode())
+        return dict(cursor=cursor, idx=o_idx, top=o_top, score=o_score, keep=(score, top, ws, params))
 
     @staticmethod
     def collect(ticket):
