@@ -78,6 +78,19 @@ __device__ __forceinline__ void qa_and_store(float* sq, const float (&Areg)[HD],
 
 // MFMA_ = false: exact fp32 VALU products (precision = "fp32" path);  true: both products on the matrix
 // cores with bf16 hi + lo operand pairs and fp32 accumulation (~2^-17 relative per product).
+#ifdef RG_STAMPS
+// Diagnostic build only (RG_DIAG=1 -> librg_gesture_diag.so): wall-clock stamps (100 MHz) of the phases of wave 0 of
+// workgroup 0 of the attention kernels; no output depends on them.
+__device__ unsigned long long* g_stamp_buf3 = nullptr;
+#define RG_STAMP3(slot)                                                                   \
+  do {                                                                                    \
+    if (g_stamp_buf3 && threadIdx.x == 0 && blockIdx.x == 0)                              \
+      g_stamp_buf3[slot] = __builtin_amdgcn_s_memrealtime();                              \
+  } while (0)
+#else
+#define RG_STAMP3(slot)
+#endif
+
 template <bool MFMA_>
 __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
                                                           const float* __restrict__ src_mask, float* __restrict__ y,
@@ -87,6 +100,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // perm: block -> work item, so that a row group is processed on the XCD whose L2 holds its rows
   // (the GEMMs put M-tile t on XCD t % 8); -1 = padding block
+  RG_STAMP3(0);
   const int item = perm ? perm[blockIdx.x] : (int)blockIdx.x;
   if (item < 0) return;
   const int b = item / (D / (HD * WAVES));
@@ -113,23 +127,33 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
       __builtin_amdgcn_global_load_lds((const void*)rp, (lds_void*)(sq + r0 * HD), 16, 0, 0);
     }
   }
-  for (int n = threadIdx.x; n < T; n += 256) smask[n] = src_mask[(size_t)b * T + n];
+  RG_STAMP3(1);
+  // token validity as a wave-uniform bit set (bit n: token n takes part); a wave touches only its own q/k/v tiles,
+  // so no workgroup barrier is needed before the softmax
+  const unsigned long long vbits = __ballot(lane < T && src_mask[(size_t)b * T + (lane < T ? lane : 0)] != 0.f);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const float* mrow = smask;
+  RG_STAMP3(2);
+  __builtin_amdgcn_wave_barrier();
+  RG_STAMP3(3);
 
   // softmax over tokens for column d = lane&31; the two half-waves split the tokens.  The column
-  // lives in registers (one batch of independent LDS reads instead of three dependent sweeps)
+  // lives in registers: ONE batch of independent, unconditional LDS reads (rows are clamped into the tile and
+  // deselected by the bit set -- a guarded read would serialise into read / wait / branch per token)
   {
     const int d = lane & 31, half = lane >> 5;
     constexpr int NH = TMAX / 2;
     float kr[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int n = half + 2 * i;
+      kr[i] = sk[(n < Tp ? n : Tp - 1) * HD + d];
+    }
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
       const int n = half + 2 * i;
       // key + (1-mask)*-1e6: a masked token's weight underflows to exactly 0 in fp32
-      kr[i] = (n < T && mrow[n] != 0.f) ? sk[n * HD + d] : -INFINITY;
+      kr[i] = ((vbits >> n) & 1ull) ? kr[i] : -INFINITY;
       mx = fmaxf(mx, kr[i]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -149,6 +173,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS writes have landed
   __builtin_amdgcn_wave_barrier();
+  RG_STAMP3(4);
   if constexpr (MFMA_) {
     typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
     typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -180,9 +205,15 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int n = 32 * ks + 8 * g + j;
-          const bool ok = n < T;
-          pv[j] = ok ? sk[n * HD + 16 * blk + l15] : 0.f;
-          vv[j] = ok ? sv[n * HD + 16 * blk + l15] : 0.f;
+          const int nn = n < Tp ? n : Tp - 1;        // unconditional in-tile reads, deselected below
+          pv[j] = sk[nn * HD + 16 * blk + l15];
+          vv[j] = sv[nn * HD + 16 * blk + l15];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool ok = 32 * ks + 8 * g + j < T;
+          pv[j] = ok ? pv[j] : 0.f;
+          vv[j] = ok ? vv[j] : 0.f;
         }
         split(pv, ph[blk], pl[blk]);
         split(vv, vh[blk], vl[blk]);
@@ -196,6 +227,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
           accA[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rb], vh[nb], accA[rb][nb], 0, 0, 0);
         }
     }
+    RG_STAMP3(5);
     // ---- y = q A.  accA[rb][nb][e] = A[16 rb + 4 g + e][16 nb + l15] is already a B fragment if the
     // contraction index is enumerated as slot (g, j) <-> d = 16*(j/4) + 4*g + j%4; q is read with the same
     // permutation (two 16-B LDS reads per fragment), so A never leaves the registers.
@@ -229,6 +261,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane's q reads are complete before y overwrites the tile
     __builtin_amdgcn_wave_barrier();
+    RG_STAMP3(6);
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
@@ -241,6 +274,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
       }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    RG_STAMP3(7);
     // coalesced y store (8 rows x 128 B per wave-instruction) and per-token statistics from the tile
     {
       float* yout = y + (size_t)b * T * ldy + h * HD;
@@ -299,7 +333,9 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
   for (int d = 0; d < HD; ++d) Areg[d] = sA[d * AS + (lane & 31)];
   qa_and_store(sq, Areg, y + (size_t)b * T * ldy + h * HD, ldy, T, lane, nullptr, sstat + wave * 2 * Tp);
   }
+  RG_STAMP3(8);
   __syncthreads();
+  RG_STAMP3(9);
   const int ngroups = D / (HD * WAVES);
   for (int n = threadIdx.x; n < T; n += 256) {
     float* so = stats + (((size_t)b * T + n) * ngroups + hg) * 2;
@@ -1104,6 +1140,12 @@ extern "C" int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }
+
+#ifdef RG_STAMPS
+extern "C" int rg_debug_set_stamp_buffer3(void* dev_ptr) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf3), &dev_ptr, sizeof(void*)) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
                                float* stats, int R, int T, int D, const int* perm, int nperm, int use_mfma,
