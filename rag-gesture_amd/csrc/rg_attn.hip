@@ -91,7 +91,8 @@ __device__ unsigned long long* g_stamp_buf3 = nullptr;
 #define RG_STAMP3(slot)
 #endif
 
-template <bool MFMA_>
+// TCAP = token capacity of the softmax's register column (48 or 64): T = 43 needs 24 values per lane, not 32
+template <bool MFMA_, int TCAP = TMAX>
 __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
                                                           const float* __restrict__ src_mask, float* __restrict__ y,
                                                           int ldy, float* __restrict__ stats, int T,
@@ -114,7 +115,9 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
   float* sv = sk + Tp * HD;
   constexpr int AS = HD + 1;
   float* sA = sk;                          // [32][33] reuses the P tile once A is in registers (Tp*32 >= 32*33)
-  // q, k, v tiles [T][32] straight into LDS: one 1-KiB LDS-DMA per 8 rows and tile
+  const float mval = src_mask[(size_t)b * T + (lane < T ? lane : 0)];   // requested first, used after the tiles
+  // q, k, v tiles [T][32] straight into LDS: one 1-KiB LDS-DMA per 8 rows and tile (register staging -- 24 plain
+  // 16-B loads, then ds_write_b128 -- was measured 0.4 us slower at R = 32)
   {
     typedef __attribute__((address_space(3))) void lds_void;
     const float* src = qkv + (size_t)b * T * ldqkv + h * HD + (lane & 7) * 4;
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
   RG_STAMP3(1);
   // token validity as a wave-uniform bit set (bit n: token n takes part); a wave touches only its own q/k/v tiles,
   // so no workgroup barrier is needed before the softmax
-  const unsigned long long vbits = __ballot(lane < T && src_mask[(size_t)b * T + (lane < T ? lane : 0)] != 0.f);
+  const unsigned long long vbits = __ballot(lane < T && mval != 0.f);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   RG_STAMP3(2);
   __builtin_amdgcn_wave_barrier();
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
   // deselected by the bit set -- a guarded read would serialise into read / wait / branch per token)
   {
     const int d = lane & 31, half = lane >> 5;
-    constexpr int NH = TMAX / 2;
+    constexpr int NH = TCAP / 2;
     float kr[NH];
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
@@ -160,7 +163,9 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-      kr[i] = (kr[i] == -INFINITY) ? 0.f : expf(kr[i] - mx);
+      // bf16 (MFMA) mode: exp2-based fast exponential (relative error ~1e-6 at these arguments, far below the
+      // bf16 operand rounding of the GEMMs around); fp32 mode keeps expf
+      kr[i] = (kr[i] == -INFINITY) ? 0.f : (MFMA_ ? __expf(kr[i] - mx) : expf(kr[i] - mx));
       sum += kr[i];
     }
     sum += __shfl_xor(sum, 32);
@@ -1157,7 +1162,10 @@ extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const 
   RG_REQUIRE(h, !perm || nperm >= R * (D / (HD * WAVES)), "perm shorter than the work list");
   RG_REQUIRE(h, !use_mfma || (ldy % 4 == 0), "ldy must be a multiple of 4 floats");
   const dim3 grid(perm ? nperm : R * (D / (HD * WAVES)));
-  if (use_mfma)
+  if (use_mfma && T <= 48)
+    hipLaunchKernelGGL((sa_attention_kernel<true, 48>), grid, dim3(256), lds, rg_stream(stream), qkv, ldqkv, D, src_mask, y,
+                       ldy, stats, T, perm);
+  else if (use_mfma)
     hipLaunchKernelGGL(sa_attention_kernel<true>, grid, dim3(256), lds, rg_stream(stream), qkv, ldqkv, D, src_mask, y, ldy,
                        stats, T, perm);
   else
