@@ -943,7 +943,6 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
   float* tiles = smask + Tp;                   // [H][Tp][32]
   const int ld = ncond * D;
   const int hpw = H / CS_WAVES;                // heads per wave (1 at D = 512)
-  const int l = lane & 31, half = lane >> 5;
   // ---- q tiles of this wave's heads straight into LDS (8 rows x 128 B per 1-KiB LDS-DMA)
   for (int hh = 0; hh < hpw; ++hh) {
     const int h = wave * hpw + hh;
@@ -982,16 +981,20 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
     g0 = gg.x; g1 = gg.y; b0 = bb.x; b1 = bb.y; sc0 = 1.0f + sc.x; sc1 = 1.0f + sc.y; sh0 = sh.x; sh1 = sh.y;
   }
   const int R = a.Rc + a.Ru;
-  if (a.qmask)
-    for (int n = threadIdx.x; n < T; n += NTH) smask[n] = a.qmask[((size_t)c * R + b) * T + n];
+  // query mask of this (condition, row group) as a wave-uniform bit set (bit n: token n is NOT masked); a wave reads
+  // only the tiles of its own heads until the statistics are combined, so no workgroup barrier is needed here
+  unsigned long long qbits = ~0ull;
+  if (a.qmask) {
+    const float mv = a.qmask[((size_t)c * R + b) * T + (lane < T ? lane : 0)];
+    qbits = __ballot(lane < T && mv != 0.f);
+  }
   float* mystat = sstat + wave * 2 * Tp;
   for (int n = lane; n < Tp; n += 64) {
     mystat[2 * n] = 0.f;
     mystat[2 * n + 1] = 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const float* qm = a.qmask ? smask : nullptr;
+  __builtin_amdgcn_wave_barrier();
   auto pk = [](float x, float y) {
     return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
   };
@@ -1035,7 +1038,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
       for (int e = 0; e < 4; ++e) {
         const int row = 16 * rb + 4 * g + e;
         if (row < T) {
-          const bool masked = qm && qm[row] == 0.f;
+          const bool masked = !((qbits >> row) & 1ull);
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
             float v = acc[rb][nb][e];
