@@ -936,6 +936,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
     }
     return;
   }
+  RG_STAMP3(0);
   const int b = blockIdx.x / ncond, c = blockIdx.x % ncond;
   float* sstat = sm;                           // [CS_WAVES][Tp][2]
   float* srow = sstat + CS_WAVES * 2 * Tp;     // [Tp][2] (mean, rstd)
@@ -943,7 +944,9 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
   float* tiles = smask + Tp;                   // [H][Tp][32]
   const int ld = ncond * D;
   const int hpw = H / CS_WAVES;                // heads per wave (1 at D = 512)
-  // ---- q tiles of this wave's heads straight into LDS (8 rows x 128 B per 1-KiB LDS-DMA)
+  // ---- q tiles of this wave's heads straight into LDS (8 rows x 128 B per 1-KiB LDS-DMA; register staging measured
+  // equal: the 2.4 us before the first MFMA are the latency of the first dependent load, and the last of the 16
+  // waves reaches the statistics barrier 2 us after the first -- in-kernel stamps, profiles/ca_stamps.py)
   for (int hh = 0; hh < hpw; ++hh) {
     const int h = wave * hpw + hh;
     const float* src = a.q3 + (size_t)b * T * ld + c * D + h * HD + (lane & 7) * 4;
@@ -993,8 +996,10 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
     mystat[2 * n] = 0.f;
     mystat[2 * n + 1] = 0.f;
   }
+  RG_STAMP3(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+  RG_STAMP3(2);
   auto pk = [](float x, float y) {
     return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
   };
@@ -1032,6 +1037,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
     (void)nrb;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane's q reads are complete before y overwrites the tile
     __builtin_amdgcn_wave_barrier();
+    RG_STAMP3(3);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
@@ -1052,6 +1058,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
       }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    RG_STAMP3(4);
     if (lane < T) {
       const float* yr = sq + lane * HD;
       float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
@@ -1067,7 +1074,9 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
       mystat[2 * lane + 1] += q0 + q1;
     }
   }
+  RG_STAMP3(5);
   __syncthreads();
+  RG_STAMP3(6);
   for (int n = threadIdx.x; n < T; n += NTH) {
     float su = 0.f, sq2 = 0.f;
 #pragma unroll
@@ -1083,6 +1092,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
     srow[2 * n + 1] = rsqrtf(var + 1e-5f);
   }
   __syncthreads();
+  RG_STAMP3(7);
   // ---- LN + stylization + SiLU -> bf16; thread -> (two adjacent columns, every 4th token)
   const int rq = threadIdx.x >> 8;   // NTH / 256 = 4 row phases
   for (int col = col0; col < D; col += 512) {
@@ -1108,6 +1118,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
           (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
     }
   }
+  RG_STAMP3(8);
 }
 
 }  // namespace
