@@ -35,6 +35,18 @@ __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// GELU for GEMMs whose operands are already bf16-rounded (relative 4e-3): erf by Abramowitz-Stegun 7.1.26 (absolute
+// error 1.5e-7) on v_rcp_f32 / v_exp_f32 -- ~14 instructions instead of libm erff's ~45, 32 times per epilogue thread.
+__device__ __forceinline__ float gelu_fast(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float e = 1.0f - pl * t * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);   // erf(|v|/sqrt 2)
+  return 0.5f * v + 0.5f * fabsf(v) * e;
+}
 
 struct SegInfo {      // LDS copy of one rg_a_segment (dynamic indexing of kernargs would go to scratch)
   const float* src;
@@ -126,20 +138,33 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
 #pragma unroll
     for (int e = 0; e < 32; ++e) v[e] += (gcol + e < Nlim) ? tb[e] : 0.f;
   }
+  // bf16-operand GEMMs (no hi/lo weight planes): exp / erf to ~1e-6, far below the operand rounding; the fp32-
+  // equivalent mode keeps libm
+  const bool fast_math = p.W_lo == nullptr;
   if (gcol < p.softmax_cols) {  // this thread's 32 columns are exactly one head
     float mx = v[0];
 #pragma unroll
     for (int e = 1; e < 32; ++e) mx = fmaxf(mx, v[e]);
     float sum = 0.f;
+    if (fast_math) {
 #pragma unroll
-    for (int e = 0; e < 32; ++e) { v[e] = expf(v[e] - mx); sum += v[e]; }
+      for (int e = 0; e < 32; ++e) { v[e] = __expf(v[e] - mx); sum += v[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) { v[e] = expf(v[e] - mx); sum += v[e]; }
+    }
     const float inv = 1.0f / sum;
 #pragma unroll
     for (int e = 0; e < 32; ++e) v[e] *= inv;
   }
   if (p.act == 1) {
+    if (fast_math) {
 #pragma unroll
-    for (int e = 0; e < 32; ++e) v[e] = gelu_f(v[e]);
+      for (int e = 0; e < 32; ++e) v[e] = gelu_fast(v[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) v[e] = gelu_f(v[e]);
+    }
   } else if (p.act == 2) {
 #pragma unroll
     for (int e = 0; e < 32; ++e) v[e] = fmaxf(v[e], 0.f);
