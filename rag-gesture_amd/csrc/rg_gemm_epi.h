@@ -115,10 +115,21 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
     float var = sq * inv - mu * mu;
     var = var < 0.f ? 0.f : var;
     const float rs = rsqrtf(var + 1e-5f);
+    if (full) {   // whole 32-column group inside the matrix: eight 16-B loads instead of 32 guarded ones
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
-      const float c1 = (gcol + e < Nlim) ? p.ln_c1[gcol + e] : 0.f;
-      v[e] = rs * (v[e] - mu * c1);
+      for (int q = 0; q < 8; ++q) {
+        const float4 c = *reinterpret_cast<const float4*>(p.ln_c1 + gcol + 4 * q);
+        v[4 * q] = rs * (v[4 * q] - mu * c.x);
+        v[4 * q + 1] = rs * (v[4 * q + 1] - mu * c.y);
+        v[4 * q + 2] = rs * (v[4 * q + 2] - mu * c.z);
+        v[4 * q + 3] = rs * (v[4 * q + 3] - mu * c.w);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 32; ++e) {
+        const float c1 = (gcol + e < Nlim) ? p.ln_c1[gcol + e] : 0.f;
+        v[e] = rs * (v[e] - mu * c1);
+      }
     }
   }
   if (p.bias) {
