@@ -27,3 +27,30 @@ def test_fails_loudly_without_gpu(rg):
         rg.capi.Handle()
     with pytest.raises(rg.capi.RgError):
         rg.smoke.run()
+
+
+def test_header_is_plain_c_and_struct_layouts_match_ctypes(rg, tmp_path):
+    """include/rg_gesture.h must compile as C (the boundary a cgo / JNI / ctypes binding sees), and the descriptor
+    structs the Python host fills through ctypes must have the compiler's size and field offsets."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    G = rg.gemm
+    fields = [name for name, _ in G.GemmDesc._fields_]
+    src = tmp_path / "abi.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rg_gesture.h"', 'int main(void) {',
+             '  printf("size %zu\\n", sizeof(rg_gemm_desc));']
+    for f in fields:
+        lines.append('  printf("%s %%zu\\n", offsetof(rg_gemm_desc, %s));' % (f, f))
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    r = subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, "the header is not plain C:\n" + r.stderr
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    assert int(out["size"]) == ctypes.sizeof(G.GemmDesc)
+    for f in fields:
+        assert int(out[f]) == getattr(G.GemmDesc, f).offset, "field %s: C offset %s, ctypes %d" % (f, out[f], getattr(G.GemmDesc, f).offset)
