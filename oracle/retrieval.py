@@ -78,8 +78,10 @@ def sort_sidx_by_textsimilarity(smp_indexes, encoded_text, feature_cache):
     return sorted(sims, key=sims.get, reverse=True)
 
 
-def discourse_retrieval(discourse, prominence, speaker_id, db, encoded_text):
-    """reference: rag/discourse_retrieval.py:8-316.  Returns (sample_indexes, d_bounds, query_bounds)."""
+def discourse_retrieval(discourse, prominence, speaker_id, db, encoded_text, trace=None):
+    """reference: rag/discourse_retrieval.py:8-316.  Returns (sample_indexes, d_bounds, query_bounds).
+    trace (test aid): a list that receives, per query relation, {"score": name -> score, "top": name -> index of the
+    relation whose bounds are reported} -- the state before the ranking walk."""
     d_bounds, sample_indexes, query_bounds = {}, {}, {}
     if len(discourse) == 0:
         return sample_indexes, d_bounds, query_bounds
@@ -91,7 +93,7 @@ def discourse_retrieval(discourse, prominence, speaker_id, db, encoded_text):
         if cv is not None:
             q_prom[i] = (senses[i], cv[1])
     for qi, (q_sense, q_conn) in enumerate(zip(senses, conns)):
-        score, rel_bounds = {}, {}
+        score, rel_bounds, tops = {}, {}, {}
         for name, rec in db["idx_2_sense"].items():
             score[name] = 0
             spk, rels = rec[0], rec[1:]
@@ -124,6 +126,9 @@ def discourse_retrieval(discourse, prominence, speaker_id, db, encoded_text):
                     if top != best[0] and not chosen:
                         top = best[0]
                 rel_bounds[name] = db["idx_2_discbounds"][name][top]
+                tops[name] = top
+        if trace is not None:
+            trace.append(dict(score=dict(score), top=dict(tops)))
         order = sorted(score, key=score.get, reverse=True)
         tiers = {}
         for name in order:

@@ -343,3 +343,42 @@ def test_hip_llm_retrieval_matches_reference_golden_and_oracle(rg, golden_dir):
             got = rg.retrieval.llm_retrieval(gindex, qq["text"], qq["text_times"], qq["speaker_id"], qq["prominence"],
                                              qq["text_features"], sim, cache.get)
             assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
+
+
+def test_host_ranking_walk_matches_oracle_without_gpu(rg):
+    """The host half of the product's discourse retrieval (survivor ordering, tier cut, tie-break ordering, the
+    10-entry walk, bounds) against the oracle, on CPU: the device results it consumes (survivors of the top-score
+    selection, tie-break similarities) are produced here from the oracle's own scores."""
+    smp = _db(rg)
+    db = oret.build_db_dicts(smp)
+    names = list(db["idx_2_sense"].keys())
+
+    class HostIndex:                      # what retrieval.py reads from a DiscourseIndex
+        dev = torch.device("cpu")
+
+        def __init__(self):
+            self.names, self.db = names, db
+
+        def sims_async(self, q, cand):   # rag/utils.py:109-121 in float64, like rg_text_diag_sim
+            out = []
+            for e in cand:
+                f = db["idx_2_text"][names[e]][0].double()
+                n = min(q.shape[0], f.shape[0])
+                out.append((q[:n].double() * f[:n]).sum() / n if n else torch.tensor(0.0, dtype=torch.float64))
+            return torch.stack(out)
+
+    index = HostIndex()
+    for seed in (11, 12, 13, 14, 21, 22, 100, 101, 102):
+        q = rg.synth.synth_query(seed)
+        trace = []
+        want = oret.discourse_retrieval(q["discourse"], q["prominence"], q["speaker_id"], db, q["text_features"], trace)
+        survivors = []
+        for t in trace:
+            sc = np.array([float(t["score"][n]) for n in names])
+            pos = np.sort(sc[sc > 0])[::-1]
+            thr = pos[9] if len(pos) >= 10 else 0.0
+            keep = np.nonzero((sc >= thr) & (sc > 0))[0]
+            survivors.append((keep, sc[keep], np.array([t["top"].get(names[e], -1) for e in keep])))
+        got = rg.retrieval.discourse_retrieval(index, q["discourse"], q["prominence"], q["speaker_id"], q["text_features"],
+                                               survivors=survivors)
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2]
