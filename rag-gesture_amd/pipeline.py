@@ -49,6 +49,24 @@ def build_submodule(cfg, **kwargs):
     return MODELS[cfg.pop("type")](**cfg, **kwargs)
 
 
+def guidance_iters_preset(name, steps=50):
+    """The named per-timestep guidance schedules of the reference's tools (tools/visualize.py:74-95,
+    tools/longform_synthesis.py: same table); index = respaced timestep (49 = noisiest), value = gradient steps."""
+    half = steps // 2
+    table = {
+        "all_one": [1] * steps, "all_zero": [0] * steps, "all_10": [10] * steps,
+        "decreasing": list(range(steps)),
+        "increasing": list(range(steps - 1, -1, -1)),
+        "drop_decreasing_till_25": [0] * half + list(range(steps))[half:steps],
+        "step_increasing_from_25": list(range(steps - 1, -1, -1))[:half] + [0] * half,
+        "decreasing_till_25": [0] * half + list(range(half)),
+        "increasing_from_25": list(range(half - 1, -1, -1)) + [0] * half,
+    }
+    if name not in table:
+        raise ValueError("Invalid guidance_iters value")
+    return table[name]
+
+
 class _TorchNoise:
     order_free = True  # draws come from torch's generator: consumers may batch / reorder them
 
@@ -294,6 +312,8 @@ class MotionDiffusion:
         inference_kwargs.pop("visualize_inversion", False)  # diagnostic decode of all levels: out of scope
         use_insertion_guidance = inference_kwargs.pop("insertion_guidance", False)
         guidance_iters = inference_kwargs.pop("guidance_iters", [10] * 50)
+        if isinstance(guidance_iters, str):     # the tools' --guidance_iters names
+            guidance_iters = guidance_iters_preset(guidance_iters)
         guidance_lr = inference_kwargs.pop("guidance_lr", 0.1)
         use_prev_latent = inference_kwargs.pop("use_prev_latent", False)
         prev_latent = inference_kwargs.pop("prev_latent", None)

@@ -170,3 +170,16 @@ def test_longform_three_windows_vs_oracle(rg):
     print("longform 3 windows fp32: rel err poses %.2e expressions %.2e trans %.2e" % (e_m, e_f, e_t))
     # (what remains in fp32 mode is the reference's -1e6 LayerNorm quirk on rows 10/20/30)
     assert e_m <= 5e-3 and e_f <= 5e-3 and e_t <= 5e-3
+
+
+def test_guidance_iters_presets(rg):
+    """tools/visualize.py:74-95: the --guidance_iters names (50 respaced steps, index 49 = noisiest)."""
+    p = rg.pipeline.guidance_iters_preset
+    assert p("all_one") == [1] * 50 and p("all_zero") == [0] * 50 and p("all_10") == [10] * 50
+    assert p("decreasing") == list(range(50)) and p("increasing") == list(range(49, -1, -1))
+    assert p("drop_decreasing_till_25") == [0] * 25 + list(range(25, 50))
+    assert p("step_increasing_from_25") == list(range(49, 24, -1)) + [0] * 25
+    assert p("decreasing_till_25") == [0] * 25 + list(range(25))
+    assert p("increasing_from_25") == list(range(24, -1, -1)) + [0] * 25
+    with pytest.raises(ValueError):
+        p("sometimes")
