@@ -12,6 +12,8 @@ Per-window conditioning features (wav2vec2 on the window's audio, BERT on its wo
 of this path: the caller supplies `features(cidx, t0, t1, annotations) -> dict` with at
 least `audio` [B,499,768] and `text_features`.
 """
+import os
+
 import torch
 
 from . import capi, packing
@@ -81,11 +83,14 @@ class LongformSynthesizer:
         self.overlap = overlap if overlap is not None else model.model.cfg["frame_chunk_size"]
 
     def run(self, data, features, use_inversion=False, insertion_guidance=False, guidance_iters=None, guidance_lr=0.1,
-            outpaint=False, inversion_start_time=-1, retrieval_method="discourse", noise_tape=None):
+            outpaint=False, inversion_start_time=-1, retrieval_method="discourse", noise_tape=None, with_gt=False):
+        """with_gt: also carry the ground-truth triple (the model's returned motion / facial / trans inputs) through the
+        same overlap blend and interpolation, as the tool does for gt_motion.npz (longform_synthesis.py:480-520, 722-745);
+        adds gt_poses / gt_expressions / gt_trans to the result."""
         sample_len = data["motion"].shape[1]
         starts, ends, remainder = window_bounds(sample_len, self.seqlen, self.overlap)
         data = pad_tail(data, remainder)
-        prev_latent, so_far, latents = None, None, []
+        prev_latent, so_far, gt_so_far, latents = None, None, None, []
         for cidx, (c0, c1) in enumerate(zip(starts, ends)):
             t0, t1 = c0 / self.fps, c1 / self.fps
             chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
@@ -111,6 +116,10 @@ class LongformSynthesizer:
             cur = (packing.scatter_parts(out["pred_upper"], out["pred_lower"], out["pred_hands"], out["pred_facepose"]),
                    out["pred_exps"].float(), out["pred_transl"].float())
             so_far = cur if cidx == 0 else blend_window(so_far, cur, self.overlap)
+            if with_gt:
+                dev = cur[0].device
+                gt = tuple(out[k].to(dev).float() for k in ("motion", "facial", "trans"))
+                gt_so_far = gt if cidx == 0 else blend_window(gt_so_far, gt, self.overlap)
         motion, facial, trans = so_far
         scale = self.target_fps // self.fps
         if scale != 1:
@@ -118,5 +127,25 @@ class LongformSynthesizer:
                                      packing.upsample_features(trans, scale))
         n_out = sample_len * scale
         cut = lambda t: t[0, :n_out].detach().cpu().numpy()
-        return dict(poses=cut(motion), expressions=cut(facial), trans=cut(trans), latents=latents,
-                    windows=list(zip(starts, ends)))
+        result = dict(poses=cut(motion), expressions=cut(facial), trans=cut(trans), latents=latents,
+                      windows=list(zip(starts, ends)))
+        if with_gt:
+            gm, gf, gt_ = gt_so_far
+            if scale != 1:
+                gm, gf, gt_ = packing.upsample_motion(gm, scale), packing.upsample_features(gf, scale), \
+                    packing.upsample_features(gt_, scale)
+            result.update(gt_poses=cut(gm), gt_expressions=cut(gf), gt_trans=cut(gt_))
+        return result
+
+    @staticmethod
+    def save(result, out_dir, raw_text=None):
+        """The per-sample files of the tool (longform_synthesis.py:760-788): full_pred_motion.npz, full_gt_motion.npz when
+        the run carried the ground truth, gt_text.txt when the transcript is given (audio / video are the caller's)."""
+        os.makedirs(out_dir, exist_ok=True)
+        packing.save_npz(os.path.join(out_dir, "full_pred_motion.npz"), result["poses"], result["expressions"], result["trans"])
+        if "gt_poses" in result:
+            packing.save_npz(os.path.join(out_dir, "full_gt_motion.npz"), result["gt_poses"], result["gt_expressions"],
+                             result["gt_trans"])
+        if raw_text is not None:
+            with open(os.path.join(out_dir, "gt_text.txt"), "w", encoding="utf-8") as f:
+                f.write(raw_text)

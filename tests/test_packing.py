@@ -145,8 +145,22 @@ def test_longform_three_windows_vs_oracle(rg):
     features = lambda cidx, t0, t1, ann: dict(audio=feats[cidx]["audio"], text_features=None)
     synth = rg.longform.LongformSynthesizer(model, overlap=15)
     tape = rg.synth.NoiseTape(31)
-    got = synth.run({k: v.clone() for k, v in data.items()}, features, noise_tape=tape)
+    got = synth.run({k: v.clone() for k, v in data.items()}, features, noise_tape=tape, with_gt=True)
     assert got["windows"] == [(0, 150), (135, 285), (270, 420)] and got["poses"].shape == (600, 165)
+    # ground truth through the same blend + interpolation (longform_synthesis.py:480-520, 722-745): overlapping windows
+    # of ONE sequence carry identical frames in the overlap, so the result is the 30-fps interpolation of the sample
+    # (all but the last output frame, which interpolates towards the zero padding behind the sample)
+    gt_want = rg.packing.upsample_motion(data["motion"].cuda().float(), 2)[0, :599].cpu()
+    assert got["gt_poses"].shape == (600, 165) and rot_close(torch.from_numpy(got["gt_poses"][:599]), gt_want)
+    want_f = rg.packing.upsample_features(data["facial"].cuda().float(), 2)[0, :599].cpu()
+    assert (torch.from_numpy(got["gt_expressions"][:599]) - want_f).abs().max() <= 1e-5
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        rg.longform.LongformSynthesizer.save(got, tmp, raw_text="hello there")
+        z = np.load(os.path.join(tmp, "full_gt_motion.npz"))
+        assert sorted(z.files) == sorted(["betas", "poses", "expressions", "trans", "model", "gender", "mocap_frame_rate"])
+        assert np.array_equal(np.load(os.path.join(tmp, "full_pred_motion.npz"))["poses"], got["poses"])
+        assert open(os.path.join(tmp, "gt_text.txt")).read() == "hello there"
     # ---- oracle loop
     otape = rg.synth.NoiseTape(31)
     sch = odf.SpacedSchedule()
