@@ -109,3 +109,35 @@ def npz_fields(poses, expressions, trans, fps=30):
 
 def save_npz(path, poses, expressions, trans, fps=30):
     np.savez(path, **npz_fields(poses, expressions, trans, fps))
+
+
+def pack_ground_truth(output, motion_fps=15, target_fps=30):
+    """The ground-truth triple of the same batch at the output rate (visualize.py:214-216, 266-291): the model returns
+    its inputs, `motion` [B,n,165] axis-angle, `facial`, `trans` (x/z made relative by the forward)."""
+    scale = target_fps // motion_fps
+    up = lambda t: _dev(t if t.is_cuda else t.cuda())     # the inputs may still live on the host
+    poses, expr, trans = up(output["motion"]), up(output["facial"]), up(output["trans"])
+    if scale != 1:
+        poses, expr, trans = upsample_motion(poses, scale), upsample_features(expr, scale), upsample_features(trans, scale)
+    return poses, expr, trans
+
+
+def save_sample_files(exp_dir, sample_names, pred, gt=None, use_inversion=False, texts=None):
+    """visualize.py:449-492, one directory per clip: pred_motion.npz, pred_motion_notrans.npz (with --use_inversion:
+    translation minus itself), gt_motion.npz and gt_text.txt when given.  pred / gt = (poses, expressions, trans)
+    batches as returned by pack_outputs / pack_ground_truth.  Audio and rendering stay with the caller."""
+    import os
+    a = lambda t: t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+    pred = tuple(a(t) for t in pred)
+    gt = None if gt is None else tuple(a(t) for t in gt)
+    for j, name in enumerate(sample_names):
+        d = os.path.join(exp_dir, name)
+        os.makedirs(d, exist_ok=True)
+        save_npz(os.path.join(d, "pred_motion.npz"), pred[0][j], pred[1][j], pred[2][j])
+        if use_inversion:
+            save_npz(os.path.join(d, "pred_motion_notrans.npz"), pred[0][j], pred[1][j], pred[2][j] - pred[2][j])
+        if gt is not None:
+            save_npz(os.path.join(d, "gt_motion.npz"), gt[0][j], gt[1][j], gt[2][j])
+        if texts is not None:
+            with open(os.path.join(d, "gt_text.txt"), "w", encoding="utf-8") as f:
+                f.write(texts[j])

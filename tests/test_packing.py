@@ -197,3 +197,33 @@ def test_guidance_iters_presets(rg):
     assert p("increasing_from_25") == list(range(24, -1, -1)) + [0] * 25
     with pytest.raises(ValueError):
         p("sometimes")
+
+
+def test_save_sample_files_layout(rg, tmp_path):
+    """visualize.py:449-492: directory per clip, file names, npz keyword set, the zeroed translation of the
+    `_notrans` copy (host-only: numpy inputs)."""
+    g = np.random.Generator(np.random.PCG64(3))
+    pred = (g.standard_normal((2, 300, 165)).astype(np.float32), g.standard_normal((2, 300, 100)).astype(np.float32),
+            g.standard_normal((2, 300, 3)).astype(np.float32))
+    gt = tuple(x + 1 for x in pred)
+    names = ["2_scott_0_1_1/0", "2_scott_0_1_1/15"]
+    rg.packing.save_sample_files(str(tmp_path), names, pred, gt=gt, use_inversion=True, texts=["a b", "c"])
+    for j, n in enumerate(names):
+        d = tmp_path / n
+        assert sorted(p.name for p in d.iterdir()) == ["gt_motion.npz", "gt_text.txt", "pred_motion.npz", "pred_motion_notrans.npz"]
+        z = np.load(d / "pred_motion.npz")
+        assert sorted(z.files) == sorted(["betas", "poses", "expressions", "trans", "model", "gender", "mocap_frame_rate"])
+        assert z["betas"].shape == (300,) and str(z["model"]) == "smplx2020" and int(z["mocap_frame_rate"]) == 30
+        assert np.array_equal(z["poses"], pred[0][j]) and np.array_equal(np.load(d / "gt_motion.npz")["trans"], gt[2][j])
+        assert not np.load(d / "pred_motion_notrans.npz")["trans"].any()
+        assert (d / "gt_text.txt").read_text() == ["a b", "c"][j]
+
+
+@pytest.mark.gpu
+def test_pack_ground_truth_is_the_interpolated_input(rg):
+    d = rg.synth.synth_batch(2, seed=5)
+    out = dict(motion=d["motion"], facial=d["facial"], trans=d["trans"])
+    poses, expr, trans = rg.packing.pack_ground_truth(out)
+    assert poses.shape == (2, 300, 165) and expr.shape == (2, 300, 100) and trans.shape == (2, 300, 3)
+    assert torch.equal(poses, rg.packing.upsample_motion(d["motion"].cuda().float(), 2))
+    assert torch.equal(expr, rg.packing.upsample_features(d["facial"].cuda().float(), 2))
