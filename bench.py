@@ -105,7 +105,9 @@ def main():
         data["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
     trans0 = data["trans"].clone()
 
-    def one_step():
+    def one_step(gather=True):
+        """gather=False: the rank-local part only (the instrumented extra steps below run on rank 0 alone and must
+        not enter a collective the other ranks are not in)."""
         d = dict(data)
         d["trans"] = trans0.clone()  # forward re-zeroes trans in place like the reference
         ikw = {}
@@ -115,7 +117,7 @@ def main():
         out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
         packed = torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
                             out["pred_transl"], out["pred_exps"]], dim=-1)
-        if dist is not None:  # the only collective on the path: final result gather (RCCL over xGMI)
+        if dist is not None and gather:  # the only collective on the path: final result gather (RCCL over xGMI)
             gathered = torch.empty(world * B, packed.shape[1], packed.shape[2], device=dev)
             dist.all_gather_into_tensor(gathered, packed.contiguous())
             return gathered
@@ -145,11 +147,11 @@ def main():
         # phase walls need device syncs at phase boundaries, which serialise concurrent lanes: the breakdown is taken
         # on a single lane (one warm-up step captures its graphs), the timed run above used model.lanes lanes
         lanes_prod, model.lanes = model.lanes, 1
-        one_step()
+        one_step(gather=False)
         model.profile_phases, model.phase_ms = True, {}
         if guided:
             model.model.database.phase_ms = model.phase_ms
-        one_step()
+        one_step(gather=False)
         torch.cuda.synchronize()
         model.profile_phases = False
         if guided:
@@ -168,10 +170,10 @@ def main():
             launches are the same).  Returns (launches, total ms, total flops) of the bf16-A GEMMs = variant 1
             (gemm_dma_kernel<true,...> / gemm_bf16_big_kernel: every per-step denoiser GEMM, ~2/3 of the GPU time)."""
             model.use_graphs = False
-            one_step()
+            one_step(gather=False)
             torch.cuda.synchronize()
             h.lib.rg_profile_begin(h._h)
-            one_step()
+            one_step(gather=False)
             model.use_graphs = True
             n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
             h.lib.rg_profile_end(h._h, 1, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
