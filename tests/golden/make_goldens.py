@@ -312,10 +312,13 @@ def run_gesture_type_goldens(ns):
     try:
         for simname, sim in (("f64", synth.synth_word_similarity), ("f32", f32_word_similarity)):
             gt.get_word_similarity_score = sim
-            for qseed in (11, 12, 13, 14):
+            for qseed in (11, 12, 13, 14, 15):
                 q = synth.synth_query(qseed)
                 labels = synth.synth_gesture_query(qseed, n_labels=2 + qseed % 2) if qseed != 14 else \
                     [dict(name="beat", word="and", start=0.2, end=0.5)]
+                if qseed == 15:   # a type no DB entry carries (all scores 0 -> empty lists), an upper-case word
+                    labels = [dict(name="emblem", word="peace", start=0.5, end=1.1),
+                              dict(name="deictic", word="THAT ONE", start=2.0, end=3.4)]
                 si, db_b, qb = gt.gesture_type_retrieval(text=None, gesture_labels=labels, speaker_id=q["speaker_id"],
                                                          db_idx_2_gesture_labels=db_labels,
                                                          encoded_text=q["text_features"], text_feat_cache=db_text)
@@ -353,8 +356,18 @@ def run_llm_retrieval_goldens(ns):
     try:
         for simname, sim in (("f64", synth.synth_word_similarity), ("f32", f32_word_similarity)):
             llm.get_word_similarity_score = sim
-            for qseed in (1, 2, 3, 4, 5, 6):
+            for qseed in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
                 q = synth.synth_llm_query(qseed)
+                if qseed == 7:    # the answer names a word the transcript does not contain, and a beat: nothing to retrieve
+                    q["llm_output"] = "[(\"unicorn\", \"iconic\"), (\"%s\", \"beat\")]" % q["text_times"][0][1]
+                if qseed == 8:    # no prominence known for the query words, speaker the DB does not have
+                    q["prominence"] = [("zzz", 0.0, 0.1, 1.0)]
+                    q["speaker_id"] = 99
+                if qseed == 9:    # a three-word label that spans the clip's first words, quoted and upper-cased
+                    ws = ["".join(c for c in t[1].lower() if c.isalnum() or c.isspace()) for t in q["text_times"][:3]]
+                    q["llm_output"] = "1. \"%s\", deictic" % " ".join(ws).upper()
+                if qseed == 10:   # the type names are matched case-sensitively (llm_retrieval.py:141): no label, empty result
+                    q["llm_output"] = "(%s, Iconic)" % q["text_times"][1][1]
                 answer = {q["text"]: q["llm_output"], "nothing here": "I cannot find any gesture words."}
                 llm.get_llm_output = lambda t: answer[t]
                 for text in ((q["text"], "   ") if qseed == 1 else (q["text"],)):
@@ -366,7 +379,9 @@ def run_llm_retrieval_goldens(ns):
                                                        mine["idx_2_gestprom"], q["text_features"], db_text, sim,
                                                        lambda t: answer[t])
                     assert osi == si and odb == db_b and oqb == qb, "oracle llm retrieval != reference"
-                    gold["queries"].append(dict(seed=qseed, sim=simname, text=text,
+                    gold["queries"].append(dict(seed=qseed, sim=simname, text=text, llm_output=q["llm_output"],
+                                                text_times=[[list(t[0]), t[1]] for t in q["text_times"]],
+                                                prominence=[list(p) for p in q["prominence"]], speaker_id=q["speaker_id"],
                                                 sample_indexes={str(k): v for k, v in si.items()},
                                                 d_bounds={str(k): {n: list(b) for n, b in v.items()} for k, v in db_b.items()},
                                                 query_bounds={str(k): list(v) for k, v in qb.items()}))

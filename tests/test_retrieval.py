@@ -295,6 +295,15 @@ def _llm_golden(golden_dir):
         return json.load(f)["queries"]
 
 
+def _llm_query(rg, q):
+    """The clip a golden entry was produced from: the stored fields (hand-made edge cases overwrite the synthetic
+    ones), token features from the seed."""
+    qq = rg.synth.synth_llm_query(q["seed"])
+    qq.update(llm_output=q["llm_output"], text_times=[(tuple(t[0]), t[1]) for t in q["text_times"]],
+              prominence=[tuple(p) for p in q["prominence"]], speaker_id=q["speaker_id"])
+    return qq
+
+
 def test_oracle_llm_retrieval_matches_reference(rg, golden_dir):
     """oracle/retrieval.py::llm_retrieval against the real reference function (get_llm_output replaced by the clip's
     canned answer, get_word_similarity_score by the deterministic stand-in; see make_goldens.py)."""
@@ -302,16 +311,17 @@ def test_oracle_llm_retrieval_matches_reference(rg, golden_dir):
     db = oret.build_db_dicts(smp)
     for q in _llm_golden(golden_dir):
         sim = rg.synth.synth_word_similarity if q["sim"] == "f64" else _f32_sim(rg)
-        qq = rg.synth.synth_llm_query(q["seed"])
+        qq = _llm_query(rg, q)
         si, dbb, qb = oret.llm_retrieval(q["text"], qq["text_times"], qq["speaker_id"], qq["prominence"],
                                          db["idx_2_gesture_labels"], db["idx_2_gestprom"], qq["text_features"],
                                          db["idx_2_text"], sim, lambda t: qq["llm_output"])
         gsi, gdb, gqb = _unpack(q)
         assert si == gsi and dbb == gdb and qb == gqb
-    # product host logic: label alignment == oracle's
-    for seed in range(1, 40):
-        qq = rg.synth.synth_llm_query(seed)
+    # product host logic: label alignment == oracle's (synthetic clips and the hand-made golden cases)
+    clips = [rg.synth.synth_llm_query(seed) for seed in range(1, 40)] + [_llm_query(rg, q) for q in _llm_golden(golden_dir)]
+    for qq in clips:
         labs = oret.parse_gesture_labels_from_llm_output(qq["llm_output"])
+        assert rg.retrieval.parse_gesture_labels_from_llm_output(qq["llm_output"]) == labs
         assert rg.retrieval.llm_query_bounds(labs, qq["text_times"]) == oret.llm_query_bounds(labs, qq["text_times"])[0]
     assert rg.retrieval.build_db_dicts(smp)["idx_2_gestprom"] == db["idx_2_gestprom"]
 
@@ -322,7 +332,7 @@ def test_hip_llm_retrieval_matches_reference_golden_and_oracle(rg, golden_dir):
     gindex = rg.retrieval.GestureTypeIndex(meta, rg.retrieval.DiscourseIndex(meta, "cuda"))
     for q in _llm_golden(golden_dir):
         sim = rg.synth.synth_word_similarity if q["sim"] == "f64" else _f32_sim(rg)
-        qq = rg.synth.synth_llm_query(q["seed"])
+        qq = _llm_query(rg, q)
         si, dbb, qb = rg.retrieval.llm_retrieval(gindex, q["text"], qq["text_times"], qq["speaker_id"], qq["prominence"],
                                                  qq["text_features"], sim, lambda t: qq["llm_output"])
         gsi, gdb, gqb = _unpack(q)
