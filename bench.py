@@ -22,7 +22,7 @@ import os
 import sys
 import time
 
-import torch
+torch = None   # imported in main(), after the rank-launch decision (the launcher parent never loads it)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -58,9 +58,42 @@ def make_re_dict(B, seed, device):
     return dict(retr_startends=rs, query_startends=qs, retr_uncropped_latents=ls)
 
 
+def launch_ranks(n, argv, dry=False):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh rank processes (one per GPU,
+    RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set as torch.distributed.run would), relay rank 0's JSON line and
+    return non-zero if any rank fails.  The parent never touches the GPU (and never exec()s): every rank is a
+    child process that initialises HIP itself."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, stderr=None if r == 0 else subprocess.PIPE, text=True))
+    rc, outs = 0, []
+    for r, p in enumerate(procs):
+        out, err = p.communicate()
+        outs.append(out)
+        if p.returncode != 0:
+            rc = rc or p.returncode or 1
+            sys.stderr.write("bench.py: rank %d exited with code %s\n%s\n" % (r, p.returncode, (err or "")[-2000:]))
+    if dry:   # one line per rank: what each child saw
+        print(json.dumps([json.loads(o.strip().splitlines()[-1]) for o in outs if o.strip()]))
+    else:
+        sys.stdout.write(outs[0])
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check (no GPU): every rank prints the environment it was started with and exits")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["guided", "base"], default="guided")
@@ -71,9 +104,21 @@ def main():
                     help="after the timed run, one extra step with device syncs at phase boundaries; prints the breakdown to stderr")
     args = ap.parse_args()
 
+    # ---- rank launch: decided before anything touches the GPU
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry=args.dry_launch))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or unset WORLD_SIZE "
+                         "to let bench.py start the ranks itself)" % (args.gpus, world, args.gpus))
+    if args.dry_launch:
+        print(json.dumps(dict(rank=rank, local_rank=local_rank, world=world, master_addr=os.environ.get("MASTER_ADDR"),
+                              master_port=os.environ.get("MASTER_PORT"), pid=os.getpid())))
+        return
+    global torch
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -245,7 +290,8 @@ def main():
     if rank == 0:
         line = {
             "metric": "SMPL-X frames/sec, len150 DDIM-50 + insertion guidance; 1/2/4/8 GPU",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if dist is not None else None, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": ("guided discourse config: discourse retrieval over a replicated %d-entry DB, "

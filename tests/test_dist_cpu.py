@@ -67,3 +67,22 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_bench_launcher_starts_one_process_per_gpu():
+    """`python bench.py --gpus N` (no torchrun environment) must start N rank processes with the
+    torch.distributed.run environment; --dry-launch makes every rank report what it saw (no GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-launch"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ranks = json.loads(r.stdout.strip().splitlines()[-1])
+    assert [x["rank"] for x in ranks] == [0, 1, 2] and [x["local_rank"] for x in ranks] == [0, 1, 2]
+    assert all(x["world"] == 3 and x["master_addr"] == "127.0.0.1" for x in ranks)
+    assert len({x["master_port"] for x in ranks}) == 1 and len({x["pid"] for x in ranks}) == 3
+    # under an external launcher the flag and the environment must agree
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
