@@ -253,6 +253,72 @@ int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows, int dim, 
 int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bias, float* out, int M,
                   int N, int K, int silu_in, int silu_out, void* stream);
 
+/* ---------------------------------------------------------------- one denoiser forward in ONE persistent launch
+ * `ReGestureTransformer.forward_test` without the CFG mix (raggesture.py:1041-1085: both classifier-free branches of
+ * every clip through diffusion_transformer.py:620-668 `forward`, :105-127 `DecoderLayer`, efficient_attention.py:23-45,
+ * 62-102, stylization_block.py:29-40) as a dataflow of tiles inside one launch instead of ~90 dependent launches:
+ *   per layer  S1 LN + QKV projection + both softmaxes + linear self-attention        (tile = sequence x head pair)
+ *              S2 stylization prologue + SA-out GEMM + residual                       (tile = sequence x 64 columns)
+ *              S3 LN + query projection + cross-attention, conditional rows only      (tile = sequence x condition x head pair)
+ *              S4 stylization prologue x3 + ca_mix(+out_layers) GEMM, K = 2048
+ *              S5 FFN linear1 + GELU    S6 FFN linear2    S7 stylization prologue + FFN-out GEMM + residual
+ *   plus the joint embedding in front and the output head behind.
+ * Tiles of one sequence (43 token rows, 2 per clip: conditional and classifier-free) depend only on earlier tiles of
+ * the same sequence, so there is no grid-wide barrier: every workgroup pulls tile descriptors from per-shard queues
+ * (topological order: deadlock-free for any number of resident workgroups), prefetches the tile's weight panel by
+ * LDS-DMA, waits on the sequence's completion counter, and publishes its outputs with write-through (sc1) stores
+ * followed by one agent-scope atomic add; consumers read activations with sc1 loads only (MI355X guide, inter-workgroup
+ * visibility).  Weights are bf16 [N][K] (rg_gemm's packed layout), accumulation fp32, LayerNorms are evaluated
+ * in fp32 from fp32 rows (no folded statistics), row statistics travel as (sum, M2) partials per 64 columns.
+ * D = 512, 16 heads x 32, FF = 1024, T <= 48.
+ * sched (DEVICE int32): [0..8] first tile of shard 0..7 and the tile count; from int 16 on one int4 per tile:
+ *   (type | layer << 8, sequence, tile index inside the stage, completion count of the sequence to wait for).
+ * ctrl (DEVICE, rg_fwd_ctrl_words(B) uint32): queue heads, abort word, per-sequence completion counters; zeroed by
+ * the call.  Returns RG_ERR_INVALID for unsupported shapes; a dependency that never resolves sets the abort word
+ * (ctrl[256] != 0 afterwards) instead of hanging. */
+enum { RG_FWD_EMBED = 0, RG_FWD_QKV_SA = 1, RG_FWD_SAOUT = 2, RG_FWD_Q3_CA = 3, RG_FWD_MIX = 4, RG_FWD_FF1 = 5,
+       RG_FWD_FF2 = 6, RG_FWD_FFOUT = 7, RG_FWD_HEAD = 8 };
+
+typedef struct rg_fwd_layer {
+  const void* w_qkv;   const float* b_qkv;   /* bf16 [1536][512] (q | k | v rows), fp32 [1536] */
+  const float* sa_g;   const float* sa_b;    /* sa_block.norm */
+  const float* sa_sg;  const float* sa_sb;   /* sa_block.proj_out.norm */
+  const void* w_sao;   const float* b_sao;   /* sa_block.proj_out.out_layers.2 */
+  const void* w_q3;    const float* b_q3;    /* bf16 [1536][512]: query weights of text | audio | speaker */
+  const float* ca_g;   const float* ca_b;    /* [3][512] ca_blocks.*.norm */
+  const float* a_pre;                        /* fp32 [3][B][16][32][32] = softmax_N(K)^T V of this layer (rg_kv_reduce) */
+  const float* ca_sg;  const float* ca_sb;   /* [3][512] ca_blocks.*.proj_out.norm */
+  const void* unc_tab;                       /* bf16 [S][2][1536]: stylized cross-attention rows of the classifier-free branch */
+  const void* w_mix;   const float* b_mix;   /* bf16 [512][2048]: ca_mix fused with the three out_layers */
+  const void* w_ff1;   const float* b_ff1;   /* [1024][512] */
+  const void* w_ff2;   const float* b_ff2;   /* [512][1024] */
+  const float* ff_sg;  const float* ff_sb;   /* ffn.proj_out.norm */
+  const void* w_ffo;   const float* b_ffo;   /* ffn.proj_out.out_layers.2 */
+} rg_fwd_layer;
+
+typedef struct rg_fwd_args {
+  const rg_fwd_layer* layers;   /* DEVICE array [L] */
+  int L, B, T, step;            /* B clips -> 2B sequences: [0,B) conditional, [B,2B) classifier-free; step = respaced index */
+  const void* w_embed; const float* b_embed; const float* tbias;   /* joint_embed; tbias [T][512] positional tables */
+  const void* w_out;   const float* b_out;
+  const float* ss;              /* fp32 [S][L][5][1024]: AdaLN (scale | shift) of every step, layer and block */
+  const float* x;               /* fp32 [B*T][512] latent at this step */
+  const float* src_mask;        /* [2B][T] */
+  const float* qmask;           /* [3][2B][T] */
+  float* xa; float* xb; float* xc; float* head;       /* fp32 [2B*T][512]; head = result */
+  void* xb_bf; void* xc_bf; void* ysa; void* yf;      /* bf16 [2B*T][512] */
+  void* y3;                                           /* bf16 [B*T][1536] */
+  void* g;                                            /* bf16 [2B*T][1024] */
+  float* st_a; float* st_b; float* st_sa; float* st_f;   /* fp32 [2B*T][8][2] (sum, M2) per 64 columns */
+  float* st3;                                         /* fp32 [B*T][24][2] */
+  const int* sched;
+  unsigned* ctrl;
+  unsigned long long* stamps;   /* NULL, or DEVICE [n_tiles][4] wall-clock stamps (100 MHz) per tile: diagnostics */
+} rg_fwd_args;
+
+int rg_fwd_ctrl_words(int B);
+int rg_denoiser_forward(rg_handle* h, const rg_fwd_args* args_host, void* stream);
+
 /* ---------------------------------------------------------------- body-part VAEs + rotations
  * Softmax multi-head attention core of torch.nn.MultiheadAttention for short sequences
  * (detr_utils.py:364-366, 427-433): o[b,i,h,:] = softmax_j(q[b,i,h,:].k[b,j,h,:]/sqrt(hd)) v[b,j,h,:].

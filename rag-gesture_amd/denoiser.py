@@ -20,7 +20,7 @@ import os
 import numpy as np
 import torch
 
-from . import capi, gemm as G
+from . import capi, fwd as F, gemm as G
 
 CONDS = ("xf_text", "xf_audio", "xf_spk")
 BLOCKS = ("sa_block", "ca_blocks.xf_text", "ca_blocks.xf_audio", "ca_blocks.xf_spk", "ffn")
@@ -196,7 +196,9 @@ class DenoiserSession:
     """Buffers + conditioning state for B clips (R = 2B rows: conditional rows first, then the
     classifier-free rows).  Not re-entrant; one per (model, batch size, stream)."""
 
-    def __init__(self, weights, B):
+    def __init__(self, weights, B, persistent=None):
+        """persistent: run `forward` as ONE persistent dataflow launch (rg_denoiser_forward) instead of ~90 dependent
+        launches.  None = whenever the shapes allow it (bf16 production path, D = 512, FF = 1024, T <= 48)."""
         w = self.w = weights
         self.h = w.h
         self.B, self.R = B, 2 * B
@@ -250,6 +252,10 @@ class DenoiserSession:
         self.perm_sa1 = dv(order(self.R, 1, T))
         self.perm_ca = dv(order(self.R, 3 * ng, T))
         self.perm_cac = dv(order(B, 3 * ng, T))
+        ok = F.supported(w, T)
+        if persistent and not ok:
+            raise capi.RgError("persistent forward: unsupported shape / precision")
+        self.pf = F.PersistentForward(self) if (ok and persistent is not False) else None
 
     # ------------------------------------------------------------------ once per clip
     def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None):
@@ -305,6 +311,8 @@ class DenoiserSession:
         """x [B,T,D] fp32 (device) at respaced step index `step`; returns the head output
         [2B,T,D] (rows [0,B) conditional, [B,2B) classifier-free) in self.head."""
         w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
+        if self.pf is not None:
+            return self.pf.run(x.contiguous(), step)
         xa, xb, xc = self.xa, self.xb, self.xc
         sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c     # sa_: written by the embed GEMM (128-wide tiles)
         sa_w = self._st_a if self.tn else self.st_a           # ... and by every FFN-out GEMM (self.tn-wide tiles)

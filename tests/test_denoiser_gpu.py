@@ -169,3 +169,52 @@ def test_fused_self_attention_stylization_matches_separate_kernels(rg, monkeypat
     e = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
     print("fused vs separate self-attention path: rel diff %.3e" % e)
     assert e <= 5e-3
+
+
+@pytest.mark.parametrize("B", [1, 3, 11])
+def test_persistent_forward_matches_launch_chain(rg, setup, B):
+    """One persistent dataflow launch (rg_denoiser_forward) against the per-op launch chain on the same
+    weights / conditions / masks (both bf16 MFMA operands: they differ by where bf16 roundings fall) and
+    against the fp32 oracle; every sequence of the batch is checked (queues, stealing, ragged shards)."""
+    cfg, P, W = setup[8]
+    data = rg.synth.synth_batch(B, seed=77)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal((B, 43, 512)).astype(np.float32))
+    mm = torch.ones(B, 43)
+    mm[:, [10, 21, 32]] = 0
+    if B > 1:
+        mm[1, 5:9] = 0   # a clip with masked motion tokens
+    qm = od.make_query_masks(mm)
+    outs = {}
+    for persistent in (True, False):
+        sess = rg.denoiser.DenoiserSession(W, B, persistent=persistent)
+        assert (sess.pf is not None) == persistent
+        sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
+        for step in (49, 7):
+            outs[persistent, step] = sess.forward(x.cuda(), step).clone()
+            torch.cuda.synchronize()
+        if persistent:
+            assert not sess.pf.aborted()
+            # replay: same inputs, same bits (the schedule is dynamic, the arithmetic per tile is not)
+            again = sess.forward(x.cuda(), 7).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(again, outs[True, 7])
+    xf = od.encode_conditions(P, data["word"], data["audio"], data["speaker_ids"])
+    rows = KEEP
+    for step, t in ((49, 999), (7, 99)):
+        a, b = outs[True, step].view(2 * B, 43, 512).cpu(), outs[False, step].view(2 * B, 43, 512).cpu()
+        for r in range(2 * B):
+            e = relerr(a[r][rows], b[r][rows])
+            assert e <= 1.5e-2, (B, step, r, e)
+        print("B=%d step=%d persistent vs launch chain: rel err %.3e" % (B, step, relerr(a[:, rows], b[:, rows])))
+    # against the fp32 oracle (CFG-mixed x0, exact LayerNorm on the -1e6 rows like the kernels)
+    sess = rg.denoiser.DenoiserSession(W, B, persistent=True)
+    sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
+    x0 = _hip_x0(rg, W, sess, x, 7)
+    od.OPTS.update(masked_ln="exact")
+    try:
+        ref = od.denoiser_forward(P, cfg, x, torch.full((B,), 99, dtype=torch.long), mm, xf, qm)
+    finally:
+        od.OPTS.update(masked_ln="torch")
+    e = relerr(x0, ref)
+    print("B=%d persistent forward, x0 vs fp32 oracle (all rows): %.3e" % (B, e))
+    assert e <= 2e-2
