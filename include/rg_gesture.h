@@ -273,9 +273,10 @@ int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bia
  * D = 512, 16 heads x 32, FF = 1024, T <= 48.
  * sched (DEVICE int32): [0..8] first tile of shard 0..7 and the tile count; from int 16 on one int4 per tile:
  *   (type | layer << 8, sequence, tile index inside the stage, completion count of the sequence to wait for).
- * ctrl (DEVICE, rg_fwd_ctrl_words(B) uint32): queue heads, abort word, per-sequence completion counters; zeroed by
- * the call.  Returns RG_ERR_INVALID for unsupported shapes; a dependency that never resolves sets the abort word
- * (ctrl[256] != 0 afterwards) instead of hanging. */
+ * ctrl (DEVICE, rg_fwd_ctrl_words(B) uint32): queue heads, abort word, per-sequence completion counters.  The caller
+ * zeroes it once; every launch leaves it zeroed again (the last workgroup to drain the queues clears it), so
+ * consecutive launches need no memset between them.  Returns RG_ERR_INVALID for unsupported shapes; a dependency that
+ * never resolves sets the abort word (ctrl[256] != 0 afterwards, block left as is: re-zero it) instead of hanging. */
 enum { RG_FWD_EMBED = 0, RG_FWD_QKV_SA = 1, RG_FWD_SAOUT = 2, RG_FWD_Q3_CA = 3, RG_FWD_MIX = 4, RG_FWD_FF1 = 5,
        RG_FWD_FF2 = 6, RG_FWD_FFOUT = 7, RG_FWD_HEAD = 8 };
 

@@ -38,6 +38,7 @@ constexpr int EPLD = 68;        // fp32 staging row stride (floats)
 constexpr int AH_LD = 33;
 constexpr int NSHARD = 8;
 constexpr int CTRL_ABORT = NSHARD * 32;        // word index of the abort flag
+constexpr int CTRL_DONE = CTRL_ABORT + 1;       // workgroups that have drained the queues
 constexpr int CTRL_CNT = CTRL_ABORT + 32;      // first completion counter; one per sequence, 16 words apart
 constexpr unsigned SPIN_LIMIT = 1u << 20;      // polls before a wait gives up (~1 s)
 
@@ -49,7 +50,7 @@ constexpr int OFF_W = OFF_EPI + EPI_BYTES;          // weight ring
 constexpr int OFF_PAR = OFF_W + NS * WT_BYTES;      // fp32 [4][512]: gamma, beta, 1 + scale, shift
 constexpr int OFF_ROW = OFF_PAR + 4 * DM * 4;       // fp32 [48][2]: mean, rstd
 constexpr int OFF_MASK = OFF_ROW + TP * 2 * 4;      // fp32 [48] token mask
-constexpr int OFF_CTL = OFF_MASK + 256;             // ints: [0] ticket, [1] abort
+constexpr int OFF_CTL = OFF_MASK + 256;             // ints: [0] ticket, [1] abort, [2] last workgroup
 constexpr int LDS_BYTES = OFF_CTL + 64;
 static_assert(3 * TP * EPLD * 4 <= TP * 1024, "q/k/v staging must fit the A panel");
 static_assert(TP * EPLD * 4 + 2 * HD * AH_LD * 4 <= EPI_BYTES, "epilogue staging");
@@ -186,7 +187,10 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
     return -1;
   };
   int next_ticket = -1;
-  if (tid == 0) next_ticket = take();
+  if (tid == 0) {
+    sCtl[1] = 0;
+    next_ticket = take();
+  }
 
   // per-lane weight DMA geometry: a tile is 8 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w and w + 4
   int wrow[2], wlc[2];
@@ -732,6 +736,23 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
       if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
     }
   }
+  // ---- the last workgroup to drain the queues (every tile has been published by then) leaves the control block
+  // zeroed for the next launch: no memset between launches, nothing for a graph to reorder.  After an abort the
+  // block stays as it is (the abort word is the caller's evidence; the caller re-zeroes it).
+  if (tid == 0) {
+    int last = 0;
+    if (sCtl[1] == 0) {
+      const unsigned d = __hip_atomic_fetch_add(ctrl + CTRL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = d == gridDim.x - 1 &&
+             __hip_atomic_load(ctrl + CTRL_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    }
+    sCtl[2] = last;
+  }
+  __syncthreads();
+  if (sCtl[2]) {
+    const int nwords = CTRL_CNT + 2 * B * 16;
+    for (int i = tid; i < nwords; i += NTH) __hip_atomic_store(ctrl + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 extern "C" int rg_fwd_ctrl_words(int B) { return CTRL_CNT + 2 * B * 16; }
@@ -750,10 +771,6 @@ extern "C" int rg_denoiser_forward(rg_handle* h, const rg_fwd_args* args_host, v
     attr = true;
   }
   hipStream_t s = rg_stream(stream);
-  if (hipMemsetAsync(a.ctrl, 0, sizeof(unsigned) * rg_fwd_ctrl_words(a.B), s) != hipSuccess) {
-    h->err = "rg_denoiser_forward: memset failed";
-    return RG_ERR_HIP;
-  }
   hipLaunchKernelGGL(rg_fwd_kernel, dim3(h->num_cus), dim3(NTH), LDS_BYTES, s, a);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
