@@ -1,15 +1,18 @@
 // One denoiser forward (both classifier-free branches of B clips, 8 layers) as ONE persistent dataflow launch.
 //
 // Why: at M = 2*B*43 <= ~4k token rows every per-op launch of the layer chain is latency, not throughput (launch
-// boundary + first dependent load + per-CU L2->LDS intake).  The sequences of a batch are
-// independent chains (linear attention only mixes the 43 tokens of one sequence, everything else is row-local), so
-// the chain is cut into tiles (sequence x 64 output columns, or sequence x head pair) that depend only on earlier
-// tiles of the SAME sequence.  Workgroups pull tiles from per-shard queues in topological order; a tile
-//   1. requests its weight panel by LDS-DMA (no dependency: the stream runs while the tile waits),
+// boundary + first dependent load + per-CU intake).  The sequences of a batch are independent
+// chains (linear attention only mixes the 43 tokens of one sequence, everything else is row-local), so the chain is
+// cut into tiles (sequence x 64 output columns, or sequence x head pair) that depend only on earlier tiles of the
+// SAME sequence.  Workgroups (4 waves, 2-3 resident per CU so one tile's latencies hide behind another's work) pull
+// tiles from per-shard queues in topological order; a tile
+//   1. requests its weight slice straight into registers (no dependency: the loads fly while the tile waits; a wave
+//      owns 16 output columns and holds their whole K = 512 slice in 64 VGPRs, so the K loop has no LDS staging of
+//      weights and no barriers),
 //   2. waits until the sequence's completion counter says its inputs exist (one lane polls with sc1 loads),
 //   3. builds its bf16 A panel [48 x 512] in LDS from the sequence's activations (sc1 loads; LayerNorm or
 //      LN * (1 + scale) + shift -> SiLU evaluated in fp32 on the way in),
-//   4. runs the K loop on the matrix cores (v_mfma_f32_16x16x32_bf16) against the weight ring,
+//   4. runs the K loop on the matrix cores (v_mfma_f32_16x16x32_bf16, A fragments from LDS, B from registers),
 //   5. applies the stage's epilogue (bias, GELU, residual, the two attention softmaxes and the 32x32 linear
 //      attention products, row statistics) and writes its outputs with write-through (sc1) 16-byte stores,
 //   6. waits for its stores (vmcnt(0) in every wave, workgroup barrier) and adds 1 to the sequence's counter.
@@ -25,14 +28,11 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int TP = 48;          // token rows of a tile (T <= 48; rows >= T repeat the last token and are never stored)
 constexpr int DM = 512;         // model width
 constexpr int HD = 32;          // head dim
 constexpr int NTH = 256;        // 4 waves
-constexpr int NS = 8;           // weight ring depth (64 x 64 bf16 tiles of 8 KiB)
-constexpr int WT_BYTES = 8192;
 constexpr int SC1 = 16;         // cache-policy bit of the buffer builtins: sc1
 constexpr int EPLD = 68;        // fp32 staging row stride (floats)
 constexpr int AH_LD = 33;
@@ -42,19 +42,17 @@ constexpr int CTRL_DONE = CTRL_ABORT + 1;       // workgroups that have drained 
 constexpr int CTRL_CNT = CTRL_ABORT + 32;      // first completion counter; one per sequence, 16 words apart
 constexpr unsigned SPIN_LIMIT = 1u << 20;      // polls before a wait gives up (~1 s)
 
-// ---- LDS map (bytes)
-constexpr int OFF_A = 0;                            // bf16 A panel [48][512], chunk-swizzled; reused as q/k/v fp32 staging
-constexpr int OFF_EPI = OFF_A + TP * 1024;          // epilogue staging: fp32 [48][68] (+ A_h [2][32][33] behind it)
-constexpr int EPI_BYTES = 24576;
-constexpr int OFF_W = OFF_EPI + EPI_BYTES;          // weight ring
-constexpr int OFF_PAR = OFF_W + NS * WT_BYTES;      // fp32 [4][512]: gamma, beta, 1 + scale, shift
-constexpr int OFF_ROW = OFF_PAR + 4 * DM * 4;       // fp32 [48][2]: mean, rstd
+// ---- LDS map (bytes).  The A panel region doubles as the epilogue's fp32 staging once the K loop is done:
+//      sQ [48][68] | sK [48][68] | sV [48][68] | A_h [2][32][33]
+constexpr int OFF_A = 0;                            // bf16 A panel [48][512], 16-byte chunks XOR-swizzled by row & 15
+constexpr int STG = TP * EPLD * 4;                  // 13056 bytes: one fp32 staging tile
+constexpr int OFF_PAR = OFF_A + TP * 1024;          // fp32 [2][512]: LayerNorm gain / offset (stylization folded in)
+constexpr int OFF_ROW = OFF_PAR + 2 * DM * 4;       // fp32 [48][2]: mean, rstd
 constexpr int OFF_MASK = OFF_ROW + TP * 2 * 4;      // fp32 [48] token mask
-constexpr int OFF_CTL = OFF_MASK + 256;             // ints: [0] ticket, [1] abort, [2] last workgroup
+constexpr int OFF_CTL = OFF_MASK + TP * 4;          // ints: [0] ticket, [1] abort, [2] last workgroup
 constexpr int LDS_BYTES = OFF_CTL + 64;
-static_assert(3 * TP * EPLD * 4 <= TP * 1024, "q/k/v staging must fit the A panel");
-static_assert(TP * EPLD * 4 + 2 * HD * AH_LD * 4 <= EPI_BYTES, "epilogue staging");
-static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+static_assert(3 * STG + 2 * HD * AH_LD * 4 <= TP * 1024, "epilogue staging must fit the A panel");
+static_assert(3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
   __bf16 b = (__bf16)f;
@@ -78,7 +76,6 @@ __device__ __forceinline__ float gelu_fast(float v) {
   const float e = 1.0f - pl * t * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
   return 0.5f * v + 0.5f * fabsf(v) * e;
 }
-__device__ __forceinline__ int w_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
@@ -95,19 +92,11 @@ __device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, int byte_off, u32x
 __device__ __forceinline__ f32x4 asf(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
 __device__ __forceinline__ u32x4 asu(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
-}
-// wait until at most `younger` weight tiles (2 DMA instructions per wave each) issued after the current one are in flight
-template <int MAXY>
-__device__ __forceinline__ void wait_tiles(int younger) {
-  if constexpr (MAXY <= 0) {
-    wait_vmcnt<0>();
-  } else {
-    if (younger >= MAXY) wait_vmcnt<MAXY * 2>();
-    else wait_tiles<MAXY - 1>(younger);
-  }
+// plain (cached) loads of launch inputs -- weights, biases, tables -- through a global-address-space pointer: pointers that
+// come out of the layer table in memory would otherwise be treated as generic (flat_load: slower, ties up lgkmcnt)
+template <class V>
+__device__ __forceinline__ V gld(const void* p) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) V*>(reinterpret_cast<uintptr_t>(p));
 }
 
 enum { PM_F32 = 0, PM_F32_LN = 1, PM_BF16 = 2, PM_BF16_STYL = 3, PM_TAB = 4 };
@@ -127,14 +116,6 @@ struct Panel {
   unsigned long long tabflags;   // PM_TAB: bit n set -> token n takes table row 1
 };
 
-// One stream of 64 x 64 weight tiles: tile i = rows [n0[j], n0[j] + 64) of W[j], k in [64 * (i / nsub), +64), j = i % nsub
-struct WStream {
-  const unsigned short* w[3];
-  int ldw;
-  int nsub;
-  int ntiles;
-};
-
 struct EpiOut {
   float* o32;            // fp32 [rows][ld32] or null
   int ld32;
@@ -143,21 +124,20 @@ struct EpiOut {
   float* stats;          // (sum, M2) partial per row: stats + (row * stats_ld + part) * 2, or null
   int stats_ld, part;
   bool stats_bf16;       // statistics of the bf16-rounded values (the consumer normalises the bf16 tensor)
-  const float* residual; // fp32 [rows][512] or null (sc1 loads)
+  const float* residual; // fp32 [rows][512] added to the tile (sc1 loads), or null
   const float* tbias;    // [T][512] or null
-  const float* bias;
   int col0;              // first output column
-  int act;               // 1 = GELU
 };
 
 }  // namespace
 
-__global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
+__global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem + OFF_A;
-  float* sEpi = reinterpret_cast<float*>(smem + OFF_EPI);
-  float* sAh = sEpi + TP * EPLD;
-  unsigned char* sW = smem + OFF_W;
+  float* sQ = reinterpret_cast<float*>(smem + OFF_A);             // staging tile 0 (generic epilogue: the output tile)
+  float* sK = reinterpret_cast<float*>(smem + OFF_A + STG);       // staging tile 1 (attention: k, then y)
+  float* sV = reinterpret_cast<float*>(smem + OFF_A + 2 * STG);
+  float* sAh = reinterpret_cast<float*>(smem + OFF_A + 3 * STG);
   float* sPar = reinterpret_cast<float*>(smem + OFF_PAR);
   float* sRow = reinterpret_cast<float*>(smem + OFF_ROW);
   float* sMask = reinterpret_cast<float*>(smem + OFF_MASK);
@@ -192,13 +172,49 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
     next_ticket = take();
   }
 
-  // per-lane weight DMA geometry: a tile is 8 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w and w + 4
-  int wrow[2], wlc[2];
+  // ---- weight slice of this wave's 16 columns for one K = 512 panel, straight into registers: lane (l15, g4) holds,
+  // for each 64-wide k block, the 32 bytes W[row l15][64 kb + 16 g4 .. + 16): the 4 lanes of a row read one whole
+  // 128-byte line.  The first 8 values feed MFMA step 0, the last 8 step 1; the A fragments are read from LDS with the
+  // same enumeration of the contraction index (chunk 8 kb + 2 g4 + s).
+  auto load_h = [&](u32x4(&wb)[8], const unsigned short* wp) {   // one half panel: k in [wp, wp + 256)
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    wrow[q] = (wave + 4 * q) * 8 + (lane >> 3);
-    wlc[q] = (lane & 7) ^ ((wrow[q] >> 1) & 7);
-  }
+    for (int kb = 0; kb < 4; ++kb) {
+      wb[2 * kb] = gld<u32x4>(wp + kb * 64);
+      wb[2 * kb + 1] = gld<u32x4>(wp + kb * 64 + 8);
+    }
+  };
+  // A fragment of row tile r, k block kbt (0..7), MFMA step s: chunk 8 kbt + 2 g4 + s of row 16 r + l15, stored at
+  // chunk ^ l15.  Its low four bits are (2 g4 ^ l15) ^ (8 (kbt & 1) + s): four per-lane base offsets, everything
+  // else is an immediate.
+  const int lx = (2 * g4) ^ l15;
+  const int ab0 = l15 * 1024 + (lx << 4), ab1 = l15 * 1024 + ((lx ^ 1) << 4);
+  const int ab8 = l15 * 1024 + ((lx ^ 8) << 4), ab9 = l15 * 1024 + ((lx ^ 9) << 4);
+  // The fragments of k block kb are read one block ahead of their MFMAs (two register sets); the scheduling barriers
+  // keep the compiler from hoisting every LDS read of a panel in front of the first MFMA (hundreds of VGPRs)
+  auto mma_h = [&](const u32x4(&wb)[8], f32x4(&ac)[3], int kb0) {   // kb0 = 0 / 4: first / second half of the A panel
+    bf16x8 af[2][6];
+    auto frags = [&](bf16x8(&f)[6], int kb) {
+      const int kbt = kb0 + kb;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int ab = (kb & 1) ? (s ? ab9 : ab8) : (s ? ab1 : ab0);   // kb0 is even: kbt & 1 == kb & 1
+#pragma unroll
+        for (int r = 0; r < 3; ++r) f[s * 3 + r] = *reinterpret_cast<const bf16x8*>(sA + ab + r * 16384 + (kbt >> 1) * 256);
+      }
+    };
+    frags(af[0], 0);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      if (kb + 1 < 4) frags(af[(kb + 1) & 1], kb + 1);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, wb[2 * kb + s]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ac[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb & 1][s * 3 + r], bfr, ac[r], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
 
   while (true) {
     if (tid == 0) sCtl[0] = next_ticket;
@@ -215,67 +231,52 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
     unsigned long long* stamp = a.stamps ? a.stamps + 4 * (size_t)ticket : nullptr;
     if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
 
+    // index arithmetic below uses an opaque copy of the thread id: the loop-invariant address math of every unrolled
+    // load / store would otherwise be hoisted out of the tile loop and live (spilled) across it
+    int vt = tid;
+    asm volatile("" : "+v"(vt));
     const bool cond = seq < B;
     const int clip = cond ? seq : seq - B;
     const int row0 = seq * T;                       // global row of token 0
     const rg_fwd_layer* LW = a.layers + layer;
     const float* ssl = a.ss + ((size_t)a.step * a.L + layer) * 5 * 1024;
 
-    // ---- stage description
-    WStream ws;
-    ws.w[0] = ws.w[1] = ws.w[2] = nullptr;
-    ws.nsub = 1;
-    int npanels = 1;
+    // ---- weight panels of the stage: panel p = rows [n0, n0 + 64) of W, k in [wk0 + 512 p, + 512)
+    const unsigned short* wbase;
+    int ldw = DM, nwp = 1;
     switch (type) {
-      case RG_FWD_EMBED:
-        ws.w[0] = reinterpret_cast<const unsigned short*>(a.w_embed) + (size_t)nt * 64 * DM; ws.ldw = DM; break;
-      case RG_FWD_QKV_SA: {
-        const unsigned short* w = reinterpret_cast<const unsigned short*>(LW->w_qkv);
-        ws.w[0] = w + (size_t)(nt * 64) * DM;
-        ws.w[1] = w + (size_t)(DM + nt * 64) * DM;
-        ws.w[2] = w + (size_t)(2 * DM + nt * 64) * DM;
-        ws.ldw = DM; ws.nsub = 3;
-      } break;
-      case RG_FWD_SAOUT:
-        ws.w[0] = reinterpret_cast<const unsigned short*>(LW->w_sao) + (size_t)nt * 64 * DM; ws.ldw = DM; break;
-      case RG_FWD_Q3_CA:   // nt = cond * 8 + head pair: rows cond * 512 + hp * 64 = nt * 64
-        ws.w[0] = reinterpret_cast<const unsigned short*>(LW->w_q3) + (size_t)nt * 64 * DM; ws.ldw = DM; break;
-      case RG_FWD_MIX:
-        ws.w[0] = reinterpret_cast<const unsigned short*>(LW->w_mix) + (size_t)nt * 64 * (4 * DM); ws.ldw = 4 * DM; npanels = 4; break;
-      case RG_FWD_FF1:
-        ws.w[0] = reinterpret_cast<const unsigned short*>(LW->w_ff1) + (size_t)nt * 64 * DM; ws.ldw = DM; break;
-      case RG_FWD_FF2:
-        ws.w[0] = reinterpret_cast<const unsigned short*>(LW->w_ff2) + (size_t)nt * 64 * (2 * DM); ws.ldw = 2 * DM; npanels = 2; break;
-      case RG_FWD_FFOUT:
-        ws.w[0] = reinterpret_cast<const unsigned short*>(LW->w_ffo) + (size_t)nt * 64 * DM; ws.ldw = DM; break;
-      default:
-        ws.w[0] = reinterpret_cast<const unsigned short*>(a.w_out) + (size_t)nt * 64 * DM; ws.ldw = DM; break;
+      case RG_FWD_EMBED: wbase = reinterpret_cast<const unsigned short*>(a.w_embed); break;
+      case RG_FWD_QKV_SA: wbase = reinterpret_cast<const unsigned short*>(LW->w_qkv); nwp = 3; break;   // q, k, v row blocks
+      case RG_FWD_SAOUT: wbase = reinterpret_cast<const unsigned short*>(LW->w_sao); break;
+      case RG_FWD_Q3_CA: wbase = reinterpret_cast<const unsigned short*>(LW->w_q3); break;   // nt = cond * 8 + head pair
+      case RG_FWD_MIX: wbase = reinterpret_cast<const unsigned short*>(LW->w_mix); ldw = 4 * DM; nwp = 4; break;
+      case RG_FWD_FF1: wbase = reinterpret_cast<const unsigned short*>(LW->w_ff1); break;
+      case RG_FWD_FF2: wbase = reinterpret_cast<const unsigned short*>(LW->w_ff2); ldw = 2 * DM; nwp = 2; break;
+      case RG_FWD_FFOUT: wbase = reinterpret_cast<const unsigned short*>(LW->w_ffo); break;
+      default: wbase = reinterpret_cast<const unsigned short*>(a.w_out); break;
     }
-    ws.ntiles = npanels * 8 * ws.nsub;
+    // this lane's row of the slice; QKV: panel p is the q / k / v row block, others: panel p is the next 512 k
+    const unsigned short* wlane = wbase + (size_t)(nt * 64 + 16 * wave + l15) * ldw + 16 * g4;
+    const size_t wstep = type == RG_FWD_QKV_SA ? (size_t)DM * DM : (size_t)DM;
 
-    // ---- weight ring: tile i -> stage i % NS
-    auto issue = [&](int i) {
-      unsigned char* st = sW + (i % NS) * WT_BYTES;
-      const int kt = i / ws.nsub, j = i - kt * ws.nsub;
-      const unsigned short* wj = j == 0 ? ws.w[0] : (j == 1 ? ws.w[1] : ws.w[2]);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_global_load_lds((const void*)(wj + (size_t)wrow[q] * ws.ldw + kt * 64 + wlc[q] * 8),
-                                         (lds_void*)(st + (wave + 4 * q) * 1024), 16, 0, 0);
-    };
-#pragma unroll
-    for (int i = 0; i < NS - 1; ++i)
-      if (i < ws.ntiles) issue(i);
+    // two half-panel buffers (k 0-255 / 256-511 of a panel: 32 VGPRs each), refilled as soon as their MFMAs are issued.
+    // Waves 1-3 request the first panel now; wave 0 polls first (its loads would sit in front of the poll's return
+    // in the in-order vmcnt queue) and requests it when the dependency has resolved
+    u32x4 wa[8], wb[8];
+    if (wave != 0) {
+      load_h(wa, wlane);
+      load_h(wb, wlane + 256);
+    }
 
-    // ---- token masks of this sequence (inputs of the launch: plain loads)
-    if (tid < TP) sMask[tid] = tid < T ? a.src_mask[(size_t)seq * T + tid] : 0.f;
+    // ---- token mask of this sequence (input of the launch: plain loads)
+    if (tid < TP) sMask[tid] = tid < T ? gld<float>(a.src_mask + (size_t)seq * T + tid) : 0.f;
     // A_h of the cross attention (two heads of one condition of this clip): requested now, parked in LDS later
     f32x4 apre[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     if (type == RG_FWD_Q3_CA) {
       const int c = nt >> 3, hp = nt & 7;
       const float* ap = LW->a_pre + ((((size_t)c * B + clip) * 16 + hp * 2) * HD) * HD;   // two consecutive heads: 2048 floats
-      apre[0] = *reinterpret_cast<const f32x4*>(ap + tid * 8);
-      apre[1] = *reinterpret_cast<const f32x4*>(ap + tid * 8 + 4);
+      apre[0] = gld<f32x4>(ap + tid * 8);
+      apre[1] = gld<f32x4>(ap + tid * 8 + 4);
     }
 
     // ---- dependency: every earlier tile of this sequence has published
@@ -297,39 +298,33 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
     __syncthreads();
     if (sCtl[1]) break;
     if (stamp && tid == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();
-
-    // ---- residual rows for the epilogue (thread -> (row, 16-byte piece) x 3), requested before the K loop
-    const float* res_src = type == RG_FWD_SAOUT ? a.xa : (type == RG_FWD_FFOUT ? a.xc : nullptr);
-    f32x4 resv[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) resv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (res_src) {
-      const __amdgpu_buffer_rsrc_t rr = rsrc_of(res_src + (size_t)row0 * DM);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int it = tid + NTH * j, row = it >> 4, c4 = it & 15;
-        const int rl = row < T ? row : T - 1;
-        resv[j] = asf(ld16(rr, (rl * DM + nt * 64 + c4 * 4) * 4));
-      }
+    if (wave == 0) {
+      load_h(wa, wlane);
+      load_h(wb, wlane + 256);
     }
 
     // ---- A panel builder
     auto fill_panel = [&](const Panel& p) {
       const bool norm = p.mode == PM_F32_LN || p.mode == PM_BF16_STYL;
       if (norm) {
-        // parameters -> LDS (inputs of the launch: plain loads), row statistics -> (mean, rstd)
-        {
-          const int i4 = (tid & 127) * 4;
-          const float* src = tid < 128 ? p.gamma : p.beta;
-          *reinterpret_cast<f32x4*>(sPar + (tid < 128 ? 0 : DM) + i4) = *reinterpret_cast<const f32x4*>(src + i4);
+        // LayerNorm gain / offset with the stylization folded in: LN(x) * (1 + scale) + shift = xhat * g' + b',
+        // g' = gamma (1 + scale), b' = beta (1 + scale) + shift  (inputs of the launch: plain loads)
+        if (vt < 128) {
+          const int i4 = vt * 4;
+          f32x4 ga = gld<f32x4>(p.gamma + i4);
+          f32x4 be = gld<f32x4>(p.beta + i4);
           if (p.mode == PM_BF16_STYL) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.ss + (tid < 128 ? 0 : DM) + i4);
-            if (tid < 128) v = v + 1.0f;
-            *reinterpret_cast<f32x4*>(sPar + (tid < 128 ? 2 * DM : 3 * DM) + i4) = v;
+            const f32x4 sc = gld<f32x4>(p.ss + i4) + 1.0f;
+            const f32x4 sh = gld<f32x4>(p.ss + DM + i4);
+            ga = ga * sc;
+            be = be * sc + sh;
           }
-        }
-        if (tid < TP) {
-          const int rl = tid < T ? tid : T - 1;
+          *reinterpret_cast<f32x4*>(sPar + i4) = ga;
+          *reinterpret_cast<f32x4*>(sPar + DM + i4) = be;
+        } else if (vt < 128 + TP) {
+          // row statistics -> (mean, rstd): 8 partial (sum, M2) pairs per row, combined exactly (Chan)
+          const int r = vt - 128;
+          const int rl = r < T ? r : T - 1;
           const __amdgpu_buffer_rsrc_t rs = rsrc_of(p.stats);
           const int off = (((p.row0 + rl) * p.stats_ld) + p.part0) * 8;
           f32x4 s[4];
@@ -345,26 +340,26 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
             const float d0 = s[q][0] * (1.0f / 64) - mean, d1 = s[q][2] * (1.0f / 64) - mean;
             m2 += s[q][1] + s[q][3] + 64.0f * (d0 * d0 + d1 * d1);
           }
-          sRow[2 * tid] = mean;
-          sRow[2 * tid + 1] = rsqrtf(m2 * (1.0f / DM) + 1e-5f);
+          sRow[2 * r] = mean;
+          sRow[2 * r + 1] = rsqrtf(m2 * (1.0f / DM) + 1e-5f);
         }
-        __syncthreads();
       }
       if (p.mode == PM_F32 || p.mode == PM_F32_LN) {
-        // unit = 4 floats (one 16-byte load) -> 4 bf16; 24 units per thread in 3 batches of 8
+        // unit = 4 floats (one 16-byte load) -> 4 bf16; 24 units per thread in 2 batches of 12
         const __amdgpu_buffer_rsrc_t rs = rsrc_of(reinterpret_cast<const float*>(p.src) + (size_t)p.row0 * p.ld + p.col0);
 #pragma unroll 1
-        for (int b8 = 0; b8 < 3; ++b8) {
-          f32x4 v[8];
+        for (int b8 = 0; b8 < 2; ++b8) {
+          f32x4 v[12];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int u = tid + NTH * (b8 * 8 + j), row = u >> 7, q = u & 127;
+          for (int j = 0; j < 12; ++j) {
+            const int u = vt + NTH * (b8 * 12 + j), row = u >> 7, q = u & 127;
             const int rl = row < T ? row : T - 1;
             v[j] = asf(ld16(rs, (rl * p.ld + q * 4) * 4));
           }
+          if (norm && b8 == 0) __syncthreads();   // parameters and row statistics are in LDS
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int u = tid + NTH * (b8 * 8 + j), row = u >> 7, q = u & 127;
+          for (int j = 0; j < 12; ++j) {
+            const int u = vt + NTH * (b8 * 12 + j), row = u >> 7, q = u & 127;
             f32x4 x = v[j];
             if (p.mode == PM_F32_LN) {
               const float mean = sRow[2 * row], rstd = sRow[2 * row + 1];
@@ -384,13 +379,14 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
         u32x4 v[12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-          const int u = tid + NTH * j, row = u >> 6, ch = u & 63;
+          const int u = vt + NTH * j, row = u >> 6, ch = u & 63;
           const int rl = row < T ? row : T - 1;
           v[j] = ld16(rs, (rl * p.ld + ch * 8) * 2);
         }
+        if (norm) __syncthreads();
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-          const int u = tid + NTH * j, row = u >> 6, ch = u & 63;
+          const int u = vt + NTH * j, row = u >> 6, ch = u & 63;
           u32x4 o = v[j];
           if (p.mode == PM_BF16_STYL) {
             const float mean = sRow[2 * row], rstd = sRow[2 * row + 1];
@@ -399,13 +395,8 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
             for (int h = 0; h < 2; ++h) {
               const f32x4 ga = *reinterpret_cast<const f32x4*>(sPar + ch * 8 + 4 * h);
               const f32x4 be = *reinterpret_cast<const f32x4*>(sPar + DM + ch * 8 + 4 * h);
-              const f32x4 sc = *reinterpret_cast<const f32x4*>(sPar + 2 * DM + ch * 8 + 4 * h);
-              const f32x4 sh = *reinterpret_cast<const f32x4*>(sPar + 3 * DM + ch * 8 + 4 * h);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float ln = (x[4 * h + e] - mean) * rstd * ga[e] + be[e];
-                x[4 * h + e] = silu_f(ln * sc[e] + sh[e]);
-              }
+              for (int e = 0; e < 4; ++e) x[4 * h + e] = silu_f(fmaf((x[4 * h + e] - mean) * rstd, ga[e], be[e]));
             }
             o = u32x4{pack2(x[0], x[1]), pack2(x[2], x[3]), pack2(x[4], x[5]), pack2(x[6], x[7])};
           }
@@ -415,10 +406,10 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
         const unsigned short* tab = reinterpret_cast<const unsigned short*>(p.src) + p.col0;
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-          const int u = tid + NTH * j, row = u >> 6, ch = u & 63;
+          const int u = vt + NTH * j, row = u >> 6, ch = u & 63;
           const int rl = row < T ? row : T - 1;
           const int var = (int)((p.tabflags >> rl) & 1ull);
-          const u32x4 o = *reinterpret_cast<const u32x4*>(tab + (size_t)var * p.ld + ch * 8);
+          const u32x4 o = gld<u32x4>(tab + (size_t)var * p.ld + ch * 8);
           *reinterpret_cast<u32x4*>(sA + row * 1024 + ((ch ^ (row & 15)) << 4)) = o;
         }
       }
@@ -427,7 +418,7 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
 
     // query-mask bit set of (condition c, this sequence): bit n set -> token n is masked (qmask == 0)
     auto qmask_bits = [&](int c) -> unsigned long long {
-      const float mv = lane < T ? a.qmask[((size_t)c * 2 * B + seq) * T + lane] : 1.0f;
+      const float mv = lane < T ? gld<float>(a.qmask + ((size_t)c * 2 * B + seq) * T + lane) : 1.0f;
       return __ballot(mv == 0.f);
     };
 
@@ -463,62 +454,55 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
       return p;
     };
 
-    // ---- K loop
-    f32x4 acc[3][3];
+    // ---- K loops.  Panel p accumulates into acc[p]: the three row blocks of QKV stay apart (q, k, v), the K panels of
+    // the other stages are summed in the epilogue -- one straight-line schedule for every stage
+    const bool qkv = type == RG_FWD_QKV_SA;
+    f32x4 acc[4][3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 3; ++r) acc[j][r] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    auto mma = [&](const unsigned char* st, int ktp, f32x4(&ac)[3]) {
+    fill_panel(panel_of(0));
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(st + w_lds_off(16 * wave + l15, 4 * s + g4));
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(sA + (r * 16 + l15) * 1024 + (((ktp * 8 + 4 * s + g4) ^ l15) << 4));
-          ac[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, ac[r], 0, 0, 0);
+    for (int p = 0; p < 4; ++p) {
+      if (p < nwp) {
+        if (p > 0 && !qkv) {   // next 512 columns of A
+          __syncthreads();
+          fill_panel(panel_of(p));
         }
-      }
-    };
-
-    {
-      const int per_panel = 8 * ws.nsub;
-      int i = 0;
-      for (int pi = 0; pi < npanels; ++pi) {
-        const Panel p = panel_of(pi);
-        fill_panel(p);
-        for (int ip = 0; ip < per_panel; ++ip, ++i) {
-          const int younger = min(NS - 2, ws.ntiles - 1 - i);
-          wait_tiles<NS - 2>(younger);
-          __builtin_amdgcn_s_barrier();
-          if (i + NS - 1 < ws.ntiles) issue(i + NS - 1);
-          const unsigned char* st = sW + (i % NS) * WT_BYTES;
-          const int ktp = ip / ws.nsub, j = ip - ktp * ws.nsub;
-          if (j == 0) mma(st, ktp, acc[0]);
-          else if (j == 1) mma(st, ktp, acc[1]);
-          else mma(st, ktp, acc[2]);
-        }
-        __syncthreads();   // every wave is done with this A panel (and, after the last panel, with LDS operands at all)
+        mma_h(wa, acc[p], 0);
+        if (p + 1 < nwp) load_h(wa, wlane + (p + 1) * wstep);
+        mma_h(wb, acc[p], 4);
+        if (p + 1 < nwp) load_h(wb, wlane + (p + 1) * wstep + 256);
       }
     }
-    if (stamp && tid == 0) stamp[2] = __builtin_amdgcn_s_memrealtime();
+    __syncthreads();   // every wave is done with the A panel: the region becomes epilogue staging
+    if (stamp && vt == 0) stamp[2] = __builtin_amdgcn_s_memrealtime();
 
-    // ---- row-major output pass shared by all stages: sEpi[48][68] fp32 holds the tile (before residual / tbias)
-    auto store_tile = [&](const EpiOut& eo) {
-      // fp32 pass: thread -> (row, 4 columns) x 3; adds residual / positional table, stores fp32, leaves the value in sEpi
+    // ---- row-major output pass shared by all stages: src[48][68] fp32 holds the tile (before residual / tbias)
+    auto store_tile = [&](float* src, const EpiOut& eo) {
+      // fp32 pass: thread -> (row, 4 columns) x 3; adds residual / positional table, stores fp32, leaves the value in src
       if (eo.o32 || eo.residual || eo.tbias) {
         const __amdgpu_buffer_rsrc_t ro = rsrc_of(eo.o32 ? eo.o32 + (size_t)row0 * eo.ld32 + eo.col0 : nullptr);
+        f32x4 resv[3];
+        if (eo.residual) {
+          const __amdgpu_buffer_rsrc_t rr = rsrc_of(eo.residual + (size_t)row0 * DM + eo.col0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int it = vt + NTH * j, row = it >> 4, c4 = it & 15;
+            resv[j] = asf(ld16(rr, ((row < T ? row : T - 1) * DM + c4 * 4) * 4));
+          }
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const int it = tid + NTH * j, row = it >> 4, c4 = it & 15;
-          f32x4 v = *reinterpret_cast<const f32x4*>(sEpi + row * EPLD + c4 * 4);
+          const int it = vt + NTH * j, row = it >> 4, c4 = it & 15;
+          f32x4 v = *reinterpret_cast<const f32x4*>(src + row * EPLD + c4 * 4);
           if (eo.residual) v = v + resv[j];
           if (eo.tbias) {
             const int rl = row < T ? row : T - 1;
-            v = v + *reinterpret_cast<const f32x4*>(eo.tbias + (size_t)rl * DM + eo.col0 + c4 * 4);
+            v = v + gld<f32x4>(eo.tbias + (size_t)rl * DM + eo.col0 + c4 * 4);
           }
-          if (eo.residual || eo.tbias) *reinterpret_cast<f32x4*>(sEpi + row * EPLD + c4 * 4) = v;
+          if (eo.residual || eo.tbias) *reinterpret_cast<f32x4*>(src + row * EPLD + c4 * 4) = v;
           if (eo.o32 && row < T) st16(ro, (row * eo.ld32 + c4 * 4) * 4, asu(v));
         }
         if ((eo.residual || eo.tbias) && (eo.o16 || eo.stats)) __syncthreads();
@@ -527,21 +511,21 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
         const __amdgpu_buffer_rsrc_t ro = rsrc_of(eo.o16 + (size_t)row0 * eo.ld16 + eo.col0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int it = tid + NTH * j, row = it >> 3, c8 = it & 7;
+          const int it = vt + NTH * j, row = it >> 3, c8 = it & 7;
           if (it < TP * 8 && row < T) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4*>(sEpi + row * EPLD + c8 * 8);
-            const f32x4 x1 = *reinterpret_cast<const f32x4*>(sEpi + row * EPLD + c8 * 8 + 4);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + row * EPLD + c8 * 8);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + row * EPLD + c8 * 8 + 4);
             st16(ro, (row * eo.ld16 + c8 * 8) * 2, u32x4{pack2(x0[0], x0[1]), pack2(x0[2], x0[3]), pack2(x1[0], x1[1]), pack2(x1[2], x1[3])});
           }
         }
       }
-      if (eo.stats && tid < TP * 4) {
+      if (eo.stats && vt < TP * 4) {
         // (sum, M2 about the part's own mean) over the tile's 64 columns: 4 threads per row, 16 columns each
-        const int row = tid >> 2, part = tid & 3;
+        const int row = vt >> 2, part = vt & 3;
         float x[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(sEpi + row * EPLD + part * 16 + 4 * q);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(src + row * EPLD + part * 16 + 4 * q);
           x[4 * q] = t[0]; x[4 * q + 1] = t[1]; x[4 * q + 2] = t[2]; x[4 * q + 3] = t[3];
         }
         if (eo.stats_bf16) {
@@ -566,9 +550,9 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
       }
     };
 
-    // accumulators (+ bias, activation) -> sEpi; wave w owns columns [16w, 16w + 16)
+    // accumulators (+ bias, activation) -> staging tile; wave w owns columns [16w, 16w + 16)
     auto acc_to_lds = [&](f32x4(&ac)[3], float* dst, const float* bias, int act) {
-      const float bv = bias ? bias[16 * wave + l15] : 0.f;
+      const float bv = gld<float>(bias + 16 * wave + l15);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -579,13 +563,14 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
         }
     };
 
-    // y[n][c] = sum_d qs[n][h*32 + d] * A_h[h][d][c & 31] for the 64 columns (2 heads) of the tile; q rows in sQ
-    // (fp32 [48][68]), A_h in sAh; result -> sEpi.  maskbits: rows whose y is rounded like the reference's y - 1e6.
-    auto qa_to_epi = [&](const float* sQ, unsigned long long maskbits) {
-      const int c = tid & 63, h = c >> 5, l = c & 31;
+    // y[n][c] = sum_d qs[n][h*32 + d] * A_h[h][d][c & 31] for the 64 columns (2 heads) of the tile; q rows in sQ,
+    // A_h in sAh; result -> sK.  maskbits: rows whose y is rounded like the reference's y - 1e6.
+    auto qa_to_sk = [&](unsigned long long maskbits) {
+      const int c = vt & 63, h = c >> 5, l = c & 31;
       float Ar[HD];
 #pragma unroll
       for (int d = 0; d < HD; ++d) Ar[d] = sAh[(h * HD + d) * AH_LD + l];
+#pragma unroll 2
       for (int n = wave; n < TP; n += 4) {
         const float* qr = sQ + n * EPLD + h * HD;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -602,72 +587,86 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
           const float z = y + (-1000000.0f);
           y = z + 1000000.0f;
         }
-        sEpi[n * EPLD + c] = y;
+        sK[n * EPLD + c] = y;
       }
     };
-    // softmax over each head's 32 columns of the q rows in sQ: thread -> (row, head), 96 threads
-    auto q_softmax = [&](float* sQ) {
-      if (tid < TP * 2) {
-        float* qr = sQ + (tid >> 1) * EPLD + (tid & 1) * HD;
-        float v[HD];
+    // softmax over each head's 32 columns of the q rows in sQ: 4 lanes per (row, head), 8 values each
+    auto q_softmax = [&]() {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(qr + 4 * q);
-          v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+      for (int j = 0; j < 2; ++j) {
+        const int it = vt + NTH * j;
+        if (it < TP * 8) {
+          float* qr = sQ + (it >> 3) * EPLD + (it & 7) * 8;
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(qr), t1 = *reinterpret_cast<const f32x4*>(qr + 4);
+          float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+          float mx = v[0];
+#pragma unroll
+          for (int e = 1; e < 8; ++e) mx = fmaxf(mx, v[e]);
+          mx = fmaxf(mx, __shfl_xor(mx, 1));
+          mx = fmaxf(mx, __shfl_xor(mx, 2));
+          float sum = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { v[e] = __expf(v[e] - mx); sum += v[e]; }
+          sum += __shfl_xor(sum, 1);
+          sum += __shfl_xor(sum, 2);
+          const float inv = 1.0f / sum;
+          *reinterpret_cast<f32x4*>(qr) = f32x4{v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv};
+          *reinterpret_cast<f32x4*>(qr + 4) = f32x4{v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv};
         }
-        float mx = v[0];
-#pragma unroll
-        for (int e = 1; e < HD; ++e) mx = fmaxf(mx, v[e]);
-        float sum = 0.f;
-#pragma unroll
-        for (int e = 0; e < HD; ++e) { v[e] = __expf(v[e] - mx); sum += v[e]; }
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          *reinterpret_cast<f32x4*>(qr + 4 * q) = f32x4{v[4 * q] * inv, v[4 * q + 1] * inv, v[4 * q + 2] * inv, v[4 * q + 3] * inv};
       }
     };
 
     EpiOut eo;
     eo.o32 = nullptr; eo.ld32 = DM; eo.o16 = nullptr; eo.ld16 = DM; eo.stats = nullptr; eo.stats_ld = 8; eo.part = nt;
-    eo.stats_bf16 = false; eo.residual = nullptr; eo.tbias = nullptr; eo.bias = nullptr; eo.col0 = nt * 64; eo.act = 0;
+    eo.stats_bf16 = false; eo.residual = nullptr; eo.tbias = nullptr; eo.col0 = nt * 64;
 
     if (type == RG_FWD_QKV_SA) {
-      // ---- q, k, v (+ bias) -> fp32 staging in the A panel region
-      float* sQ = reinterpret_cast<float*>(sA);
-      float* sK = sQ + TP * EPLD;
-      float* sV = sK + TP * EPLD;
+      // ---- q, k, v (+ bias) -> fp32 staging
       acc_to_lds(acc[0], sQ, LW->b_qkv + nt * 64, 0);
       acc_to_lds(acc[1], sK, LW->b_qkv + DM + nt * 64, 0);
       acc_to_lds(acc[2], sV, LW->b_qkv + 2 * DM + nt * 64, 0);
       __syncthreads();
-      // softmax of q over head_dim (waves 0-1), of k over the tokens (wave 2), v * mask (wave 3)
-      // (efficient_attention.py:32-36: key + (1 - mask) * -1e6 underflows to weight 0 exactly)
-      q_softmax(sQ);
-      if (wave == 2) {
-        const int c = lane;
-        float mx = -INFINITY;
-        for (int n = 0; n < T; ++n)
-          if (sMask[n] != 0.f) mx = fmaxf(mx, sK[n * EPLD + c]);
-        float sum = 0.f;
-        for (int n = 0; n < T; ++n) {
-          const float e = sMask[n] != 0.f ? __expf(sK[n * EPLD + c] - mx) : 0.f;
-          sK[n * EPLD + c] = e;
-          sum += e;
+      // softmax of q over head_dim; softmax of k over the tokens: 4 lanes per column, 12 tokens each
+      // (efficient_attention.py:32-36: key + (1 - mask) * -1e6 underflows to weight 0 exactly, so P = 0 on masked
+      // tokens and the value mask is implied)
+      q_softmax();
+      {
+        const int c = vt >> 2, part = vt & 3;
+        float kr[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int n = part + 4 * i;
+          const float kv = sK[(n < TP ? n : TP - 1) * EPLD + c];
+          kr[i] = (n < T && sMask[n < TP ? n : TP - 1] != 0.f) ? kv : -INFINITY;
         }
+        float mx = kr[0];
+#pragma unroll
+        for (int i = 1; i < 12; ++i) mx = fmaxf(mx, kr[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          kr[i] = kr[i] == -INFINITY ? 0.f : __expf(kr[i] - mx);
+          sum += kr[i];
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
         const float inv = 1.0f / sum;
-        for (int n = 0; n < T; ++n) sK[n * EPLD + c] *= inv;
-      } else if (wave == 3) {
-        const int c = lane;
-        for (int n = 0; n < T; ++n) sV[n * EPLD + c] *= sMask[n];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int n = part + 4 * i;
+          if (n < TP) sK[n * EPLD + c] = kr[i] * inv;
+        }
       }
       __syncthreads();
       // A_h[d][l] = sum_n P[n][d] V[n][l]: thread -> (head, d, 8 columns)
       {
-        const int h = tid >> 7, d = (tid >> 2) & 31, l0 = (tid & 3) * 8;
+        const int h = vt >> 7, d = (vt >> 2) & 31, l0 = (vt & 3) * 8;
         float s8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s8[e] = 0.f;
+#pragma unroll 4
         for (int n = 0; n < T; ++n) {
           const float pn = sK[n * EPLD + h * HD + d];
           const f32x4 v0 = *reinterpret_cast<const f32x4*>(sV + n * EPLD + h * HD + l0);
@@ -682,18 +681,17 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
         for (int e = 0; e < 8; ++e) sAh[(h * HD + d) * AH_LD + l0 + e] = s8[e];
       }
       __syncthreads();
-      qa_to_epi(sQ, 0ull);
+      qa_to_sk(0ull);
       __syncthreads();
       eo.o16 = reinterpret_cast<unsigned short*>(a.ysa);
       eo.stats = a.st_sa; eo.stats_bf16 = true;
-      store_tile(eo);
+      store_tile(sK, eo);
     } else if (type == RG_FWD_Q3_CA) {
       const int c = nt >> 3, hp = nt & 7;
-      float* sQ = reinterpret_cast<float*>(sA);
       acc_to_lds(acc[0], sQ, LW->b_q3 + nt * 64, 0);
-      // park A_h: thread tid holds floats [8 tid, 8 tid + 8) of the two heads' [2][32][32]
+      // park A_h: thread vt holds floats [8 vt, 8 vt + 8) of the two heads' [2][32][32]
       {
-        const int f0 = tid * 8, h = f0 >> 10, d = (f0 >> 5) & 31, l0 = f0 & 31;
+        const int f0 = vt * 8, h = f0 >> 10, d = (f0 >> 5) & 31, l0 = f0 & 31;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           sAh[(h * HD + d) * AH_LD + l0 + e] = apre[0][e];
@@ -702,34 +700,38 @@ __global__ void __launch_bounds__(NTH, 1) rg_fwd_kernel(const rg_fwd_args a) {
       }
       const unsigned long long mb = qmask_bits(c);
       __syncthreads();
-      q_softmax(sQ);
+      q_softmax();
       __syncthreads();
-      qa_to_epi(sQ, mb);
+      qa_to_sk(mb);
       __syncthreads();
       eo.o16 = reinterpret_cast<unsigned short*>(a.y3);
       eo.ld16 = 3 * DM; eo.col0 = c * DM + hp * 64;
       eo.stats = a.st3; eo.stats_ld = 24; eo.part = c * 8 + hp; eo.stats_bf16 = true;
-      store_tile(eo);
+      store_tile(sK, eo);
     } else {
+      const float* bias;
+      int act = 0;
       switch (type) {
-        case RG_FWD_EMBED: eo.bias = a.b_embed; eo.tbias = a.tbias; eo.o32 = a.xa; eo.stats = a.st_a; break;
+        case RG_FWD_EMBED: bias = a.b_embed; eo.tbias = a.tbias; eo.o32 = a.xa; eo.stats = a.st_a; break;
         case RG_FWD_SAOUT:
-          eo.bias = LW->b_sao; eo.residual = a.xa; eo.o32 = a.xb; eo.o16 = reinterpret_cast<unsigned short*>(a.xb_bf);
+          bias = LW->b_sao; eo.residual = a.xa; eo.o32 = a.xb; eo.o16 = reinterpret_cast<unsigned short*>(a.xb_bf);
           eo.stats = a.st_b; break;
-        case RG_FWD_MIX: eo.bias = LW->b_mix; eo.o32 = a.xc; eo.o16 = reinterpret_cast<unsigned short*>(a.xc_bf); break;
-        case RG_FWD_FF1: eo.bias = LW->b_ff1; eo.act = 1; eo.o16 = reinterpret_cast<unsigned short*>(a.g); eo.ld16 = 2 * DM; break;
+        case RG_FWD_MIX: bias = LW->b_mix; eo.o32 = a.xc; eo.o16 = reinterpret_cast<unsigned short*>(a.xc_bf); break;
+        case RG_FWD_FF1: bias = LW->b_ff1; act = 1; eo.o16 = reinterpret_cast<unsigned short*>(a.g); eo.ld16 = 2 * DM; break;
         case RG_FWD_FF2:
-          eo.bias = LW->b_ff2; eo.o16 = reinterpret_cast<unsigned short*>(a.yf); eo.stats = a.st_f; eo.stats_bf16 = true; break;
-        case RG_FWD_FFOUT: eo.bias = LW->b_ffo; eo.residual = a.xc; eo.o32 = a.xa; eo.stats = a.st_a; break;
-        default: eo.bias = a.b_out; eo.o32 = a.head; break;
+          bias = LW->b_ff2; eo.o16 = reinterpret_cast<unsigned short*>(a.yf); eo.stats = a.st_f; eo.stats_bf16 = true; break;
+        case RG_FWD_FFOUT: bias = LW->b_ffo; eo.residual = a.xc; eo.o32 = a.xa; eo.stats = a.st_a; break;
+        default: bias = a.b_out; eo.o32 = a.head; break;
       }
-      acc_to_lds(acc[0], sEpi, eo.bias + nt * 64, eo.act);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) acc[0][r] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+      acc_to_lds(acc[0], sQ, bias + nt * 64, act);
       __syncthreads();
-      store_tile(eo);
+      store_tile(sQ, eo);
     }
 
     // ---- publish: every wave's stores have completed, then one agent-scope add on the sequence's counter
-    wait_vmcnt<0>();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
       __hip_atomic_fetch_add(ctrl + CTRL_CNT + seq * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -762,16 +764,19 @@ extern "C" int rg_denoiser_forward(rg_handle* h, const rg_fwd_args* args_host, v
   const rg_fwd_args& a = *args_host;
   RG_REQUIRE(h, a.layers && a.sched && a.ctrl && a.x && a.xa && a.head, "null pointer");
   RG_REQUIRE(h, a.L >= 1 && a.B >= 1 && a.T >= 1 && a.T <= TP && a.step >= 0, "unsupported shape (T <= 48)");
-  static bool attr = false;
-  if (!attr) {
+  static int wgs_per_cu = 0;
+  if (wgs_per_cu == 0) {
     if (hipFuncSetAttribute((const void*)rg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
       h->err = "rg_denoiser_forward: cannot reserve LDS";
       return RG_ERR_HIP;
     }
-    attr = true;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)rg_fwd_kernel, NTH, LDS_BYTES) != hipSuccess || n < 1) n = 1;
+    wgs_per_cu = n > 3 ? 3 : n;
   }
-  hipStream_t s = rg_stream(stream);
-  hipLaunchKernelGGL(rg_fwd_kernel, dim3(h->num_cus), dim3(NTH), LDS_BYTES, s, a);
+  // one workgroup per resident slot; correctness does not depend on the grid size (any number of workgroups drains
+  // the queues), only the overlap of one tile's latencies with another tile's work does
+  hipLaunchKernelGGL(rg_fwd_kernel, dim3(h->num_cus * wgs_per_cu), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }
