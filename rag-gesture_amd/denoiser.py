@@ -198,7 +198,9 @@ class DenoiserSession:
 
     def __init__(self, weights, B, persistent=None):
         """persistent: run `forward` as ONE persistent dataflow launch (rg_denoiser_forward) instead of ~90 dependent
-        launches.  None = whenever the shapes allow it (bf16 production path, D = 512, FF = 1024, T <= 48)."""
+        launches (bf16 production path, D = 512, FF = 1024, T <= 48).  Parity-green, but measured SLOWER than the
+        launch chain on MI355X (1244 vs 881 us per forward at M = 1376, 1864 vs 1437 us at M = 4128: every tile pays
+        ~3 memory round trips of ~2 us for its hand-offs), so it is opt-in: None / False = launch chain."""
         w = self.w = weights
         self.h = w.h
         self.B, self.R = B, 2 * B
@@ -255,7 +257,7 @@ class DenoiserSession:
         ok = F.supported(w, T)
         if persistent and not ok:
             raise capi.RgError("persistent forward: unsupported shape / precision")
-        self.pf = F.PersistentForward(self) if (ok and persistent is not False) else None
+        self.pf = F.PersistentForward(self) if (ok and persistent) else None
 
     # ------------------------------------------------------------------ once per clip
     def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None):

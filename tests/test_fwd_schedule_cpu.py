@@ -75,3 +75,17 @@ def test_in_order_workers_never_deadlock(workers):
         idle_rounds = 0 if progressed else idle_rounds + 1
         assert idle_rounds < 2, "deadlock"
     assert all(h == e for h, e in zip(heads, starts[1:]))
+
+
+def test_ctypes_structs_mirror_the_header():
+    """rg_fwd_layer / rg_fwd_args in include/rg_gesture.h and their ctypes mirrors list the same fields in the same
+    order (every field is a pointer or an int: same layout)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = open(os.path.join(root, "include", "rg_gesture.h")).read()
+    for cname, cls in (("rg_fwd_layer", F.FwdLayer), ("rg_fwd_args", F.FwdArgs)):
+        i, j = h.index("typedef struct %s {" % cname), h.index("} %s;" % cname)
+        body = re.sub(r"/\*.*?\*/", "", h[i:j], flags=re.S)
+        names = re.findall(r"[\*\s](\w+)\s*[;,]", body.split("{", 1)[1])
+        assert names == [f[0] for f in cls._fields_], cname
