@@ -173,8 +173,8 @@ int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_le
  * shape), 2 = prefer the LDS-DMA ring kernel, 3 = prefer the depth-4 register-staged kernel, 4 = prefer the
  * 128-row big-tile kernel (bf16 A), 5 = never use it. */
 int rg_set_gemm_path(rg_handle* h, int path);
-/* Tuning knob: waves per workgroup of the LDS-DMA GEMM kernel (0 = auto by shape, 4 or 8; process-wide, default 0). */
-int rg_set_gemm_waves(int waves);
+/* Tuning knob of this handle: waves per workgroup of the LDS-DMA GEMM kernel (0 = auto by shape, 4 or 8; default 0). */
+int rg_set_gemm_waves(rg_handle* h, int waves);
 
 /* Measurement aid (bench.py roofline): between begin and end every rg_gemm launch is bracketed by
  * HIP events on its stream; end synchronises and returns launch count, summed kernel time and summed
@@ -246,6 +246,13 @@ int rg_kv_reduce(rg_handle* h, const float* kv, int ldkv, float* A, int B, int N
 /* Partial LayerNorm statistics of fp32 rows that no GEMM produced (the gathered speaker
  * embeddings): stats[row][dim/64][2] = (sum, sumsq) over each 64-column part. */
 int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows, int dim, void* stream);
+
+/* Guard of the folded LayerNorm (rg_gemm_desc.ln_stats): *max_ratio = max(*max_ratio, max over rows of mean^2 / var)
+ * from the partial (sum, sumsq) statistics [rows][nparts][2] of K-wide rows.  *max_ratio must hold a non-negative
+ * float (zero it first).  The folded form multiplies bf16(x) with x un-normalised: its error grows with |mean| / std
+ * (efficient_attention.py:29,72-74 normalise first); the host reads the figure once per session and uses the
+ * LayerNorm pre-pass instead when it is large. */
+int rg_ln_guard(rg_handle* h, const float* stats, int rows, int nparts, int K, float* max_ratio, void* stream);
 
 /* Exact fp32 linear for load-time tables: out[M,N] = f_out( f_in(a)[M,K] w[N,K]^T + bias ),
  * f = SiLU if the flag is set (time_embed MLP, diffusion_transformer.py:404-408, and the 40

@@ -516,6 +516,32 @@ __global__ void __launch_bounds__(256) row_stats_kernel(const float* __restrict_
   }
 }
 
+// max over rows of mean^2 / var from partial (sum, sumsq) statistics: how far a row's mean sits from zero in units of
+// its spread.  The folded LayerNorm (rg_gemm: ln_stats / ln_c1) multiplies the bf16 copy of the UN-normalised row, whose
+// rounding error scales with |mean|; the host reads this figure once per session and falls back to the LayerNorm
+// pre-pass when rows are far off centre.  Non-negative floats order like their bit patterns: atomicMax on the bits.
+__global__ void __launch_bounds__(256) ln_guard_kernel(const float* __restrict__ stats, int rows, int nparts, int K,
+                                                      unsigned* __restrict__ max_ratio_bits) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  float ratio = 0.f;
+  if (row < rows) {
+    const float* sp = stats + (size_t)row * nparts * 2;
+    float su = 0.f, sq = 0.f;
+    for (int q = 0; q < nparts; ++q) {
+      su += sp[2 * q];
+      sq += sp[2 * q + 1];
+    }
+    const float inv = 1.0f / (float)K;
+    const float mu = su * inv;
+    float var = sq * inv - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    ratio = mu * mu / (var + 1e-5f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, o));
+  if ((threadIdx.x & 63) == 0 && ratio > 0.f) atomicMax(max_ratio_bits, __float_as_uint(ratio));
+}
+
 // out[row, s*seg_len + k] = bf16( f_s(src_s[row, k]) ), f_s = identity / LayerNorm / LN*(1+scale)+shift->SiLU.
 // The same transforms rg_gemm applies in its A prologue, done ONCE per element: used where a GEMM
 // would otherwise redo an expensive prologue in every column tile (the K = 4*512 ca_mix GEMM).
@@ -1156,6 +1182,15 @@ extern "C" int rg_row_stats(rg_handle* h, const float* x, float* stats, int rows
   const int64_t waves = (int64_t)rows * (dim / 64);
   hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, rg_stream(stream), x,
                      stats, rows, dim);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_ln_guard(rg_handle* h, const float* stats, int rows, int nparts, int K, float* max_ratio, void* stream) {
+  RG_REQUIRE(h, stats && max_ratio, "null pointer");
+  RG_REQUIRE(h, rows > 0 && nparts > 0 && K > 0, "bad shape");
+  hipLaunchKernelGGL(ln_guard_kernel, dim3((rows + 255) / 256), dim3(256), 0, rg_stream(stream), stats, rows, nparts, K,
+                     reinterpret_cast<unsigned*>(max_ratio));
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -20,6 +20,7 @@ struct rg_handle {
   int num_cus = 256;
   std::string err;
   int gemm_path = 0;               // rg_set_gemm_path
+  int gemm_waves = 0;              // rg_set_gemm_waves: 0 = auto, or 4 / 8 waves per LDS-DMA GEMM workgroup
   bool profiling = false;          // rg_profile_begin/end: HIP events around every rg_gemm launch
   std::vector<rg_prof_rec> prof;
   std::vector<hipEvent_t> ev_pool;

@@ -402,7 +402,7 @@ bool reg_fast_eligible(const rg_gemm_desc* d) {
 }  // namespace
 
 bool rg_gemm_dma_eligible(const rg_gemm_desc* d);          // rg_gemm_dma.hip
-void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream);
+void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, int waves, void* stream);
 bool rg_gemm_big_eligible(const rg_gemm_desc* d);          // rg_gemm_big.hip
 int rg_gemm_big_width(const rg_gemm_desc* d, int num_cus); // 0 = do not use, else 128 / 256
 void rg_gemm_big_launch(const rg_gemm_desc* d, int bn, void* stream);
@@ -454,14 +454,14 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   if (d->tile_n == 64) {
     RG_REQUIRE(h, d->a_is_bf16 && !d->W_lo && dma_ok && d->N % 64 == 0 && d->split_col == 0,
                "tile_n = 64 needs a bf16 A operand, aligned shapes and N % 64 == 0");
-    rg_gemm_dma_launch(d, h->num_cus, stream);
+    rg_gemm_dma_launch(d, h->num_cus, h->gemm_waves, stream);
   } else if (big_bn) {
     rg_gemm_big_launch(d, big_bn, stream);
   } else if (fast_ok && path == 3) {
     if (d->a_is_bf16) launch<true, false, true>(d, grid, rg_stream(stream));
     else launch<false, false, true>(d, grid, rg_stream(stream));
   } else if (path != 1 && dma_ok) {
-    rg_gemm_dma_launch(d, h->num_cus, stream);
+    rg_gemm_dma_launch(d, h->num_cus, h->gemm_waves, stream);
   } else if (d->W_lo) {
     launch<false, true, false>(d, grid, rg_stream(stream));
   } else if (d->a_is_bf16) {

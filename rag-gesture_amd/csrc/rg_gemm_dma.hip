@@ -426,9 +426,7 @@ bool rg_gemm_dma_eligible(const rg_gemm_desc* d) {
   return true;
 }
 
-int g_dma_waves = 0;   // tuning knob (rg_set_gemm_waves): 0 = auto, or force 4 / 8 waves per workgroup
-
-void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream) {
+void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, int waves, void* stream) {
   if (d->tile_n == 64) {
     dma_launch_narrow(d, rg_stream(stream));
     return;
@@ -443,7 +441,7 @@ void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream) {
   bool plain = true;
   if (!d->a_is_bf16)
     for (int i = 0; i < d->nseg; ++i) plain = plain && d->seg[i].mode == RG_A_IDENT;
-  const bool use8 = g_dma_waves == 8 || (g_dma_waves == 0 && plain && (int)grid.x <= num_cus);
+  const bool use8 = waves == 8 || (waves == 0 && plain && (int)grid.x <= num_cus);
   if (d->W_lo) {
     dma_launch<false, true, 3, 4>(d, grid, s);
   } else if (use8) {
@@ -469,9 +467,10 @@ void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, void* stream) {
   }
 }
 
-extern "C" int rg_set_gemm_waves(int waves) {
-  if (waves != 0 && waves != 4 && waves != 8) return RG_ERR_INVALID;
-  g_dma_waves = waves;
+extern "C" int rg_set_gemm_waves(rg_handle* h, int waves) {
+  RG_REQUIRE(h, h != nullptr, "null handle");
+  RG_REQUIRE(h, waves == 0 || waves == 4 || waves == 8, "waves must be 0, 4 or 8");
+  h->gemm_waves = waves;
   return RG_OK;
 }
 

@@ -15,7 +15,6 @@ buffers.  What is hoisted out of the 50-step loop, all exact alge
     one K=2048 GEMM instead of three 512x512 GEMMs plus the 1536->512 mix.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -196,11 +195,18 @@ class DenoiserSession:
     """Buffers + conditioning state for B clips (R = 2B rows: conditional rows first, then the
     classifier-free rows).  Not re-entrant; one per (model, batch size, stream)."""
 
-    def __init__(self, weights, B, persistent=None):
+    def __init__(self, weights, B, persistent=None, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False,
+                 xcd_affine=True):
         """persistent: run `forward` as ONE persistent dataflow launch (rg_denoiser_forward) instead of ~90 dependent
         launches (bf16 production path, D = 512, FF = 1024, T <= 48).  Parity-green, but measured SLOWER than the
         launch chain on MI355X (1244 vs 881 us per forward at M = 1376, 1864 vs 1437 us at M = 4128: every tile pays
-        ~3 memory round trips of ~2 us for its hand-offs), so it is opt-in: None / False = launch chain."""
+        ~3 memory round trips of ~2 us for its hand-offs), so it is opt-in: None / False = launch chain.
+        ln_mode (bf16 launch chain): "folded" = LayerNorm folded into the consuming GEMM's epilogue (two passes per
+        layer fewer; its bf16 operand is the UN-normalised row, so the error grows with |row mean| / std),
+        "prologue" = LayerNorm in a pre-pass (exact for any offset), "auto" = folded unless the session's first
+        forward finds rows more than LN_GUARD_SIGMAS standard deviations off centre (one read-back, once per session).
+        styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain."""
+        assert ln_mode in ("auto", "folded", "prologue")
         w = self.w = weights
         self.h = w.h
         self.B, self.R = B, 2 * B
@@ -212,6 +218,7 @@ class DenoiserSession:
         # where the producer runs 64x64 tiles, self.tn): allocated for the finer split, viewed per producer
         self._st_a, self._st_b, self.st_c = f(M, D // 64, 2), f(M, D // 64, 2), f(M, D // G.STATS_COLS, 2)
         parts128 = lambda t: t.view(-1)[:M * (D // G.STATS_COLS) * 2].view(M, D // G.STATS_COLS, 2)
+        self._parts128 = parts128
         self.st_a, self.st_b = parts128(self._st_a), parts128(self._st_b)
         self.qkv, self.q3 = f(M, 3 * D), f(M, 3 * D)
         self.y_sa, self.st_sa = f(M, D), f(M, D // 128, 2)
@@ -222,15 +229,17 @@ class DenoiserSession:
         self.head = f(M, D)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
         self.abf = self.xa_bf = self.v_sa = None
-        if w.precision == "bf16" and os.environ.get("RG_STYL_PREPASS", "1") == "1":
+        self.ln_mode = ln_mode if (w.precision == "bf16" and styl_prepass) else "prologue"
+        self.ln_ratio = None     # max mean^2 / var seen by the guard (ln_mode "auto", after the first forward)
+        if w.precision == "bf16" and styl_prepass:
             self.abf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
             self.abf3 = torch.empty(B * T, 3 * D, device=dev, dtype=torch.bfloat16)
-            if os.environ.get("RG_LN_EPILOGUE", "1") == "1":
-                self.xa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+            if self.ln_mode != "prologue":
+                self._xa_bf_buf = self.xa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
                 # experimental: self-attention + stylization in one 16-wave kernel (rg_sa_stylize).  Measured
                 # slower than the two separate kernels at B <= 48 (it concentrates 16 heads on R <= 96 CUs:
                 # sampling 50.4 vs 48.1 ms, inversion equal), so it is off unless asked for
-                if os.environ.get("RG_SA_FUSED", "0") == "1" and D == 512:
+                if sa_fused and D == 512:
                     self.v_sa = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.qmask_c = torch.ones(3, B, T, device=dev)
@@ -240,14 +249,14 @@ class DenoiserSession:
         self.qmask = torch.ones(3, self.R, T, device=dev)
         # optional 64x64 GEMM tiles for the N = D launches while they still fit one round of workgroups (twice the
         # CUs on the same weight bytes).  Measured: no gain (146.1 vs 143.2 ms guided, 71.6 vs 69.6 ms base): the
-        # fixed part of these launches, not the K loop, decides -- off unless RG_TILE64=1
+        # fixed part of these launches, not the K loop, decides -- off unless tile64=True
         self.tn = 0
-        if self.xa_bf is not None and os.environ.get("RG_TILE64", "0") == "1" and D % 64 == 0 and \
+        if self.xa_bf is not None and tile64 and D % 64 == 0 and \
                 ((M + 63) // 64) * (D // 64) <= w.h.lib.rg_num_cus(w.h._h):
             self.tn = 64
             self.st_b, self.st_f = self._st_b, self._st_f
         ng = D // 128
-        order = xcd_affine_order if os.environ.get("RG_XCD_AFFINE", "1") == "1" else \
+        order = xcd_affine_order if xcd_affine else \
             (lambda n, ipg, T_: np.arange(n * ipg, dtype=np.int32))
         dv = lambda a: torch.from_numpy(a).to(dev)
         self.perm_sa = dv(order(self.R, ng, T))
@@ -315,6 +324,37 @@ class DenoiserSession:
         w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
         if self.pf is not None:
             return self.pf.run(x.contiguous(), step)
+        if self.ln_mode == "auto":
+            return self._forward_guarded(x, step)
+        return self._forward_chain(x, step)
+
+    LN_GUARD_SIGMAS = 3.0   # |row mean| beyond this many standard deviations: the folded LayerNorm is not used
+
+    def _forward_guarded(self, x, step):
+        """First forward of an ln_mode="auto" session: run the folded path with rg_ln_guard behind every GEMM that
+        leaves row statistics, read the figure back once, settle the mode (and redo the step in the LayerNorm pre-pass
+        form if the rows are off centre).  Never inside a graph capture: callers warm up before they capture."""
+        if torch.cuda.is_current_stream_capturing():
+            raise capi.RgError("DenoiserSession(ln_mode='auto'): run one forward before capturing a graph")
+        self._guard = torch.zeros(1, device=self.w.dev)
+        self.ln_mode = "folded"
+        out = self._forward_chain(x, step)
+        self.ln_ratio = float(self._guard.item())
+        self._guard = None
+        if self.ln_ratio > self.LN_GUARD_SIGMAS ** 2:
+            self.ln_mode, self.xa_bf, self.v_sa = "prologue", None, None
+            if self.tn:   # 64-wide tiles were tied to the folded path
+                self.tn = 0
+                self.st_b, self.st_f = self._parts128(self._st_b), self._parts128(self._st_f)
+            out = self._forward_chain(x, step)
+        return out
+
+    def _guard_stats(self, stats):
+        if getattr(self, "_guard", None) is not None:
+            self.h.call("ln_guard", stats, self.M, stats.shape[1], self.w.D, self._guard)
+
+    def _forward_chain(self, x, step):
+        w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
         xa, xb, xc = self.xa, self.xb, self.xc
         sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c     # sa_: written by the embed GEMM (128-wide tiles)
         sa_w = self._st_a if self.tn else self.st_a           # ... and by every FFN-out GEMM (self.tn-wide tiles)
@@ -322,6 +362,7 @@ class DenoiserSession:
         # h = joint_embed(x) + positional tables, duplicated for the two CFG branches
         G.gemm(h, M=M, N=D, K=D, W=w.w_embed, out=xa, segs=[G.Seg(x.view(B * T, D))], seg_len=D, a_row_mod=B * T,
                bias=w.b_embed, tbias=w.tbias, tb_period=T, stats_out=sa_, out2=self.xa_bf)
+        self._guard_stats(sa_)
         for l, lw in enumerate(w.layers):
             ss = w.ss[step, l]
             # --- self attention
@@ -366,6 +407,7 @@ class DenoiserSession:
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, segs=[sa_seg], seg_len=D, bias=lw["b_sao"], residual=xa,
                        stats_out=sb_)
+            self._guard_stats(sb_)
             # --- three parallel cross attentions on the same input
             if self.hcat is not None:
                 # production path: query projection + cross attention on the conditional rows only; the
@@ -428,6 +470,7 @@ class DenoiserSession:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_w,
                        out2=self.xa_bf, tile_n=tn)
                 sa_ = sa_w   # the next layer's QKV reads the statistics in this tile split
+                self._guard_stats(sa_)
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, segs=[ff_seg], seg_len=D, bias=lw["b_ffo"], residual=xc,
                        stats_out=sa_)

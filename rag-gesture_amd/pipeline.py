@@ -20,6 +20,7 @@ Differences that are deliberate and documented in DESIGN.md:
     (an object with draw(shape)) replays explicit noise in the reference's consumption order
      for parity tests.
 """
+import collections
 import contextlib
 import copy
 import os
@@ -36,6 +37,43 @@ MODELS = {}
 def register_module(cls):
     MODELS[cls.__name__] = cls
     return cls
+
+
+def register_with_mmcv(force=False):
+    """Put MotionDiffusion / ReGestureTransformer into the registries the reference's tools build from
+    (mogen/models/builder.py:11-26: `MODELS = Registry('models', parent=mmcv.cnn.MODELS)`, ARCHITECTURES = SUBMODULES =
+    MODELS; classes are looked up by `cfg.model.type`).  force=True replaces the reference's own classes of the same
+    names: after that one call `tools/visualize.py:138-147` (build_architecture, load_checkpoint, MMDataParallel,
+    model.eval()) and `:189-200` (model(**data)) run unchanged on this implementation.  Returns the registries touched
+    (empty when mmcv is not installed)."""
+    regs = []
+    try:
+        from mmcv.cnn import MODELS as mmcv_models
+        regs.append(mmcv_models)
+    except ImportError:
+        return regs
+    try:
+        from mogen.models.builder import MODELS as mogen_models
+        regs.append(mogen_models)
+    except ImportError:
+        pass
+    for reg in regs:
+        for cls in (MotionDiffusion, ReGestureTransformer):
+            try:
+                reg.register_module(name=cls.__name__, module=cls, force=force)
+            except (KeyError, TypeError):   # already registered and not forced
+                pass
+    return regs
+
+
+def read_vae_checkpoint(path):
+    """State dict of one body-part VAE as the reference stores it: {"model_state": ...}, keys optionally prefixed
+    `module.` by DataParallel (diffusion_transformer.py:169-188 `load_checkpoints`)."""
+    states = torch.load(path, map_location="cpu")
+    sd = states["model_state"] if "model_state" in states else states
+    if sd and all(k.startswith("module.") for k in sd):
+        sd = collections.OrderedDict((k[7:], v) for k, v in sd.items())
+    return sd
 
 
 def build_architecture(cfg, **kwargs):
@@ -103,7 +141,7 @@ class ReGestureTransformer:
             scale_func_cfg=scale_func_cfg, per_joint_scale=per_joint_scale,
         )
         assert scale_func_cfg is not None, "the shipped config always runs the CFG mix (scale_func_cfg)"
-        self.vae_cfgs = self._read_vae_cfgs(vae_cfg)
+        self.vae_cfgs, self.vae_states = self._read_vae_cfgs(vae_cfg)
         self.retrieval_cfg, self.use_retrieval_for_test = retrieval_cfg, use_retrieval_for_test
         self.database = None
         if retrieval_cfg is not None and use_retrieval_for_test:
@@ -114,27 +152,53 @@ class ReGestureTransformer:
     @staticmethod
     def _read_vae_cfgs(vae_cfg):
         """vae_cfg holds YAML paths (diffusion_transformer.py:151-154) or, for synthetic models,
-        the dicts themselves under the same keys."""
-        out = {}
+        the dicts themselves under the same keys.  Like the reference's `load_vae` (:151-168) the YAML's `test_ckpt`
+        names the VAE checkpoint that sits NEXT TO the YAML; its weights are read here and used for every
+        `gesture_rep_encoder.<part>_vae.*` key the diffusion checkpoint does not carry itself."""
+        out, states = {}, {}
         for part in vae_mod.PARTS:
             v = vae_cfg["%s_cfg" % part]
+            base = None
             if isinstance(v, str):
+                base = os.path.dirname(v)
                 with open(v, "r", encoding="utf-8") as f:
                     v = yaml.safe_load(f)
             out[part] = dict(v)
             out[part].setdefault("frame_chunk_size", vae_cfg.get("frame_chunk_size", 15))
-        return out
+            ck = out[part].get("test_ckpt")
+            path = None
+            if ck:
+                path = os.path.join(base, os.path.basename(ck)) if base is not None else ck
+            states[part] = read_vae_checkpoint(path) if path and os.path.exists(path) else None
+        return out, states
 
     def post_process(self, motion):
         return motion
 
 
+IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
+
+
 @register_module
-class MotionDiffusion:
+class MotionDiffusion(torch.nn.Module):
+    """nn.Module like the reference's class (diffusion_architecture.py:64), so the tools' plumbing works on it as
+    written: `mmcv.runner.load_checkpoint(model, path)` (walks `_load_from_state_dict`), `.cuda()` / `.eval()`,
+    `MMDataParallel(model, device_ids=[0])(**data)`, `model.state_dict()`.  It owns no nn.Parameters: the weights live
+    packed in HBM (DenoiserWeights / GestureRepEncoder) and `state_dict()` hands back the tensors it was loaded from.
+
+    Options beyond the reference's keys (constructor arguments, not environment variables):
+      precision   "bf16" (production) | "fp32" (bf16x3 operands, parity checks)
+      lanes       concurrent clip groups per forward, each on its own hardware queue (measured on MI355X: 2 lanes
+                  149.7 vs 156 ms guided B=16, 71.3 vs 73.0 ms base B=32; 3-4 lanes no better)
+      session_options   keyword arguments of denoiser.DenoiserSession (ln_mode, persistent, ...)
+      vae_options       keyword arguments of vae.GestureRepEncoder (part_streams, chain)"""
+
     def __init__(self, model=None, loss_recon=None, loss_gen=None, loss_contact=None, loss_laplace=None,
                  diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
-                 body_part_lossweights=None, device="cuda", precision="bf16", **kwargs):
+                 body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, session_options=None,
+                 vae_options=None, **kwargs):
+        super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
         dt = dict(diffusion_test)
@@ -145,30 +209,56 @@ class MotionDiffusion:
         assert inference_type == "ddim", "only the DDIM inference path is implemented (config: inference_type='ddim')"
         self.device, self.precision = torch.device(device), precision
         self.training = False
+        self.session_options, self.vae_options = dict(session_options or {}), dict(vae_options or {})
+        self._state = None
         self._sessions = {}
         self._graphs = {}
         self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
         self.profile_phases, self.phase_ms = False, {}
-        # concurrent clip groups per forward, each on its own hardware queue (measured on MI355X: 2 lanes
-        # 149.7 vs 156 ms guided B=16, 71.3 vs 73.0 ms base B=32; 3-4 lanes no better)
-        self.lanes = int(os.environ.get("RG_LANES", "2"))
+        self.lanes = int(lanes)
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
         """Accepts the reference's key names: `model.` prefixed (mmcv checkpoint of MotionDiffusion,
-        tools/visualize.py:141) or un-prefixed ReGestureTransformer keys."""
+        tools/visualize.py:141, bare or wrapped in {"state_dict": ...}) or un-prefixed ReGestureTransformer keys.
+        Body-part VAE weights missing from `state` are taken from the VAE checkpoints named by the YAMLs
+        (diffusion_transformer.py:151-188).  Returns (missing_keys, unexpected_keys) like nn.Module."""
         if "state_dict" in state and not torch.is_tensor(state["state_dict"]):
             state = state["state_dict"]
         if any(k.startswith("model.") for k in state):
             state = {k[len("model."):]: v for k, v in state.items() if k.startswith("model.")}
+        else:
+            state = dict(state)
         m = self.model
+        for part in vae_mod.PARTS:
+            pre = "gesture_rep_encoder.%s_vae." % part
+            sd = (getattr(m, "vae_states", None) or {}).get(part)
+            if sd is not None and not any(k.startswith(pre) for k in state):
+                state.update({pre + k: v for k, v in sd.items()})
         m.weights = denoiser.DenoiserWeights(state, m.cfg, self.schedule, self.device, precision=self.precision)
-        m.gesture_rep_encoder = vae_mod.GestureRepEncoder(state, m.vae_cfgs, self.device, self.precision)
+        m.gesture_rep_encoder = vae_mod.GestureRepEncoder(state, m.vae_cfgs, self.device, self.precision, **self.vae_options)
         m.gesture_rep_encoder.graph_runner = self._graph_run
+        self._state = state
         self._sessions = {}
         self._graphs = {}
-        return self
+        return IncompatibleKeys([], [])
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """The hook `mmcv.runner.load_checkpoint` (mmcv/runner/checkpoint.py `load_state_dict`) and
+        `nn.Module.load_state_dict` walk: called once on this module with the whole checkpoint dict."""
+        sd = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        try:
+            self.load_state_dict(sd, strict=strict)
+        except KeyError as e:
+            missing_keys.append(prefix + str(e).strip("'"))
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        """The reference-format tensors this model was loaded from (`model.`-prefixed like MotionDiffusion's own)."""
+        out = collections.OrderedDict() if destination is None else destination
+        for k, v in (self._state or {}).items():
+            out[prefix + "model." + k] = v
+        return out
 
     def _graph_run(self, key, inputs, fn):
         """Run fn(static_inputs) -> outputs through a cached HIP graph: `inputs` (dict of device
@@ -200,7 +290,9 @@ class MotionDiffusion:
         graph.replay()
         return tuple(o.clone() for o in outs)
 
-    def eval(self):
+    def train(self, mode=True):
+        if mode:
+            raise capi.RgError("this is the inference hot path: training is out of scope")
         self.training = False
         return self
 
@@ -217,13 +309,19 @@ class MotionDiffusion:
         torch.cuda.synchronize()
         self.phase_ms[name] = self.phase_ms.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
-    def cuda(self, *a):
+    def cuda(self, *a, **k):
+        return self
+
+    def cpu(self):
+        return self   # weights stay packed in HBM; forward() raises without a GPU (no CPU fallback)
+
+    def to(self, *a, **k):
         return self
 
     def _session(self, B, role="sample", lane=0):
         key = (B, role, lane)
         if key not in self._sessions:
-            self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B)
+            self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B, **self.session_options)
         return self._sessions[key]
 
     def _set_conditions(self, B, role, lane, word, audio, speaker_ids, motion_mask, query_masks):
@@ -294,9 +392,6 @@ class MotionDiffusion:
         n = max(1, min(want, B, len(self._lane_streams)))
         cuts = [(B * i) // n for i in range(n + 1)]
         return [(i, self._lane_streams[i], cuts[i], cuts[i + 1]) for i in range(n)]
-
-    def __call__(self, **kwargs):
-        return self.forward(**kwargs)
 
     # ------------------------------------------------------------------ forward (eval)
     def forward(self, **kwargs):

@@ -655,6 +655,7 @@ class RetrievalDatabase:
                 for qp, name, placed in plan:
                     ex.append((b, qp, name, placed))
         tick("retrieval.search")
+        self.last_exemplars = [(b, qp, name, placed is not None) for b, qp, name, placed in ex]   # visiting order (tests)
         # ---- fetch + VAE-encode every visited exemplar in one batch (noise in the reference's order)
         recs = [self.dataset[name] for _, _, name, _ in ex]
         lat = None

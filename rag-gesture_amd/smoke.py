@@ -18,7 +18,8 @@ def run():
     for precision, tol in (("fp32", 1e-2), ("bf16", 3e-2)):
         model = pipeline.build_architecture(synth.reference_style_model_cfg(cfg, vae_cfgs), database=None,
                                             device="cuda:0", precision=precision)
-        model.load_state_dict(P).eval()
+        model.load_state_dict(P)
+        model.eval()
         for tag, ikw, need_re in (("base", {}, False),
                                   ("guided", dict(use_inversion=True, insertion_guidance=True, guidance_iters=gi,
                                                   guidance_lr=0.1), True)):

@@ -11,7 +11,6 @@ batch-major [B*S, D] (the reference is sequence-major; attention is per sequence
 The VAE hyper-parameters come from the YAML shipped with each checkpoint, so
 nothing here is specialised to one width/depth/arch.
 """
-import os
 
 import torch
 
@@ -69,7 +68,9 @@ class TransformerVAE:
     decoder_arch, position_embedding, nfeats, num_frames, frame_chunk_size,
     transformer_activation, transformer_normalize_before, vae_dist)."""
 
-    def __init__(self, state, vcfg, device="cuda", precision="bf16"):
+    def __init__(self, state, vcfg, device="cuda", precision="bf16", chain=True):
+        """chain: bf16 path only -- producers hand bf16 copies to the GEMMs that consume them (False: every GEMM converts
+        its fp32 operand tiles itself; a measurement knob)."""
         assert vcfg.get("vae_dist", "normal") == "normal", "only the Normal posterior is supported"
         self.cfg = vcfg
         self.dev = torch.device(device)
@@ -77,7 +78,7 @@ class TransformerVAE:
         self.precision = precision
         # bf16 path: every op that feeds a GEMM hands over a bf16 copy (LayerNorm, attention, FF1) so the GEMMs
         # read bf16 A operands instead of converting fp32 tiles in each of their column tiles
-        self.chain = precision == "bf16" and os.environ.get("RG_VAE_CHAIN", "1") == "1"
+        self.chain = precision == "bf16" and bool(chain)
         self._copies = None
         split = precision == "fp32"
         D = self.D = vcfg["latent_dim"]
@@ -265,21 +266,23 @@ class TransformerVAE:
 class GestureRepEncoder:
     """diffusion_transformer.py:131-330: four VAEs, 6D rotation packing, separator tokens."""
 
-    def __init__(self, state, vae_cfgs, device="cuda", precision="bf16", prefix="gesture_rep_encoder."):
+    def __init__(self, state, vae_cfgs, device="cuda", precision="bf16", prefix="gesture_rep_encoder.", part_streams=True,
+                 chain=True):
+        """part_streams: run the four body-part VAEs as concurrent launch chains (False: one chain); chain: see
+        TransformerVAE."""
         self.dev = torch.device(device)
         self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
         self.vaes = {}
         for part in PARTS:
             p = "%s%s_vae." % (prefix, part)
             sd = {k[len(p):]: v for k, v in state.items() if k.startswith(p)}
-            self.vaes[part] = TransformerVAE(sd, vae_cfgs[part], device, precision)
+            self.vaes[part] = TransformerVAE(sd, vae_cfgs[part], device, precision, chain=chain)
         self.vae_latent_dim = vae_cfgs["upper"]["latent_dim"]
         self.frame_chunk_size = vae_cfgs["upper"]["frame_chunk_size"]
         self.uj = self.lj = self.fj = self.hj = self.tj = None
         # the four body-part VAEs are independent launch chains of small kernels: each runs on a stream of its own
-        # (forked from / joined into the caller's stream, also inside a graph capture) -- RG_VAE_STREAMS=0: one chain
-        self.part_streams = ([torch.cuda.Stream(device=self.dev) for _ in PARTS]
-                             if os.environ.get("RG_VAE_STREAMS", "1") != "0" else None)
+        # (forked from / joined into the caller's stream, also inside a graph capture); part_streams=False: one chain
+        self.part_streams = [torch.cuda.Stream(device=self.dev) for _ in PARTS] if part_streams else None
 
     def _fan_out(self, jobs):
         """Run the per-part jobs (callables) concurrently: job i on part stream i, all ordered after the work already

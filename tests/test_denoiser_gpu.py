@@ -146,8 +146,8 @@ def test_sample_loop_graph_matches_eager_and_oracle(rg, setup):
     assert e <= 2e-2
 
 
-def test_fused_self_attention_stylization_matches_separate_kernels(rg, monkeypatch):
-    """RG_SA_FUSED=1 routes the self-attention block through rg_sa_stylize (16-wave kernel, V as bf16 from the
+def test_fused_self_attention_stylization_matches_separate_kernels(rg):
+    """DenoiserSession(sa_fused=True) routes the self-attention block through rg_sa_stylize (16-wave kernel, V as bf16 from the
     QKV GEMM's split output); it must agree with the default sa_attention + stylize path to bf16 accuracy."""
     cfg = rg.synth.default_model_cfg(num_layers=2)
     sch = rg.schedule.Schedule()
@@ -160,10 +160,9 @@ def test_fused_self_attention_stylization_matches_separate_kernels(rg, monkeypat
     mask[:, [10, 21, 32]] = 0
     mask[1, 7:10] = 0
     outs = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RG_SA_FUSED", flag)
-        sess = rg.denoiser.DenoiserSession(W, B)
-        assert (sess.v_sa is not None) == (flag == "1")
+    for fused in (False, True):
+        sess = rg.denoiser.DenoiserSession(W, B, sa_fused=fused, ln_mode="folded")
+        assert (sess.v_sa is not None) == fused
         sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, None)
         outs.append(sess.forward(x, 17).clone())
     e = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()

@@ -1,0 +1,147 @@
+"""GPU: the two single-GPU BASELINE configurations at FULL size, checked per clip against the CPU oracle.
+
+  config 3: B = 16, use_inversion + insertion_guidance (decreasing_till_25), discourse retrieval over the replicated
+            32768-entry DB, bf16, concurrent lanes, 8 layers  -- clips {0, 7, 15}
+  config 2: B = 32 base diffusion, bf16                          -- clips {0, 31}
+
+Clips are independent, so clip i of the batched HIP run must equal a batch-of-one oracle run that is fed clip i's
+inputs and clip i's share of the noise.  The batched run's explicit noise tape is recorded; ClipTape replays, in the
+oracle's draw order, the rows that belong to one clip (VAE noise rows [10 i, 10 i + 10), the exemplar-encode draws of
+the clip's own exemplars, row i of every [B, 43, 512] draw).
+Bars: retrieved samples, bounds and placement exact; final latent <= 3e-2 relative (bf16 operands vs fp32, rows 10/20/30
+excluded as everywhere); decoded translation <= 5e-2.
+"""
+import pytest
+import torch
+
+from oracle import diffusion as odf, pipeline as opipe, retrieval as oret
+
+pytestmark = pytest.mark.gpu
+KEEP = [r for r in range(43) if r not in (10, 20, 30)]
+GI = [0] * 25 + list(range(25))
+
+
+def relerr(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+class RecordingTape:
+    def __init__(self, tape):
+        self.tape, self.record = tape, []
+
+    def draw(self, shape, device=None):
+        t = self.tape.draw(shape)
+        self.record.append(t)
+        return t.to(device) if device is not None else t
+
+
+class ClipTape:
+    """Clip i's share of a recorded batched tape, in the order a batch-of-one run draws it."""
+
+    def __init__(self, record, i, B, exemplar_clips):
+        E = len(exemplar_clips)
+        seq = [record[k][10 * i:10 * i + 10] for k in range(4)]                      # VAE encode of the clip batch
+        assert all(record[k].shape == (B * 10, 1, 512) for k in range(4))
+        for e, b in enumerate(exemplar_clips):                                        # 4 draws per visited exemplar
+            chunk = record[4 + 4 * e:8 + 4 * e]
+            assert all(c.shape == (10, 1, 512) for c in chunk)
+            if b == i:
+                seq += chunk
+        for t in record[4 + 4 * E:]:
+            assert t.shape == (B, 43, 512), t.shape
+            seq.append(t[i:i + 1])
+        self.seq, self.pos = seq, 0
+
+    def draw(self, shape, device=None):
+        t = self.seq[self.pos]
+        self.pos += 1
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+        return t
+
+
+def _clip(data, i):
+    out = {}
+    for k, v in data.items():
+        if torch.is_tensor(v):
+            out[k] = v[i:i + 1].cpu().clone()
+        elif isinstance(v, (list, tuple)):
+            out[k] = [v[i].cpu() if torch.is_tensor(v[i]) else v[i]]
+    return out
+
+
+def test_config3_guided_b16_full_db_vs_oracle(rg):
+    dev = torch.device("cuda", 0)
+    B, N_DB = 16, 32768
+    cfg = rg.synth.default_model_cfg(num_layers=8)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    database = rg.synth.SyntheticDataset(N_DB, seed=2025, device=dev, feat_device=dev)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=database,
+                                  device=dev)
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    model.load_state_dict(P)
+    model.eval()
+    assert model.precision == "bf16" and model.lanes >= 2
+    data = rg.synth.synth_batch(B, seed=1234, device=dev)
+    qs = [rg.synth.synth_query(i) for i in range(B)]
+    data["discourse"] = [q["discourse"] for q in qs]
+    data["prominence"] = [q["prominence"] for q in qs]
+    data["text_features"] = [q["text_features"].to(dev) for q in qs]
+    data["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
+    ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    tape = RecordingTape(rg.synth.NoiseTape(9))
+    keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}   # forward re-zeroes trans in place
+    out = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=tape)))
+    torch.cuda.synchronize()
+    ex = model.model.database.last_exemplars
+    assert len(ex) >= B, "the synthetic queries should retrieve exemplars"
+    rd = out["retrieval_dict"]
+
+    cpu_db = oret.build_db_dicts([dict(r, text_feature=r["text_feature"].cpu()) for r in database.retrieval_samples])
+    cpu_ds = rg.synth.SyntheticDataset(0)
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    for i in (0, 7, 15):
+        cdata = _clip(keep, i)
+        ccond = dict(text_features=cdata["text_features"], discourse=cdata["discourse"], prominence=cdata["prominence"],
+                     speaker_ids=cdata["speaker_ids"])
+        got = {}
+        ct = ClipTape(tape.record, i, B, [b for b, _, _, _ in ex])
+        with torch.no_grad():
+            ref = opipe.motion_diffusion_forward(
+                P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, ct,
+                re_dict=lambda tp: got.setdefault("re", oret.database_forward(P, vae_cfgs, cpu_db, cpu_ds, ccond,
+                                                                               cdata["sample_name"], tp)), **ikw)
+        assert ct.pos == len(ct.seq), "the oracle consumed exactly the clip's share of the noise"
+        # retrieval: same exemplars, same spans (bit-exact bar)
+        assert rd["retr_startends"][i] == got["re"]["retr_startends"][0]
+        assert rd["query_startends"][i] == got["re"]["query_startends"][0]
+        assert list(rd["retr_uncropped_latents"][i].keys()) == list(got["re"]["retr_uncropped_latents"][0].keys())
+        assert len(rd["retr_startends"][i]) >= 1
+        e = relerr(out["prev_latentout"][i:i + 1].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP])
+        et = relerr(out["pred_transl"][i:i + 1].cpu(), ref["pred_transl"])
+        print("config 3, clip %d: %d exemplars, final latent rel err %.3e, transl %.3e" % (i, len(rd["retr_startends"][i]), e, et))
+        assert e <= 3e-2 and et <= 5e-2
+
+
+def test_config2_base_b32_vs_oracle(rg):
+    dev = torch.device("cuda", 0)
+    B = 32
+    cfg = rg.synth.default_model_cfg(num_layers=8)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=False), database=None,
+                                  device=dev)
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    model.load_state_dict(P)
+    model.eval()
+    data = rg.synth.synth_batch(B, seed=1234, device=dev)
+    keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+    tape = RecordingTape(rg.synth.NoiseTape(10))
+    out = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(noise_tape=tape)))
+    torch.cuda.synchronize()
+    for i in (0, 31):
+        ct = ClipTape(tape.record, i, B, [])
+        with torch.no_grad():
+            ref = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), _clip(keep, i), ct)
+        e = relerr(out["prev_latentout"][i:i + 1].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP])
+        et = relerr(out["pred_transl"][i:i + 1].cpu(), ref["pred_transl"])
+        print("config 2, clip %d: final latent rel err %.3e, transl %.3e" % (i, e, et))
+        assert e <= 3e-2 and et <= 5e-2

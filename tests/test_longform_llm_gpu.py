@@ -25,7 +25,8 @@ def test_longform_llm_guidance_windows(rg, tmp_path):
     ds = rg.synth.SyntheticDataset(300, seed=31)
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds,
                                   precision="bf16")
-    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs)).eval()
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
     rdb = model.model.database
     cache = rg.retrieval.LLMResponseCache(str(tmp_path / "llm_cache.json"), call=_answer(rg))
     rdb.word_similarity, rdb.llm_output = rg.synth.synth_word_similarity, cache.get

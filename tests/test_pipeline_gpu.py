@@ -107,7 +107,8 @@ def test_end_to_end_vs_reference_golden(rg, models, golden_dir, rtag, ikw, need_
     print(rtag, precision, "final latent rel err (rows != 10,20,30) %.3e" % e)
     # fp32 mode: what remains is the reference's platform-dependent LayerNorm rounding on the three
     # -1e6 rows leaking through self-attention; bf16 mode: operand rounding
-    assert e <= (1e-2 if precision == "fp32" else 3e-2)
+    # (measured 9e-4 in fp32 mode)
+    assert e <= (2e-3 if precision == "fp32" else 3e-2)
     for k in ("pred_upper", "pred_lower", "pred_facepose", "pred_hands", "pred_transl", "pred_exps"):
         r = torch.from_numpy(g["%s_%s" % (rtag, k)])
         ek = rot_relerr(out[k].cpu(), r) if k in ROT else relerr(out[k].cpu(), r)
@@ -116,18 +117,21 @@ def test_end_to_end_vs_reference_golden(rg, models, golden_dir, rtag, ikw, need_
         assert ek <= (3e-2 if precision == "fp32" else 8e-2), k
 
 
-def test_end_to_end_with_retrieval_database_vs_oracle(rg):
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_end_to_end_with_retrieval_database_vs_oracle(rg, precision):
     """build_architecture(cfg.model, database=train_dataset) with use_retrieval_for_test: discourse
     retrieval over the replicated DB (HIP sweep), exemplar encode, batched inversion, guided sampling --
-    against the oracle run of the same chain (retrieval indices/placement exact, latents close)."""
+    against the oracle run of the same chain (retrieval indices/placement exact, latents close), in the
+    fp32-equivalent mode and on the bf16 production path."""
     from oracle import retrieval as oret, diffusion as odf
     cfg = rg.synth.default_model_cfg(num_layers=2)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder", num_layers=2)
     ds = rg.synth.SyntheticDataset(300, seed=31)
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds,
-                                  precision="fp32")
+                                  precision=precision)
     P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
-    model.load_state_dict(P).eval()
+    model.load_state_dict(P)
+    model.eval()
     B = 2
     qs = [rg.synth.synth_query(41), rg.synth.synth_query(42)]
 
@@ -154,8 +158,42 @@ def test_end_to_end_with_retrieval_database_vs_oracle(rg):
     assert sum(len(x) for x in rd["retr_startends"]) >= 2, "the synthetic queries should retrieve exemplars"
     lat, r = out["prev_latentout"].cpu(), ref["prev_latentout"]
     e = relerr(lat[:, KEEP], r[:, KEEP])
-    print("e2e with retrieval DB (fp32 mode): final latent rel err %.3e" % e)
-    assert e <= 1e-2
+    print("e2e with retrieval DB (%s): final latent rel err %.3e" % (precision, e))
+    assert e <= (2e-3 if precision == "fp32" else 3e-2)
+
+
+@pytest.mark.parametrize("rtag,ikw,need_re", RUNS[:2])
+def test_end_to_end_all_token_rows_vs_exact_ln_oracle(rg, models, rtag, ikw, need_re):
+    """Rows 20 and 30 are real hands / face tokens whose cross-attention queries the reference masks
+    (diffusion_architecture.py:155); the goldens of the real reference cannot pin them tightly because torch's
+    LayerNorm of (y - 1e6) rounds platform-dependently.  Against the oracle in masked_ln="exact"
+    mode -- the same arithmetic with that LayerNorm evaluated exactly, which is what the kernels do -- EVERY token row
+    (all but the three zero separators 10 / 21 / 32) must agree in the fp32-equivalent mode."""
+    from oracle import denoiser as od, diffusion as odf
+    model = models[("L2", "fp32")]
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    B = 2
+    data = rg.synth.synth_batch(B, seed=4321)
+    re = opipe.synthetic_re_dict(B, seed=77) if need_re else None
+    if need_re:
+        data["re_dict"] = opipe.synthetic_re_dict(B, seed=77)
+    out = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=rg.synth.NoiseTape(2024))))
+    torch.cuda.synchronize()
+    od.OPTS.update(masked_ln="exact")
+    try:
+        with torch.no_grad():
+            ref = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), rg.synth.synth_batch(B, seed=4321),
+                                                 rg.synth.NoiseTape(2024), re_dict=re, **ikw)
+    finally:
+        od.OPTS.update(masked_ln="torch")
+    tokens = [r for r in range(43) if r not in (10, 21, 32)]
+    lat, r = out["prev_latentout"].cpu(), ref["prev_latentout"]
+    e_all = relerr(lat[:, tokens], r[:, tokens])
+    e_2030 = relerr(lat[:, [20, 30]], r[:, [20, 30]])
+    print(rtag, "fp32 mode vs exact-LN oracle: all token rows %.3e, rows 20/30 %.3e" % (e_all, e_2030))
+    assert e_all <= 2e-3 and e_2030 <= 2e-3
 
 
 def test_concurrent_lanes_equal_single_lane(rg, models):
