@@ -157,7 +157,6 @@ def main():
         d["trans"] = trans0.clone()  # forward re-zeroes trans in place like the reference
         ikw = {}
         if guided:
-            model.model.database.test_indexes.clear()  # no cross-step caching of retrieval results
             ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
         out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
         packed = torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],

@@ -426,6 +426,16 @@ int rg_gesture_scores(rg_handle* h, const int* spk, const int* lab_off, const in
                       const double* lab_prom, const double* word_sim, int n_entries, int q_type, int q_word, int q_spk,
                       double spk_bonus, double q_prom, int sim_f32, double* score_out, int* top_out, void* stream);
 
+/* Word similarity of the gesture_type / llm methods as the reference effectively computes it (rag/utils.py:239-272:
+ * the word2vec / fasttext models are undefined, so every call returns `fuzz.partial_ratio(db_word, query_word) / 100`,
+ * fuzzywuzzy 0.18, pure-python SequenceMatcher flavour): out[v] = partial_ratio(vocab word v, query) / 100 for the
+ * n_words strings vocab[v][0 .. vocab_len[v]) (int32 code points, row stride `stride`) -- the word_sim vector
+ * rg_gesture_scores takes.  query_host: HOST int32 code points.  Strings longer than rg_partial_ratio_max_len() code
+ * points give NaN (the host computes those with the standard library's difflib). */
+int rg_partial_ratio(rg_handle* h, const int* vocab, const int* vocab_len, int n_words, int stride,
+                     const int* query_host, int query_len, double* out, void* stream);
+int rg_partial_ratio_max_len(void);
+
 /* Candidate selection for the ranking walk of rag/discourse_retrieval.py:224-300: the reference sorts
  * all scores and visits entries until it holds 10, so only entries with score >= the 10th largest
  * score (with multiplicity; all ties included) and score > 0 can be visited.  Appends those

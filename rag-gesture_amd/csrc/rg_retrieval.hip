@@ -326,6 +326,110 @@ __global__ void __launch_bounds__(256) compact_kernel(const double* __restrict__
   }
 }
 
+
+// ------------------------------------------------------------------------------ fuzzy word similarity
+// fuzzywuzzy 0.18 `fuzz.partial_ratio` (pure-python flavour: difflib.SequenceMatcher) of one query string against every
+// word of the DB vocabulary, one thread per word -- the similarity `get_word_similarity_score` effectively returns
+// (rag/utils.py:239-272: the embedding models are undefined, every call ends in `fuzz.partial_ratio(w1, w2) / 100`).
+// Strings are code-point arrays.  difflib's matcher for sequences below its autojunk length, written out:
+//   find_longest_match: longest common substring of a[alo:ahi], b[blo:bhi]; among equals the earliest in a, then in b
+//   get_matching_blocks: LIFO queue of the pieces left and right of each match
+//   ratio = 2 * matched / (len a + len b)
+// partial_ratio: for every diagonal d = max(j - i, 0) of the outer blocks (the (la, lb, 0) sentinel included) the ratio
+// of `shorter` against longer[d : d + la]; > .995 -> 100; else int(round(100 * max)) (round half to even, like Python).
+constexpr int PR_MAX = 48;   // longest string handled on the device (longer: out = NaN, the host computes it)
+
+struct PrQuery {
+  int len;
+  int c[PR_MAX];
+};
+
+__device__ int pr_longest(const int* a, const int* b, int alo, int ahi, int blo, int bhi, int& bi, int& bj) {
+  unsigned char prev[PR_MAX], cur[PR_MAX];
+  for (int j = blo; j < bhi; ++j) prev[j] = 0;
+  int best = 0;
+  bi = alo;
+  bj = blo;
+  for (int i = alo; i < ahi; ++i) {
+    const int ai = a[i];
+    for (int j = blo; j < bhi; ++j) {
+      int k = 0;
+      if (b[j] == ai) {
+        k = (j > blo ? prev[j - 1] : 0) + 1;
+        if (k > best) {
+          best = k;
+          bi = i - k + 1;
+          bj = j - k + 1;
+        }
+      }
+      cur[j] = (unsigned char)k;
+    }
+    for (int j = blo; j < bhi; ++j) prev[j] = cur[j];
+  }
+  return best;
+}
+
+// matched characters of SequenceMatcher(None, a, b); diag (optional): bit d set for every block diagonal max(j - i, 0)
+__device__ int pr_matches(const int* a, int la, const int* b, int lb, unsigned long long* diag) {
+  short st[PR_MAX + 2][4];
+  int sp = 0, total = 0;
+  st[0][0] = 0; st[0][1] = (short)la; st[0][2] = 0; st[0][3] = (short)lb;
+  sp = 1;
+  while (sp > 0) {
+    --sp;
+    const int alo = st[sp][0], ahi = st[sp][1], blo = st[sp][2], bhi = st[sp][3];
+    int i, j;
+    const int k = pr_longest(a, b, alo, ahi, blo, bhi, i, j);
+    if (k) {
+      total += k;
+      if (diag) *diag |= 1ull << (j - i > 0 ? j - i : 0);
+      if (alo < i && blo < j) {
+        st[sp][0] = (short)alo; st[sp][1] = (short)i; st[sp][2] = (short)blo; st[sp][3] = (short)j;
+        ++sp;
+      }
+      if (i + k < ahi && j + k < bhi) {
+        st[sp][0] = (short)(i + k); st[sp][1] = (short)ahi; st[sp][2] = (short)(j + k); st[sp][3] = (short)bhi;
+        ++sp;
+      }
+    }
+  }
+  return total;
+}
+
+__global__ void __launch_bounds__(64) partial_ratio_kernel(const int* __restrict__ vocab, const int* __restrict__ vlen,
+                                                           int n_words, int stride, const PrQuery q,
+                                                           double* __restrict__ out) {
+  const int v = blockIdx.x * 64 + threadIdx.x;
+  if (v >= n_words) return;
+  const int l1 = vlen[v], l2 = q.len;
+  if (l1 > PR_MAX || l2 > PR_MAX) {
+    out[v] = __longlong_as_double(0x7ff8000000000000ll);   // NaN: too long for the device form
+    return;
+  }
+  int s1[PR_MAX], s2[PR_MAX];
+  for (int i = 0; i < l1; ++i) s1[i] = vocab[(size_t)v * stride + i];
+  for (int i = 0; i < l2; ++i) s2[i] = q.c[i];
+  bool same = l1 == l2;
+  for (int i = 0; same && i < l1; ++i) same = s1[i] == s2[i];
+  if (same) { out[v] = 1.0; return; }             // check_for_equivalence (also two empty strings)
+  if (l1 == 0 || l2 == 0) { out[v] = 0.0; return; }
+  const int* a = l1 <= l2 ? s1 : s2;               // shorter (ties: the first argument = the DB word)
+  const int* b = l1 <= l2 ? s2 : s1;
+  const int la = l1 <= l2 ? l1 : l2, lb = l1 <= l2 ? l2 : l1;
+  unsigned long long diag = 1ull << (lb - la);     // the (la, lb, 0) sentinel block
+  pr_matches(a, la, b, lb, &diag);
+  double best = 0.0;
+  bool hit = false;
+  for (int d = 0; d <= lb && !hit; ++d) {
+    if (!((diag >> d) & 1ull)) continue;
+    const int ls = (d + la <= lb) ? la : lb - d;   // longer[d : d + la] is cut at the end of the string
+    const int m = pr_matches(a, la, b + d, ls, nullptr);
+    const double r = (la + ls) ? 2.0 * (double)m / (double)(la + ls) : 1.0;
+    if (r > .995) hit = true;
+    best = r > best ? r : best;
+  }
+  out[v] = hit ? 1.0 : rint(100.0 * best) / 100.0;
+}
 }  // namespace
 
 static int select_launch(rg_handle* h, const double* score, const int* top, int n_entries, int n_queries,
@@ -412,3 +516,18 @@ extern "C" int rg_gesture_scores(rg_handle* h, const int* spk, const int* lab_of
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }
+
+extern "C" int rg_partial_ratio(rg_handle* h, const int* vocab, const int* vocab_len, int n_words, int stride,
+                                const int* query_host, int query_len, double* out, void* stream) {
+  RG_REQUIRE(h, vocab && vocab_len && out && (query_host || query_len == 0), "null pointer");
+  RG_REQUIRE(h, n_words > 0 && stride >= 1 && query_len >= 0, "bad shape");
+  PrQuery q;
+  q.len = query_len;
+  for (int i = 0; i < PR_MAX; ++i) q.c[i] = (i < query_len && query_len <= PR_MAX) ? query_host[i] : 0;
+  hipLaunchKernelGGL(partial_ratio_kernel, dim3((n_words + 63) / 64), dim3(64), 0, rg_stream(stream), vocab, vocab_len,
+                     n_words, stride, q, out);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_partial_ratio_max_len(void) { return PR_MAX; }

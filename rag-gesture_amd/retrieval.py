@@ -301,6 +301,36 @@ def discourse_retrieval(index, discourse, prominence, speaker_id, encoded_text, 
 _NEP50 = int(np.__version__.split(".")[0]) >= 2
 
 
+def partial_ratio_host(s1, s2):
+    """fuzzywuzzy 0.18 `fuzz.partial_ratio`, pure-python flavour (the package calls difflib.SequenceMatcher when
+    python-Levenshtein is absent, as in the reference's requirements.txt).  Host form of rg_partial_ratio: used for
+    single pairs and for strings longer than the kernel handles."""
+    from difflib import SequenceMatcher
+    if s1 is None or s2 is None:
+        return 0
+    if s1 == s2:
+        return 100
+    if len(s1) == 0 or len(s2) == 0:
+        return 0
+    shorter, longer = (s1, s2) if len(s1) <= len(s2) else (s2, s1)
+    scores = []
+    for i, j, _ in SequenceMatcher(None, shorter, longer).get_matching_blocks():
+        start = j - i if j - i > 0 else 0
+        r = SequenceMatcher(None, shorter, longer[start:start + len(shorter)]).ratio()
+        if r > .995:
+            return 100
+        scores.append(r)
+    return int(round(100 * max(scores)))
+
+
+def fuzzy_word_similarity(db_word, query_word):
+    """The reference's get_word_similarity_score as it effectively behaves (rag/utils.py:239-272): its word2vec /
+    fasttext models are never defined, every call raises inside the `try` and returns
+    `fuzz.partial_ratio(word1, word2) / 100`.  This is the DEFAULT `word_similarity` of RetrievalDatabase; whole
+    vocabularies go through the device form (rg_partial_ratio) in GestureTypeIndex.sweep."""
+    return partial_ratio_host(db_word, query_word) / 100
+
+
 class GestureTypeIndex:
     """Device copy of the DB's semantic gesture labels (raggesture.py:262 idx_2_gesture_labels, beat labels dropped
     like gesture_type_retrieval.py:57-59 does): CSR over entries with integer-coded types and words.  Shares the
@@ -329,6 +359,36 @@ class GestureTypeIndex:
         self.spk, self.lab_off, self.lab_type, self.lab_word = i32(spk), i32(off), i32(lt or [0]), i32(lw or [0])
         self.lab_prom = None if gestprom is None else torch.tensor(lp or [0.0], dtype=torch.float64, device=self.dev)
         self.vocab = list(self.word_code.keys())
+        # the vocabulary as code-point rows for rg_partial_ratio (the default word similarity)
+        self.pr_max = int(self.h.lib.rg_partial_ratio_max_len())
+        codes = np.zeros((max(1, len(self.vocab)), self.pr_max), dtype=np.int32)
+        lens = np.zeros(max(1, len(self.vocab)), dtype=np.int32)
+        for v, w in enumerate(self.vocab):
+            lens[v] = len(w)
+            cp = [ord(ch) for ch in w[:self.pr_max]]
+            codes[v, :len(cp)] = cp
+        self.vocab_codes, self.vocab_len = torch.from_numpy(codes).to(self.dev), torch.from_numpy(lens).to(self.dev)
+
+    def fuzzy_similarities(self, words):
+        """[len(words), len(vocab)] float64 on the device: partial_ratio(vocab word, query word) / 100 for every query
+        word, one rg_partial_ratio launch each; pairs with a string beyond the kernel's length are patched from the host."""
+        V = max(1, len(self.vocab))
+        out = torch.empty(len(words), V, dtype=torch.float64, device=self.dev)
+        vp, s = ctypes.c_void_p, torch.cuda.current_stream().cuda_stream
+        for q, word in enumerate(words):
+            cp = (ctypes.c_int * max(1, len(word)))(*[ord(ch) for ch in word])
+            rc = self.h.lib.rg_partial_ratio(self.h._h, vp(self.vocab_codes.data_ptr()), vp(self.vocab_len.data_ptr()),
+                                             len(self.vocab) or 1, self.pr_max, cp, len(word), vp(out[q].data_ptr()), vp(s))
+            if rc != 0:
+                raise capi.RgError("rg_partial_ratio failed: %s" % self.h.lib.rg_last_error(self.h._h).decode())
+        long_rows = [v for v, w in enumerate(self.vocab) if len(w) > self.pr_max]
+        for q, word in enumerate(words):
+            rows = range(len(self.vocab)) if len(word) > self.pr_max else long_rows
+            for v in rows:
+                out[q, v] = fuzzy_word_similarity(self.vocab[v], word)
+        if not self.vocab:
+            out.zero_()
+        return out
 
     def sweep(self, queries, word_similarity, spk_bonus=2.0, proms=None):
         """[(type, word, speaker_id)] (+ per-query prominence, None = unknown: the llm method) -> per query (entry idx ascending, score, top label index) of the entries that
@@ -344,14 +404,19 @@ class GestureTypeIndex:
         o_idx = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
         o_top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
         o_score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
-        raw = [[word_similarity(w, q[1]) for w in self.vocab] or [0.0] for q in queries]
-        # float32 similarities make the reference's score float32 only under NumPy >= 2 promotion rules (NEP 50); the
-        # reference pins numpy < 1.24, where scalar-scalar arithmetic promotes to float64: follow the installed numpy
-        f32 = [int(_NEP50 and any(isinstance(v, np.float32) for v in row)) for row in raw]
+        if word_similarity is fuzzy_word_similarity:
+            # the reference's effective similarity (python floats -> float64 scores): whole vocabulary on the device
+            sims = self.fuzzy_similarities([q[1] for q in queries])
+            f32 = [0] * Q
+        else:
+            raw = [[word_similarity(w, q[1]) for w in self.vocab] or [0.0] for q in queries]
+            # float32 similarities make the reference's score float32 only under NumPy >= 2 promotion rules (NEP 50); the
+            # reference pins numpy < 1.24, where scalar-scalar arithmetic promotes to float64: follow the installed numpy
+            f32 = [int(_NEP50 and any(isinstance(v, np.float32) for v in row)) for row in raw]
+            sims = torch.tensor([[float(v) for v in row] for row in raw], dtype=torch.float64, device=self.dev)
         if proms is not None and self.lab_prom is None:
             raise capi.RgError("llm retrieval needs idx_2_gestprom in the DB metadata (raggesture.py:270-272)")
         nan = float("nan")
-        sims = torch.tensor([[float(v) for v in row] for row in raw], dtype=torch.float64, device=self.dev)
         s = torch.cuda.current_stream().cuda_stream
         for q, (q_type, q_word, speaker_id) in enumerate(queries):
             rc = lib.rg_gesture_scores(self.h._h, vp(self.spk.data_ptr()), vp(self.lab_off.data_ptr()),
@@ -522,6 +587,7 @@ class RetrievalDatabase:
     face/hands, facial, trans, contact, motion_mask, word, audio, speaker_id).  DB metadata comes
     from `metadata` (dict of idx_2_text / idx_2_sense / idx_2_discbounds / idx_2_prominence) or from
     `dataset.retrieval_samples` (raw records, see build_db_dicts)."""
+    CACHE_CAP = 4096   # clips kept in the write-only test_indexes / test_dbounds / test_qbounds dicts
 
     def __init__(self, num_retrieval=None, topk=None, latent_dim=512, text_latent_dim=768, max_seq_len=150,
                  motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", word_similarity=None,
@@ -537,10 +603,11 @@ class RetrievalDatabase:
         self.max_seq_len, self.motion_fps, self.motion_framechunksize = max_seq_len, motion_fps, motion_framechunksize
         self.latent_dim, self.text_latent_dim = latent_dim, text_latent_dim
         self.index = DiscourseIndex(metadata, device)
-        # gesture_type method: needs idx_2_gesture_labels in the metadata and the word-similarity model of
-        # rag/utils.py:239-272 (external: `word_similarity(db_word, query_word) -> float`)
+        # gesture_type / llm methods: need idx_2_gesture_labels in the metadata.  word_similarity(db_word, query_word):
+        # None = the reference's effective behaviour, fuzz.partial_ratio / 100 (rag/utils.py:239-272; device form
+        # rg_partial_ratio); a callable = the embedding-model similarity the reference's comments intend
         self.gesture_index = GestureTypeIndex(metadata, self.index) if "idx_2_gesture_labels" in metadata else None
-        self.word_similarity = word_similarity
+        self.word_similarity = fuzzy_word_similarity if word_similarity is None else word_similarity
         # llm method: `llm_output(text) -> str` stands for get_llm_output (rag/llm_retrieval.py:69-96, the GPT call);
         # an LLMResponseCache (cached answers, BASELINE config 5) or any callable
         self.llm_output = llm_output.get if isinstance(llm_output, LLMResponseCache) else llm_output
@@ -549,19 +616,17 @@ class RetrievalDatabase:
 
     def retrieve(self, retr_method, text_features, discourse, prominence, speaker_id, idx=None, ready=None,
                  gesture_labels=None, text=None, text_times=None):
-        """raggesture.py:313-477 (eval branch, first-call behaviour; results cached per idx)."""
+        """raggesture.py:313-477, eval branch: the reference reads its per-idx cache only under `self.training` (:335);
+        in eval every call recomputes and overwrites test_indexes[idx] -- so do we (the dicts are written for parity
+        of that side effect only, bounded to the last CACHE_CAP clips)."""
         if retr_method not in ("discourse", "gesture_type", "llm"):
             raise NotImplementedError("retrieval method %r (the reference's `prosody` raises too, raggesture.py:431)" % retr_method)
-        if idx is not None and idx in self.test_indexes and retr_method in self.test_indexes[idx]:
-            si, db_b, qb = (self.test_indexes[idx][retr_method], self.test_dbounds[idx][retr_method],
-                            self.test_qbounds[idx][retr_method])
-        else:
+        if True:
             if ready is not None:
                 si, db_b, qb = ready
             elif retr_method in ("gesture_type", "llm"):
-                if self.gesture_index is None or self.word_similarity is None:
-                    raise capi.RgError("%s retrieval needs idx_2_gesture_labels in the DB metadata and a "
-                                       "word_similarity callable (rag/utils.py:239 get_word_similarity_score)" % retr_method)
+                if self.gesture_index is None:
+                    raise capi.RgError("%s retrieval needs idx_2_gesture_labels in the DB metadata (raggesture.py:262)" % retr_method)
                 if retr_method == "gesture_type":
                     si, db_b, qb = gesture_type_retrieval(self.gesture_index, gesture_labels, speaker_id, text_features,
                                                           self.word_similarity)
@@ -575,6 +640,10 @@ class RetrievalDatabase:
             self.test_indexes.setdefault(idx, {})[retr_method] = si
             self.test_dbounds.setdefault(idx, {})[retr_method] = db_b
             self.test_qbounds.setdefault(idx, {})[retr_method] = qb
+            while len(self.test_indexes) > self.CACHE_CAP:
+                old = next(iter(self.test_indexes))
+                for d in (self.test_indexes, self.test_dbounds, self.test_qbounds):
+                    d.pop(old, None)
         data = {q: [s for s in idxs if s != idx][:self.num_retrieval] for q, idxs in si.items()}
         return data, db_b, qb
 
@@ -628,9 +697,6 @@ class RetrievalDatabase:
             pending, queries = {}, []
             if retrieval_method == "discourse":
                 for b in range(B):
-                    key = idx[b] if idx is not None else None
-                    if key is not None and key in self.test_indexes and retrieval_method in self.test_indexes[key]:
-                        continue
                     qs = discourse_queries(conditions["discourse"][b], conditions["prominence"][b], spks[b])
                     pending[b] = (len(queries), len(qs))
                     queries += qs
@@ -680,7 +746,10 @@ class RetrievalDatabase:
         tick("retrieval.exemplar_encode")
         retr_se, query_se, retr_lats, names_out, type2words = ([{} for _ in range(B)] for _ in range(5))
         zero_motion = torch.zeros(B, T, D, device=dev)
-        tmpl = self.dataset[0] if self.dataset is not None else None
+        if self.dataset is None:
+            raise capi.RgError("RetrievalDatabase.forward needs `dataset=` (the exemplars' motion / audio / text records); "
+                               "metadata alone only supports retrieve()")
+        tmpl = self.dataset[0]
         raw_motion = torch.zeros(B, self.max_seq_len, tmpl["motion"].shape[-1], device=dev)
         raw_trans = torch.zeros(B, self.max_seq_len, tmpl["trans"].shape[-1], device=dev)
         raw_facial = torch.zeros(B, self.max_seq_len, tmpl["facial"].shape[-1], device=dev)
