@@ -105,6 +105,19 @@ def guidance_iters_preset(name, steps=50):
     return table[name]
 
 
+E_BUCKET = 4   # exemplar counts are padded to a multiple of this: bounded graph / session caches under real retrieval
+
+
+def bucket(n, m=E_BUCKET):
+    return -(-n // m) * m
+
+
+def pad_rows(t, n):
+    """t [E, ...] -> [n, ...]: padding rows repeat row 0 (valid data: the padded exemplars are inverted like the real
+    ones and never spliced anywhere)."""
+    return t if t.shape[0] == n else torch.cat([t, t[:1].expand(n - t.shape[0], *t.shape[1:])], dim=0)
+
+
 class _TorchNoise:
     order_free = True  # draws come from torch's generator: consumers may batch / reorder them
 
@@ -266,8 +279,12 @@ class MotionDiffusion(torch.nn.Module):
         and clones of the outputs are returned.  Falls back to eager launches if use_graphs is off."""
         if not self.use_graphs:
             return fn(inputs)
-        ent = self._graphs.get(key)
+        ent = self._graphs.pop(key, None)
+        if ent is not None:
+            self._graphs[key] = ent                               # most recently used goes last
         if ent is None:
+            while len(self._graphs) >= self.MAX_GRAPHS:
+                del self._graphs[next(iter(self._graphs))]
             torch.cuda.synchronize()  # other lanes may have work in flight: capture from a quiet device
             static = {k: (None if v is None else torch.empty(v.shape, dtype=v.dtype, device=v.device).copy_(v))
                       for k, v in inputs.items()}
@@ -318,10 +335,20 @@ class MotionDiffusion(torch.nn.Module):
     def to(self, *a, **k):
         return self
 
+    MAX_SESSIONS, MAX_GRAPHS = 24, 96   # LRU caps (a session holds ~45 MB of activations per 16 clips, a graph its statics)
+
     def _session(self, B, role="sample", lane=0):
         key = (B, role, lane)
         if key not in self._sessions:
+            while len(self._sessions) >= self.MAX_SESSIONS:      # evict the least recently used session and its graphs
+                old = next(iter(self._sessions))
+                del self._sessions[old]
+                for gk in [g for g in self._graphs if g[0] in ("cond", "invert", "sample", "guided") and g[1] == old[0]
+                           and old[2] in g[2:4]]:
+                    del self._graphs[gk]
             self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B, **self.session_options)
+        else:
+            self._sessions[key] = self._sessions.pop(key)        # most recently used goes last
         return self._sessions[key]
 
     def _set_conditions(self, B, role, lane, word, audio, speaker_ids, motion_mask, query_masks):
@@ -473,9 +500,10 @@ class MotionDiffusion(torch.nn.Module):
                     continue
                 stream.wait_event(fork)   # main's state before the exemplar VAE encode was queued
                 with torch.cuda.stream(stream):
-                    st = lambda k: torch.stack([recs[e][k] for e in sel]).to(dev)
-                    eqm = {c: torch.stack([qmask[ex[e][0]] for e in sel]) for c in denoiser.CONDS}
-                    self._set_conditions(len(sel), "invert", lane, st("word"), st("audio"), st("speaker_id"),
+                    Ep = bucket(len(sel))
+                    st = lambda k: pad_rows(torch.stack([recs[e][k] for e in sel]).to(dev), Ep)
+                    eqm = {c: pad_rows(torch.stack([qmask[ex[e][0]] for e in sel]), Ep) for c in denoiser.CONDS}
+                    self._set_conditions(Ep, "invert", lane, st("word"), st("audio"), st("speaker_id"),
                                          gre.latent_mask(st("motion_mask").float()), eqm)
                 early_cond[lane] = len(sel)
 
@@ -546,19 +574,22 @@ class MotionDiffusion(torch.nn.Module):
                 if use_inversion:
                     ex = [(b, q_idx) for b in range(b0, b1) for q_idx in retrieval_dict["retr_uncropped_latents"][b].keys()]
                     if ex:
+                        # the lane's E exemplars run as a batch of Ep = E rounded up (padding = copies of exemplar 0,
+                        # inverted and dropped): sessions, condition graphs and inversion graphs exist per Ep only
                         E = len(ex)
+                        Ep = bucket(E)
                         lat = lambda b, q: retrieval_dict["retr_uncropped_latents"][b][q]
-                        cat = lambda key: torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0)
-                        esess = self._session(E, "invert", lane)
+                        cat = lambda key: pad_rows(torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0), Ep)
+                        esess = self._session(Ep, "invert", lane)
                         with self._phase("exemplar_conditions"):
                             if early_cond.get(lane) != E:   # not already projected while the exemplars were encoded
-                                eqm = {c: torch.stack([qmask[b] for b, _ in ex]) for c in denoiser.CONDS}
-                                self._set_conditions(E, "invert", lane, cat("retr_text"), cat("retr_audio"), cat("retr_spkid"),
+                                eqm = {c: pad_rows(torch.stack([qmask[b] for b, _ in ex]), Ep) for c in denoiser.CONDS}
+                                self._set_conditions(Ep, "invert", lane, cat("retr_text"), cat("retr_audio"), cat("retr_spkid"),
                                                      cat("retr_motion_mask"), eqm)
                             x_e = cat("retr_motion_latent").float().contiguous()
                         with self._phase("inversion"):
-                            (inv,) = self._graph_run(("invert", E, lane), dict(x=x_e), lambda s, esess=esess, E=E: (
-                                sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, E, T, D, device=dev)),))
+                            (inv,) = self._graph_run(("invert", Ep, lane, T), dict(x=x_e), lambda s, esess=esess, Ep=Ep: (
+                                sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, Ep, T, D, device=dev)),))
                         for e, (b, q_idx) in enumerate(ex):
                             r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
                             q0, q1 = retrieval_dict["query_startends"][b][q_idx]
@@ -566,7 +597,7 @@ class MotionDiffusion(torch.nn.Module):
                             lvl = inversion_start_time % S
                             h.call("splice_rows", inv[lvl], start_noise, T, D, n_lat, e, b, r0, r1, q0, q1)
                             if use_insertion_guidance:
-                                h.call("splice_rows_rep", inv, invl, T, D, n_lat, e, b, r0, r1, q0, q1, S, E, B)
+                                h.call("splice_rows_rep", inv, invl, T, D, n_lat, e, b, r0, r1, q0, q1, S, Ep, B)
                     if use_insertion_guidance and use_prev_latent and prev_latent is not None:
                         for idx in (up_i, ha_i, fa_i, lt_i):
                             invl[:, b0:b1, idx[0], :] = 0
@@ -581,11 +612,11 @@ class MotionDiffusion(torch.nn.Module):
                 with self._phase("sampling"):
                     if use_insertion_guidance:
                         gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
-                        key = ("guided", Bl, lane, in_seq is not None, gi, lr)
+                        key = ("guided", Bl, lane, T, in_seq is not None, gi, lr)
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess, gi=gi, lr=lr: (
                             sampler.ddim_guided_sample_loop(sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),))
                     else:
-                        key = ("sample", Bl, lane, in_seq is not None)
+                        key = ("sample", Bl, lane, T, in_seq is not None)
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess: (sampler.ddim_sample_loop(
                             sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
                     x_out[b0:b1].copy_(xl)

@@ -736,8 +736,15 @@ class RetrievalDatabase:
                 eps_list = [torch.randn(E * L, 1, D, device=dev) for _ in range(4)]  # generator noise: order is immaterial
             fork = torch.cuda.Event()     # work started by on_exemplars orders itself after this point, not after the encode
             fork.record()
-            lat, _ = gre.encode(stack("motion_upper"), stack("motion_lower"), stack("motion_face"), stack("motion_hands"),
-                                stack("trans"), stack("facial"), stack("contact"), stack("motion_mask"), eps_list)
+            # batch of Ep = E rounded up to a multiple of 4 (padding = copies of exemplar 0 with zero noise, dropped below):
+            # the captured encode graphs exist per Ep, not per exemplar count
+            Ep = -(-E // 4) * 4
+            padr = lambda t: t if t.shape[0] == Ep else torch.cat([t, t[:1].expand(Ep - E, *t.shape[1:])], dim=0).contiguous()
+            eps_list = [torch.cat([e, e.new_zeros((Ep - E) * L, 1, D)], dim=0) if Ep != E else e for e in eps_list]
+            lat, _ = gre.encode(padr(stack("motion_upper")), padr(stack("motion_lower")), padr(stack("motion_face")),
+                                padr(stack("motion_hands")), padr(stack("trans")), padr(stack("facial")), padr(stack("contact")),
+                                padr(stack("motion_mask")), eps_list)
+            lat = lat[:E]
         if on_exemplars is not None and ex:
             # the caller may start work that needs the exemplars' conditioning only (their K/V projections) on other
             # streams while this stream VAE-encodes their motion; the encode (one graph launch) is queued first so
