@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the RAG-Gesture inference hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload guided|base] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload guided|base|longform] [--batch B]
 
 One "step" = one pass of the hot path over one batch of synthetic clips through the drop-in
 `model(**data)`: 4x VAE encode -> conditioning precompute -> [batched DDIM inversion of the
@@ -10,9 +10,14 @@ retrieved exemplars] -> 50-step DDIM with CFG [+ insertion guidance] -> 4x VAE d
 the timed region.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), clips
 sharded across ranks (weak scaling, B clips per rank), results all-gathered once per step.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, HIP-event
-timed in a separate instrumented step of the same workload) and `cpu_baseline` (the CPU oracle
-= a faithful port of the reference, timed on a bounded sample, rank 0 at N = 1 only).
+Prints ONE JSON line (rank 0) with the contract fields plus
+  `roofline`            dominant kernel of the headline workload, HIP-event timed in an instrumented step,
+  `roofline_retrieval`  the DB sweep against the HBM roofline,
+  `also`                the other single-GPU figures in the same run: base B=32 (BASELINE config 2), the headline
+                        workload in the fp32-equivalent mode (bf16x3 operands: same precision class as the reference),
+                        long-form synthesis (config 5: 10 clips x 3 windows, window k of all clips in one forward),
+  `cpu_baseline`        the CPU oracle (= a faithful port of the reference) on a bounded sample, rank 0 at N = 1 only:
+                        one warm-up, median of 3, in the reference-faithful and the loop-invariant-hoisted form.
 """
 import argparse
 import ctypes
@@ -30,6 +35,7 @@ if ROOT not in sys.path:
 
 GI = [0] * 25 + list(range(25))  # tools/visualize.py:74-95 "decreasing_till_25"
 MFMA_BF16_PEAK = 2.5e15          # dense bf16 FLOP/s, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12                # B/s (spec), MI355X_MICROARCH.md
 
 
 def make_re_dict(B, seed, device):
@@ -89,6 +95,189 @@ def launch_ranks(n, argv, dry=False):
     return rc
 
 
+class Workload:
+    """One benchmark configuration: model + resident synthetic inputs + step()."""
+
+    def __init__(self, rg, kind, B, dev, rank, db_size, precision="bf16", database=None, clips=10, windows=3):
+        self.rg, self.kind, self.B, self.dev, self.precision = rg, kind, B, dev, precision
+        self.cfg = rg.synth.default_model_cfg(num_layers=8)
+        self.vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+        self.guided = kind == "guided"
+        # guided: the retrieval DB (discourse metadata + token features) is replicated on every GPU
+        self.database = database
+        if self.guided and database is None:
+            self.database = rg.synth.SyntheticDataset(db_size, seed=2025, device=dev, feat_device=dev)
+        self.model = rg.build_architecture(rg.synth.reference_style_model_cfg(self.cfg, self.vae_cfgs, with_retrieval=self.guided),
+                                           database=self.database if self.guided else None, device=dev, precision=precision)
+        self.model.load_state_dict(rg.synth.synth_full_state(0, self.cfg, self.vae_cfgs))
+        self.model.eval()
+        if kind == "longform":
+            self.n_clips, self.windows = clips, windows
+            n = 135 * windows   # hop 135: sample lengths in (135 (w - 1), 135 w] give w windows (longform_synthesis.py:262-265)
+            self.clips = []
+            for c in range(clips):
+                parts = [rg.synth.synth_batch(1, seed=5000 + 100 * rank + 10 * c + w, device=dev) for w in range(windows)]
+                self.clips.append({k: torch.cat([p[k] for p in parts], dim=1)[:, :n] for k in rg.longform.MOTION_KEYS + rg.longform.REPEAT_KEYS
+                                   if k in parts[0] and torch.is_tensor(parts[0][k]) and parts[0][k].dim() >= 2 and parts[0][k].shape[1] == 150})
+            self.audio = [rg.synth.synth_batch(1, seed=7000 + w, device=dev)["audio"] for w in range(windows)]
+            self.synth = rg.longform.LongformSynthesizer(self.model, overlap=15)
+            self.frames_per_step = clips * n
+            return
+        self.data = rg.synth.synth_batch(B, seed=1234 + rank, device=dev)
+        if self.guided:  # per-clip discourse relations / prominence / BERT token features (3 relations per query)
+            qs = [rg.synth.synth_query(1000 * rank + i) for i in range(B)]
+            self.data["discourse"] = [q["discourse"] for q in qs]
+            self.data["prominence"] = [q["prominence"] for q in qs]
+            self.data["text_features"] = [q["text_features"].to(dev) for q in qs]
+            self.data["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
+        self.trans0 = self.data["trans"].clone()
+        self.frames_per_step = B * 150
+
+    def step(self):
+        """One pass of the hot path; returns the packed [B,150,268] result (None for longform)."""
+        if self.kind == "longform":
+            self.synth.run_many([dict(c, trans=c["trans"].clone()) for c in self.clips],
+                                lambda ci, cidx, t0, t1, ann: dict(audio=self.audio[cidx], text_features=None), shard=False)
+            return None
+        d = dict(self.data)
+        d["trans"] = self.trans0.clone()  # forward re-zeroes trans in place like the reference
+        ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1) if self.guided else {}
+        out = self.model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
+        return torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
+                          out["pred_transl"], out["pred_exps"]], dim=-1)
+
+    def timed(self, steps, warmup, fence):
+        for _ in range(warmup):
+            self.step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        fence()
+        return time.perf_counter() - t0
+
+    def gemm_roofline(self, local_rank):
+        """HIP events around every rg_gemm launch of one eager step (graph replays cannot hold events; the launches are
+        the same).  bf16 mode: the bf16-A GEMMs (variant 1); fp32 mode: the bf16x3 GEMMs (variant 2, 3 MFMAs per
+        product: priced at a third of the bf16 peak)."""
+        rg, model = self.rg, self.model
+        h = rg.capi.get_handle(local_rank)
+        variant = 1 if self.precision == "bf16" else 2
+        peak = MFMA_BF16_PEAK if variant == 1 else MFMA_BF16_PEAK / 3
+
+        def events():
+            model.use_graphs = False
+            self.step()
+            torch.cuda.synchronize()
+            h.lib.rg_profile_begin(h._h)
+            self.step()
+            model.use_graphs = True
+            n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            h.lib.rg_profile_end(h._h, variant, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+            return n.value, ms.value, fl.value
+
+        n, ms, fl = events()
+        ach = fl / (ms * 1e-3) if ms > 0 else 0.0
+        r = {"bound": "mfma", "kernel": ("rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)"
+                                          if variant == 1 else "rg_gemm bf16x3 kernels (fp32-equivalent products: hi*hi + hi*lo + lo*hi)"),
+             "achieved": round(ach / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 5),
+             "launches": n, "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "flops_per_launch_avg": round(fl / max(1, n)),
+             "lanes": model.lanes}
+        if model.lanes > 1:
+            # The timed run cuts the batch into concurrent lanes: its launches are 1/lanes of the batch each and overlap
+            # in time, so the per-launch figure above understates what the chip does.  The same kernels on one lane:
+            lanes_prod, model.lanes = model.lanes, 1
+            n1, ms1, fl1 = events()
+            model.lanes = lanes_prod
+            a1 = fl1 / (ms1 * 1e-3) if ms1 > 0 else 0.0
+            r["single_lane"] = {"achieved": round(a1 / 1e12, 3), "frac": round(a1 / peak, 5), "launches": n1,
+                                "avg_launch_us": round(ms1 * 1e3 / max(1, n1), 2), "flops_per_launch_avg": round(fl1 / max(1, n1))}
+        return r
+
+
+def retrieval_roofline(rg, wl):
+    """The DB sweep (rg_discourse_scores_batched: every query relation of the batch against every DB entry) against the
+    HBM roofline: algorithmic bytes = what one pass must read (the integer-coded CSR, once per query relation) and
+    write (a float64 score and an int32 relation index per entry and query), over its HIP-event time."""
+    idx = wl.database_index()
+    queries = []
+    spks = [int(v) for v in wl.data["speaker_ids"][:, 0].tolist()]
+    for b in range(wl.B):
+        queries += rg.retrieval.discourse_queries(wl.data["discourse"][b], wl.data["prominence"][b], spks[b])
+    for _ in range(2):
+        idx.collect(idx.sweep_async(queries))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        pend = idx.sweep_async(queries)
+    e1.record()
+    torch.cuda.synchronize()
+    idx.collect(pend)
+    ms = e0.elapsed_time(e1) / reps
+    db_bytes = sum(t.numel() * t.element_size() for t in (idx.spk, idx.rel_off, idx.rel_sense, idx.rel_conn, idx.rel_prom))
+    Q, n = len(queries), idx.n
+    alg = Q * (db_bytes + n * 12)
+    ach = alg / (ms * 1e-3)
+    return {"bound": "hbm", "kernel": "discourse_scores_batched + top-score selection (one batch of query relations)",
+            "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(ach / HBM_PEAK, 5),
+            "bytes_per_sweep": alg, "queries": Q, "db_entries": n, "sweep_ms": round(ms, 4),
+            "note": "includes the selection launches; the CSR (%.1f MB) is re-read per query relation from L2 / Infinity Cache"
+                    % (db_bytes / 1e6)}
+
+
+def cpu_baseline(rg, wl, guided):
+    """the fp32 CPU port on the host cores, one warm-up, median of 3, in the reference-faithful
+    form (K/V projections recomputed on every denoiser call, as the reference does) and with that loop-invariant part
+    hoisted.  Sample: ONE clip of the headline workload (150 frames)."""
+    from oracle import pipeline as opipe, diffusion as odf, retrieval as oret, denoiser as od
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))  # the port is bandwidth/latency bound well below that
+    torch.set_num_threads(cores)
+    cfg, vae_cfgs = wl.cfg, wl.vae_cfgs
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    cdata0 = rg.synth.synth_batch(1, seed=1234)
+    ckw = {}
+    if guided:
+        cpu_db = oret.build_db_dicts([dict(r, text_feature=r["text_feature"].cpu()) for r in wl.database.retrieval_samples])
+        cpu_ds = rg.synth.SyntheticDataset(0)
+        q0 = rg.synth.synth_query(0)
+        ccond = dict(text_features=[q0["text_features"]], discourse=[q0["discourse"]], prominence=[q0["prominence"]],
+                     speaker_ids=torch.tensor([[q0["speaker_id"]] * 150]))
+        ckw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+
+    def one(full=True):
+        cdata = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in cdata0.items()}
+        tape = rg.synth.NoiseTape(1)
+        od.hoist_clear()
+        t = time.perf_counter()
+        with torch.no_grad():
+            if guided and full:  # sweep over the same DB + exemplar encode + placement, as the reference does per clip
+                cre = lambda tp: oret.database_forward(P, vae_cfgs, cpu_db, cpu_ds, ccond, ["bench_query"], tp)
+                opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, tape, re_dict=cre, **ckw)
+            else:
+                opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, tape, re_dict=None)
+        return time.perf_counter() - t
+
+    out = {}
+    one(full=False)   # warm-up: one base clip (thread pool, allocator, first-touch of the weights)
+    for mode in ("faithful", "hoisted"):
+        od.OPTS["hoist"] = mode == "hoisted"
+        ts = sorted(one() for _ in range(3))
+        out[mode] = ts[1]
+    od.OPTS["hoist"] = False
+    od.hoist_clear()
+    return {"value": round(150.0 / out["faithful"], 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "hoisted": {"value": round(150.0 / out["hoisted"], 2), "seconds_per_clip": round(out["hoisted"], 2)},
+            "seconds_per_clip": round(out["faithful"], 2),
+            "sample": "1 clip (150 frames) of the headline workload (%s), torch fp32 on %d host threads; 1 warm-up, median of 3 "
+                      "per mode; value = reference-faithful (recomputes the cross-attention K/V side every denoiser call), "
+                      "hoisted = that loop-invariant part computed once" % ("guided" if guided else "base", cores)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,9 +285,10 @@ def main():
                     help="launcher check (no GPU): every rank prints the environment it was started with and exits")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["guided", "base"], default="guided")
-    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 16 guided, 32 base)")
+    ap.add_argument("--workload", choices=["guided", "base", "longform"], default="guided")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 16 guided, 32 base, 10 longform)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the additional single-GPU records (base, fp32 mode, longform)")
     ap.add_argument("--db-size", type=int, default=32768, help="retrieval DB entries (guided workload)")
     ap.add_argument("--phases", action="store_true",
                     help="after the timed run, one extra step with device syncs at phase boundaries; prints the breakdown to stderr")
@@ -130,47 +320,24 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     rg = importlib.import_module("rag-gesture_amd")
-    B = args.batch or (16 if args.workload == "guided" else 32)
-    cfg = rg.synth.default_model_cfg(num_layers=8)
-    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
-    guided = args.workload == "guided"
-    # guided: the retrieval DB (discourse metadata + token features) is replicated on every GPU
-    database = rg.synth.SyntheticDataset(args.db_size, seed=2025, device=dev, feat_device=dev) if guided else None
-    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=guided),
-                                  database=database, device=dev)
-    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
-    model.eval()
-
-    data = rg.synth.synth_batch(B, seed=1234 + rank, device=dev)
-    if guided:  # per-clip discourse relations / prominence / BERT token features (3 relations per query)
-        qs = [rg.synth.synth_query(1000 * rank + i) for i in range(B)]
-        data["discourse"] = [q["discourse"] for q in qs]
-        data["prominence"] = [q["prominence"] for q in qs]
-        data["text_features"] = [q["text_features"].to(dev) for q in qs]
-        data["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
-    trans0 = data["trans"].clone()
-
-    def one_step(gather=True):
-        """gather=False: the rank-local part only (the instrumented extra steps below run on rank 0 alone and must
-        not enter a collective the other ranks are not in)."""
-        d = dict(data)
-        d["trans"] = trans0.clone()  # forward re-zeroes trans in place like the reference
-        ikw = {}
-        if guided:
-            ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
-        out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
-        packed = torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
-                            out["pred_transl"], out["pred_exps"]], dim=-1)
-        if dist is not None and gather:  # the only collective on the path: final result gather (RCCL over xGMI)
-            gathered = torch.empty(world * B, packed.shape[1], packed.shape[2], device=dev)
-            dist.all_gather_into_tensor(gathered, packed.contiguous())
-            return gathered
-        return packed
+    Workload.database_index = lambda self: self.model.model.database.index
+    kind = args.workload
+    B = args.batch or {"guided": 16, "base": 32, "longform": 10}[kind]
+    wl = Workload(rg, kind, B, dev, rank, args.db_size, clips=B)
+    guided = kind == "guided"
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def one_step():
+        packed = wl.step()
+        if dist is not None and packed is not None:  # the only collective on the path: final result gather (RCCL over xGMI)
+            gathered = torch.empty(world * packed.shape[0], packed.shape[1], packed.shape[2], device=dev)
+            dist.all_gather_into_tensor(gathered, packed.contiguous())
+            return gathered
+        return packed
 
     for _ in range(args.warmup):
         one_step()
@@ -185,17 +352,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * B * 150 * args.steps / dt
+    value = world * wl.frames_per_step * args.steps / dt
 
-    if args.phases and rank == 0:
+    if args.phases and rank == 0 and kind != "longform":
         # phase walls need device syncs at phase boundaries, which serialise concurrent lanes: the breakdown is taken
         # on a single lane (one warm-up step captures its graphs), the timed run above used model.lanes lanes
+        model = wl.model
         lanes_prod, model.lanes = model.lanes, 1
-        one_step(gather=False)
+        wl.step()
         model.profile_phases, model.phase_ms = True, {}
         if guided:
             model.model.database.phase_ms = model.phase_ms
-        one_step(gather=False)
+        wl.step()
         torch.cuda.synchronize()
         model.profile_phases = False
         if guided:
@@ -204,103 +372,65 @@ def main():
         print("phase breakdown (ms, one synchronised single-lane step; the timed run used %d lanes): " % lanes_prod +
               ", ".join("%s %.1f" % kv for kv in model.phase_ms.items()), file=sys.stderr)
 
-    # ---- roofline of the dominant kernel (HIP events around every rg_gemm launch, one extra step)
-    roofline = None
+    # ---- rank-0-only records (instrumented / additional steps never enter a collective)
+    roofline = roof_retr = None
+    also = {}
     if rank == 0:
-        h = rg.capi.get_handle(local_rank)
-
-        def gemm_events():
-            """HIP events around every rg_gemm launch of one eager step (graph replays cannot hold events; the
-            launches are the same).  Returns (launches, total ms, total flops) of the bf16-A GEMMs = variant 1
-            (gemm_dma_kernel<true,...> / gemm_bf16_big_kernel: every per-step denoiser GEMM, ~2/3 of the GPU time)."""
-            model.use_graphs = False
-            one_step(gather=False)
-            torch.cuda.synchronize()
-            h.lib.rg_profile_begin(h._h)
-            one_step(gather=False)
-            model.use_graphs = True
-            n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-            h.lib.rg_profile_end(h._h, 1, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
-            return n.value, ms.value, fl.value
-
-        n, ms, fl = gemm_events()
-        ach = fl / (ms * 1e-3) if ms > 0 else 0.0
-        # HBM-side bytes per launch from the committed PMC passes over the same kernels
-        # (profiles/r01e_pmc_gemm_traffic.txt explains how they were collected and corrected); null if absent
-        traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_gemm_traffic.json")) as f:
-                rows = json.load(f)
-            traffic = round(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows))
-        except (OSError, ValueError, KeyError, ZeroDivisionError):
-            pass
-        roofline = {"bound": "mfma", "kernel": "rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)",
-                    "achieved": round(ach / 1e12, 3), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK, 5), "traffic": traffic, "launches": n,
-                    "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "flops_per_launch_avg": round(fl / max(1, n)),
-                    "lanes": model.lanes}
-        if model.lanes > 1:
-            # The timed run cuts the batch into concurrent lanes: its launches are 1/lanes of the batch each and
-            # overlap in time, so the per-launch figure above understates what the chip does.  The same kernels on
-            # one lane (whole batch per launch; the shapes of the PMC passes and of profiles/r01f_*):
-            lanes_prod, model.lanes = model.lanes, 1
-            n1, ms1, fl1 = gemm_events()
-            model.lanes = lanes_prod
-            a1 = fl1 / (ms1 * 1e-3) if ms1 > 0 else 0.0
-            roofline["single_lane"] = {"achieved": round(a1 / 1e12, 3), "frac": round(a1 / MFMA_BF16_PEAK, 5), "launches": n1,
-                                       "avg_launch_us": round(ms1 * 1e3 / max(1, n1), 2),
-                                       "flops_per_launch_avg": round(fl1 / max(1, n1))}
+        if kind != "longform":
+            roofline = wl.gemm_roofline(local_rank)
+            # HBM-side bytes per launch from the committed PMC passes over the same kernels
+            # (profiles/r01e_pmc_gemm_traffic.txt explains how they were collected and corrected); null if absent
+            roofline["traffic"] = None
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01e_pmc_gemm_traffic.json")) as f:
+                    rows = json.load(f)
+                roofline["traffic"] = round(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows))
+            except (OSError, ValueError, KeyError, ZeroDivisionError):
+                pass
+        if guided:
+            roof_retr = retrieval_roofline(rg, wl)
+        if world == 1 and not args.no_also and guided:
+            def record(w, steps=3, warmup=1):
+                d = w.timed(steps, warmup, torch.cuda.synchronize)
+                r = {"value": round(w.frames_per_step * steps / d, 1), "unit": "frames/s", "ms_per_step": round(d / steps * 1e3, 2),
+                     "steps": steps, "warmup": warmup, "dtype": "bf16" if w.precision == "bf16" else "bf16x3 (fp32-equivalent)"}
+                if w.kind != "longform":
+                    r["roofline"] = w.gemm_roofline(local_rank)
+                return r
+            also["base_B32"] = dict(record(Workload(rg, "base", 32, dev, rank, args.db_size)),
+                                    workload="base diffusion len150 DDIM-50 (no guidance), 32 clips (BASELINE config 2)")
+            also["guided_B16_fp32mode"] = dict(
+                record(Workload(rg, "guided", B, dev, rank, args.db_size, precision="fp32", database=wl.database)),
+                workload="the headline workload with bf16x3 split operands (~fp32 products): same-precision figure")
+            lw = Workload(rg, "longform", 10, dev, rank, args.db_size)
+            also["longform_10clips"] = dict(
+                record(lw), workload="long-form synthesis (BASELINE config 5 on one GPU): 10 clips x %d overlapping 150-frame "
+                                     "windows, window k of all clips in one forward, prev-latent chaining, 6D blend, 30 fps; "
+                                     "frames = model frames at 15 fps" % lw.windows)
     if dist is not None:
         dist.barrier()
 
     # ---- CPU baseline: the oracle (faithful port of the reference) on a bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pipeline as opipe, diffusion as odf, retrieval as oret
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cores = os.cpu_count() or 1
-        cores = max(1, min(cores, 32))  # the port is bandwidth/latency bound well below that
-        torch.set_num_threads(cores)
-        P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
-        cdata = rg.synth.synth_batch(1, seed=1234)
-        ckw, cre = {}, None
-        tape = rg.synth.NoiseTape(1)
-        if guided:
-            cpu_db = oret.build_db_dicts([dict(r, text_feature=r["text_feature"].cpu()) for r in database.retrieval_samples])
-            cpu_ds = rg.synth.SyntheticDataset(0)
-            q0 = rg.synth.synth_query(0)
-            ccond = dict(text_features=[q0["text_features"]], discourse=[q0["discourse"]], prominence=[q0["prominence"]],
-                         speaker_ids=torch.tensor([[q0["speaker_id"]] * 150]))
-            ckw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
-        tc = time.perf_counter()
-        with torch.no_grad():
-            if guided:  # sweep over the same DB + exemplar encode + placement, as the reference does per clip
-                cre = lambda tp: oret.database_forward(P, vae_cfgs, cpu_db, cpu_ds, ccond, ["bench_query"], tp)
-                opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, tape, re_dict=cre, **ckw)
-            else:
-                opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), cdata, tape, re_dict=None)
-        tc = time.perf_counter() - tc
-        cpu = {"value": round(150.0 / tc, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-               "sample": "1 clip (150 frames), same workload (%s), torch fp32 on %d host threads, %.1f s"
-                         % (args.workload, cores, tc)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and kind != "longform":
+        cpu = cpu_baseline(rg, wl, guided)
 
     if rank == 0:
+        names = {"guided": ("guided discourse config: discourse retrieval over a replicated %d-entry DB, use_inversion + "
+                            "insertion_guidance decreasing_till_25, <=3 exemplars/clip, len150 DDIM-50" % args.db_size),
+                 "base": "base diffusion len150 DDIM-50 (no guidance)",
+                 "longform": "long-form synthesis: %d clips x 3 overlapping 150-frame windows per GPU" % B}
         line = {
             "metric": "SMPL-X frames/sec, len150 DDIM-50 + insertion guidance; 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if dist is not None else None, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("guided discourse config: discourse retrieval over a replicated %d-entry DB, "
-                                    "use_inversion + insertion_guidance decreasing_till_25, <=3 exemplars/clip, "
-                                    "len150 DDIM-50" % args.db_size
-                                    if args.workload == "guided" else "base diffusion len150 DDIM-50 (no guidance)"),
+            "config": {"workload": names[kind],
                        "clips_per_gpu": B, "global_batch": world * B, "frames_per_clip": 150, "ddim_steps": 50,
                        "denoiser": "8 layers x 512, CFG x2 rows", "vae": "all_encoder, 8 layers, synthetic hparams",
                        "weights": "random-init at config shapes", "parallelism": "clip-sharded x%d" % world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_retrieval": roof_retr, "also": also or None, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if dist is not None:

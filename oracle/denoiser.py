@@ -19,7 +19,16 @@ T_TOKENS = 43
 #   masked_ln : "torch" = F.layer_norm in fp32 on the -1e6-offset rows (implementation-defined
 #               rounding of a mean near -1e6, see DESIGN.md "masked query rows");
 #               "exact" = the same LayerNorm evaluated in fp64 on the fp32-quantised row.
-OPTS = {"bf16": False, "masked_ln": "torch"}
+# "hoist":      False = reference-faithful (the cross-attention K/V side is recomputed on every denoiser call, as the
+#               reference does: SURVEY F7); True = it is computed once per conditioning tensor and reused (the
+#               loop-invariant part hoisted) -- only bench.py's cpu_baseline "hoisted" mode sets it; hoist_clear()
+#               drops the memo between clips.
+OPTS = {"bf16": False, "masked_ln": "torch", "hoist": False}
+_HOIST = {}
+
+
+def hoist_clear():
+    _HOIST.clear()
 
 
 def linear(P, name, x):
@@ -80,18 +89,30 @@ def efficient_cross_attention(P, name, x, xf, emb, query_mask, cond_type, num_he
     N = xf.shape[1]
     H = num_heads
     query = linear(P, name + ".query", layer_norm(P, name + ".norm", x))
-    xfn = layer_norm(P, name + ".text_norm", xf)
-    key = linear(P, name + ".key", xfn)
+    ck = None
+    if OPTS.get("hoist"):   # cpu_baseline "hoisted" mode only: the K/V side of the block depends on the conditioning alone
+        # (keyed on the tensor's content, not its address: exemplar conditionings are freed and reallocated)
+        ck = (name, tuple(xf.shape), float(xf.sum()), float(xf.view(-1)[::997].abs().sum()),
+              None if cond_type is None else tuple(cond_type.view(-1).tolist()))
+    hit = ck is not None and ck in _HOIST
+    if not hit:
+        xfn = layer_norm(P, name + ".text_norm", xf)
+        key = linear(P, name + ".key", xfn)
     query = F.softmax(query.view(B, T, H, -1), dim=-1)
-    if cond_type is None:
-        key = F.softmax(key.view(B, N, H, -1), dim=1)
-        value = linear(P, name + ".value", xfn).view(B, N, H, -1)
+    if hit:
+        attention = _HOIST[ck]
     else:
-        tct = ((cond_type % 10) > 0).float().view(B, 1, 1).repeat(1, N, 1)
-        key = key + (1 - tct) * -1000000
-        key = F.softmax(key.view(B, N, H, -1), dim=1)
-        value = linear(P, name + ".value", xfn * tct).view(B, N, H, -1)
-    attention = torch.einsum("bnhd,bnhl->bhdl", key, value)
+        if cond_type is None:
+            key = F.softmax(key.view(B, N, H, -1), dim=1)
+            value = linear(P, name + ".value", xfn).view(B, N, H, -1)
+        else:
+            tct = ((cond_type % 10) > 0).float().view(B, 1, 1).repeat(1, N, 1)
+            key = key + (1 - tct) * -1000000
+            key = F.softmax(key.view(B, N, H, -1), dim=1)
+            value = linear(P, name + ".value", xfn * tct).view(B, N, H, -1)
+        attention = torch.einsum("bnhd,bnhl->bhdl", key, value)
+        if ck is not None:
+            _HOIST[ck] = attention
     y = torch.einsum("bnhd,bhdl->bnhl", query, attention)
     if query_mask is not None:
         y = y + (1 - query_mask).view(B, T, 1, 1) * -1000000

@@ -11,12 +11,18 @@
 Per-window conditioning features (wav2vec2 on the window's audio, BERT on its words: :320-343) are not part
 of this path: the caller supplies `features(cidx, t0, t1, annotations) -> dict` with at
 least `audio` [B,499,768] and `text_features`.
+
+Throughput (BASELINE config 5: 10 clips x N windows on 8 GPUs): the windows of ONE clip are sequential (prev-latent
+chain), the clips are independent.  `run_many` therefore (a) shards the clips over the ranks of the process group
+(`dist.shard_range`, as the tool's DistributedSampler does, :211, 256) and (b) runs window k of all clips of a rank as
+ONE forward of batch = clips still running, each clip keeping its own prev-latent chain and blend state.  The reference
+runs batch 1 per clip; per clip the results are the same (clips never interact inside the model).
 """
 import os
 
 import torch
 
-from . import capi, packing
+from . import capi, dist as rg_dist, packing
 
 MOTION_KEYS = ("motion", "motion_upper", "motion_lower", "motion_face", "motion_hands", "contact", "trans", "facial", "beta",
                "word")
@@ -134,6 +140,96 @@ class LongformSynthesizer:
             if scale != 1:
                 gm, gf, gt_ = packing.upsample_motion(gm, scale), packing.upsample_features(gf, scale), \
                     packing.upsample_features(gt_, scale)
+            result.update(gt_poses=cut(gm), gt_expressions=cut(gf), gt_trans=cut(gt_))
+        return result
+
+    def run_many(self, clips, features, use_inversion=False, insertion_guidance=False, guidance_iters=None, guidance_lr=0.1,
+                 outpaint=False, inversion_start_time=-1, retrieval_method="discourse", noise_tape=None, with_gt=False,
+                 shard=True, gather=False):
+        """clips: list of batch-of-one sample dicts (any lengths); features(clip_index, cidx, t0, t1, annotations) -> dict.
+        shard: with torch.distributed initialised, this rank takes clips[shard_range(len(clips), rank, world)].
+        Returns {clip_index: result dict as `run`} for this rank's clips (gather=True: for all clips on every rank,
+        exchanged with all_gather_object -- the final result gather of mogen/apis/test.py:129-160)."""
+        import torch.distributed as td
+        mine = list(range(len(clips)))
+        if shard and td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+            lo, hi = rg_dist.shard_range(len(clips), td.get_rank(), td.get_world_size())
+            mine = mine[lo:hi]
+        state = {}
+        for ci in mine:
+            sample_len = clips[ci]["motion"].shape[1]
+            starts, ends, remainder = window_bounds(sample_len, self.seqlen, self.overlap)
+            state[ci] = dict(data=pad_tail(clips[ci], remainder), starts=starts, ends=ends, sample_len=sample_len,
+                             prev=None, so_far=None, gt_so_far=None, latents=[])
+        n_win = max((len(st["starts"]) for st in state.values()), default=0)
+        for cidx in range(n_win):
+            act = [ci for ci in mine if cidx < len(state[ci]["starts"])]     # clips that still have a window cidx
+            chunks = []
+            for ci in act:
+                st = state[ci]
+                c0, c1 = st["starts"][cidx], st["ends"][cidx]
+                t0, t1 = c0 / self.fps, c1 / self.fps
+                data = st["data"]
+                chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
+                assert chunk["motion"].shape[0] == 1 and chunk["motion"].shape[1] == self.seqlen
+                ann = window_annotations(data, t0, t1)
+                chunk.update(ann)
+                chunk.update(features(ci, cidx, t0, t1, ann))
+                chunk["sample_name"] = [data["sample_name"][0].replace("/0", "/%d" % cidx)] if "sample_name" in data \
+                    else ["clip%d/%d" % (ci, cidx)]
+                chunks.append(chunk)
+            # one batch: tensors concatenated along the clip dimension, per-clip lists chained
+            batch = {}
+            for k in chunks[0]:
+                v0 = chunks[0][k]
+                if torch.is_tensor(v0):
+                    batch[k] = torch.cat([c[k] for c in chunks], dim=0)
+                elif isinstance(v0, (list, tuple)):
+                    batch[k] = [x for c in chunks for x in c[k]]
+                else:
+                    batch[k] = v0
+            batch["motion_length"] = [self.seqlen] * len(act)
+            batch["retrieval_method"] = retrieval_method
+            prev = None if cidx == 0 else torch.cat([state[ci]["prev"] for ci in act], dim=0)
+            ikw = dict(use_inversion=use_inversion, outpaint=outpaint, inversion_start_time=inversion_start_time,
+                       insertion_guidance=insertion_guidance, guidance_lr=guidance_lr, use_prev_latent=True, prev_latent=prev)
+            if guidance_iters is not None:
+                ikw["guidance_iters"] = guidance_iters
+            if noise_tape is not None:
+                ikw["noise_tape"] = noise_tape.for_clips(act) if hasattr(noise_tape, "for_clips") else noise_tape
+            batch["inference_kwargs"] = ikw
+            out = self.model(**batch)
+            motion = packing.scatter_parts(out["pred_upper"], out["pred_lower"], out["pred_hands"], out["pred_facepose"])
+            for j, ci in enumerate(act):
+                st = state[ci]
+                st["prev"] = out["prev_latentout"][j:j + 1]
+                st["latents"].append(st["prev"])
+                cur = (motion[j:j + 1], out["pred_exps"][j:j + 1].float(), out["pred_transl"][j:j + 1].float())
+                st["so_far"] = cur if cidx == 0 else blend_window(st["so_far"], cur, self.overlap)
+                if with_gt:
+                    dev = cur[0].device
+                    gt = tuple(out[k][j:j + 1].to(dev).float() for k in ("motion", "facial", "trans"))
+                    st["gt_so_far"] = gt if cidx == 0 else blend_window(st["gt_so_far"], gt, self.overlap)
+        results = {ci: self._finish(state[ci], with_gt) for ci in mine}
+        if gather and td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+            parts = [None] * td.get_world_size()
+            slim = {ci: {k: v for k, v in r.items() if k != "latents"} for ci, r in results.items()}
+            td.all_gather_object(parts, slim)
+            results = {ci: r for part in parts for ci, r in part.items()}
+        return results
+
+    def _finish(self, st, with_gt):
+        motion, facial, trans = st["so_far"]
+        scale = self.target_fps // self.fps
+        up = lambda m, f, t: (packing.upsample_motion(m, scale), packing.upsample_features(f, scale),
+                              packing.upsample_features(t, scale)) if scale != 1 else (m, f, t)
+        motion, facial, trans = up(motion, facial, trans)
+        n_out = st["sample_len"] * scale
+        cut = lambda t: t[0, :n_out].detach().cpu().numpy()
+        result = dict(poses=cut(motion), expressions=cut(facial), trans=cut(trans), latents=st["latents"],
+                      windows=list(zip(st["starts"], st["ends"])))
+        if with_gt:
+            gm, gf, gt_ = up(*st["gt_so_far"])
             result.update(gt_poses=cut(gm), gt_expressions=cut(gf), gt_trans=cut(gt_))
         return result
 

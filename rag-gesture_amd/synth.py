@@ -211,6 +211,28 @@ class NoiseTape:
         return t.to(device) if device is not None else t
 
 
+class ClipTapes:
+    """One NoiseTape per clip behind the batch interface: draw((n * k, ...)) for n clips = the clips' own draws of
+    (k, ...) stacked in clip order.  A clip's noise then does not depend on which other clips share its batch: the
+    batched long-form driver (longform.run_many) and a per-clip run consume identical numbers."""
+
+    def __init__(self, seeds, clips=None):
+        self.tapes = {c: NoiseTape(s) for c, s in (seeds.items() if isinstance(seeds, dict) else enumerate(seeds))}
+        self.clips = list(self.tapes) if clips is None else list(clips)
+
+    def for_clips(self, clips):
+        out = ClipTapes({}, clips)
+        out.tapes = self.tapes
+        return out
+
+    def draw(self, shape, device=None):
+        n = len(self.clips)
+        assert shape[0] % n == 0, (shape, n)
+        per = (shape[0] // n,) + tuple(shape[1:])
+        t = torch.cat([self.tapes[c].draw(per) for c in self.clips], dim=0)
+        return t.to(device) if device is not None else t
+
+
 def synth_batch(batch, seed=1234, device="cpu"):
     """Synthetic collated batch with the schema of mogen/datasets/builder.py:55-92 and the
     value distributions of SURVEY.md section 8(d)."""

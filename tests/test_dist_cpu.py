@@ -86,3 +86,70 @@ def test_bench_launcher_starts_one_process_per_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+# ---- long-form clip sharding (BASELINE config 5: 10 clips over 8 GPUs; tools/longform_synthesis.py:211, 256)
+class _StubModel:
+    """Stands for MotionDiffusion on CPU: outputs are deterministic functions of the window and of the clip's own
+    prev-latent chain, so a wrong chain / a clip on the wrong rank / a mixed-up batch order changes the result."""
+
+    class model:
+        cfg = dict(frame_chunk_size=15)
+
+    def __call__(self, **kw):
+        m = kw["motion"].float()
+        B = m.shape[0]
+        prev = kw["inference_kwargs"]["prev_latent"]
+        prev = torch.zeros(B, 43, 512) if prev is None else prev
+        lat = prev * 0.5 + m.mean(dim=(1, 2)).view(B, 1, 1) + kw["audio"].float().mean(dim=(1, 2)).view(B, 1, 1)
+        s = lat.mean(dim=(1, 2)).view(B, 1, 1)
+        out = dict(kw, prev_latentout=lat, pred_upper=m[:, :, :39] + s, pred_lower=m[:, :, 39:66] + s,
+                   pred_facepose=m[:, :, 66:69] + s, pred_hands=m[:, :, 69:159] + s, pred_transl=kw["trans"].float() + s,
+                   pred_exps=kw["facial"].float() + s)
+        return out
+
+
+def _longform_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rg = importlib.import_module("rag-gesture_amd")
+    lf = rg.longform
+    # CPU stand-ins for the HIP post-processing (blend / scatter / interpolation are covered on the GPU)
+    lf.blend_window = lambda prev, cur, ov: tuple(torch.cat([p[:, :-ov], c], 1) for p, c in zip(prev, cur))
+    lf.packing.scatter_parts = lambda up, lo, ha, fa: torch.cat([up, lo, fa, ha, torch.zeros_like(up[:, :, :6])], -1)
+    lf.packing.upsample_motion = lambda t, s: t.repeat_interleave(s, dim=1)
+    lf.packing.upsample_features = lambda t, s: t.repeat_interleave(s, dim=1)
+    lens = [300, 150, 430, 200, 150]
+    clips = []
+    for ci, n in enumerate(lens):
+        g = torch.Generator().manual_seed(ci)
+        clips.append(dict(motion=torch.randn(1, n, 165, generator=g), trans=torch.randn(1, n, 3, generator=g),
+                          facial=torch.randn(1, n, 100, generator=g), motion_mask=torch.ones(1, n),
+                          speaker_ids=torch.zeros(1, n, dtype=torch.int64)))
+    feats = lambda ci, cidx, t0, t1, ann: dict(audio=torch.full((1, 499, 768), float(ci + 0.1 * cidx)), text_features=None)
+    synth = lf.LongformSynthesizer(_StubModel(), overlap=15)
+    res = synth.run_many(clips, feats, gather=True)
+    mine = synth.run_many(clips, feats, gather=False)
+    q.put((rank, {ci: float(r["poses"].sum()) for ci, r in res.items()}, sorted(mine)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_longform_run_many_shards_clips_over_ranks():
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world, port in ((1, 29621), (2, 29622)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_longform_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out[world] = sorted(q.get(timeout=180) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+    (_, single, all_clips), = out[1]
+    assert all_clips == [0, 1, 2, 3, 4]
+    (r0, g0, m0), (r1, g1, m1) = out[2]
+    assert m0 == [0, 1, 2] and m1 == [3, 4], "contiguous balanced shards (dist.shard_range)"
+    assert g0 == g1 == single, "every rank ends with every clip's result, equal to the single-process run"
