@@ -326,6 +326,15 @@ typedef struct rg_fwd_args {
 
 int rg_fwd_ctrl_words(int B);
 int rg_denoiser_forward(rg_handle* h, const rg_fwd_args* args_host, void* stream);
+/* The same tiles, ONE LAUNCH PER STAGE (58 launches for 8 layers instead of the ~90 of the per-op chain: LayerNorm /
+ * stylization ride in the consuming GEMM's A prologue, QKV + self-attention and query projection + cross-attention are
+ * one stage each): stage s runs tiles [stage_first_host[s], stage_first_host[s + 1]) of the DEVICE list stage_tiles
+ * (int4 per tile as in `sched`; type 255 = padding slot), one workgroup per tile.  The kernel boundary orders producers
+ * and consumers, so activations use the default cache policy and stay in the L2 of the XCD that wrote them when the list
+ * keeps a sequence on one XCD (workgroups are dealt round-robin over the 8 XCDs: slot p -> XCD p % 8).
+ * args.sched / args.ctrl are not used. */
+int rg_denoiser_forward_stages(rg_handle* h, const rg_fwd_args* args_host, const int* stage_tiles,
+                               const int* stage_first_host, int n_stages, void* stream);
 
 /* ---------------------------------------------------------------- body-part VAEs + rotations
  * Softmax multi-head attention core of torch.nn.MultiheadAttention for short sequences

@@ -7,8 +7,9 @@ cfg = rg.synth.default_model_cfg(num_layers=8)
 sch = rg.schedule.Schedule()
 W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, sch, "cuda")
 STEPS = 10
-for B in (8, 16, 24, 48):
-    sess = rg.denoiser.DenoiserSession(W, B)
+ENGINES = sys.argv[1:] or ["chain", "stages", "persistent"]
+for B, engine in [(b, e) for b in (8, 16, 24, 48) for e in ENGINES]:
+    sess = rg.denoiser.DenoiserSession(W, B, engine=engine, ln_mode="folded")
     d = rg.synth.synth_batch(B, seed=1)
     mask = torch.ones(B, 43)
     mask[:, [10, 21, 32]] = 0
@@ -32,4 +33,4 @@ for B in (8, 16, 24, 48):
             e0.record(); g.replay(); e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / STEPS)
-    print("B=%2d (M=%4d): %.1f us per forward step" % (B, 2 * B * 43, best), flush=True)
+    print("B=%2d (M=%4d) %-10s: %.1f us per forward step" % (B, 2 * B * 43, engine, best), flush=True)

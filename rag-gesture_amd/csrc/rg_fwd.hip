@@ -80,14 +80,19 @@ __device__ __forceinline__ float gelu_fast(float v) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
+// activation traffic; POL = SC1 inside the persistent launch (hand-offs between running workgroups), 0 = default cache
+// policy when every stage is a launch of its own (the kernel boundary orders producers and consumers, rows stay in L2)
+template <int POL>
 __device__ __forceinline__ u32x4 ld16(__amdgpu_buffer_rsrc_t r, int byte_off) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, SC1);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, POL);
 }
+template <int POL>
 __device__ __forceinline__ void st16(__amdgpu_buffer_rsrc_t r, int byte_off, u32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, SC1);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, POL);
 }
+template <int POL>
 __device__ __forceinline__ void st8(__amdgpu_buffer_rsrc_t r, int byte_off, u32x2 v) {
-  __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, SC1);
+  __builtin_amdgcn_raw_buffer_store_b64(v, r, byte_off, 0, POL);
 }
 __device__ __forceinline__ f32x4 asf(u32x4 v) { return __builtin_bit_cast(f32x4, v); }
 __device__ __forceinline__ u32x4 asu(f32x4 v) { return __builtin_bit_cast(u32x4, v); }
@@ -131,7 +136,12 @@ struct EpiOut {
 
 }  // namespace
 
-__global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
+// PERSIST = true: the whole forward, tiles pulled from the queues (a.sched) with dependency waits and publishes.
+// PERSIST = false: ONE stage per launch -- workgroup b runs tile tile0 + b of the stage-major list `stage_tiles`
+// (same tile code; the kernel boundary replaces the hand-off protocol, activations use the default cache policy).
+template <bool PERSIST>
+__global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a, const int* __restrict__ stage_tiles, int tile0) {
+  constexpr int POL = PERSIST ? SC1 : 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem + OFF_A;
   float* sQ = reinterpret_cast<float*>(smem + OFF_A);             // staging tile 0 (generic epilogue: the output tile)
@@ -169,7 +179,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
   int next_ticket = -1;
   if (tid == 0) {
     sCtl[1] = 0;
-    next_ticket = take();
+    next_ticket = PERSIST ? take() : tile0 + (int)blockIdx.x;
   }
 
   // ---- weight slice of this wave's 16 columns for one K = 512 panel, straight into registers: lane (l15, g4) holds,
@@ -221,13 +231,14 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
     __syncthreads();
     const int ticket = sCtl[0];
     if (ticket < 0) break;
-    const int4 td = *reinterpret_cast<const int4*>(sched + 16 + 4 * (size_t)ticket);
+    const int4 td = *reinterpret_cast<const int4*>((PERSIST ? sched + 16 : stage_tiles) + 4 * (size_t)ticket);
     const int type = __builtin_amdgcn_readfirstlane(td.x & 0xff);
+    if (!PERSIST && type == 0xff) break;   // padding slot of the stage list
     const int layer = __builtin_amdgcn_readfirstlane(td.x >> 8);
     const int seq = __builtin_amdgcn_readfirstlane(td.y);
     const int nt = __builtin_amdgcn_readfirstlane(td.z);
     const unsigned target = (unsigned)__builtin_amdgcn_readfirstlane(td.w);
-    if (tid == 0) next_ticket = take();   // in flight during the tile
+    if (tid == 0) next_ticket = PERSIST ? take() : -1;   // in flight during the tile
     unsigned long long* stamp = a.stamps ? a.stamps + 4 * (size_t)ticket : nullptr;
     if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
 
@@ -263,7 +274,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
     // Waves 1-3 request the first panel now; wave 0 polls first (its loads would sit in front of the poll's return
     // in the in-order vmcnt queue) and requests it when the dependency has resolved
     u32x4 wa[8], wb[8];
-    if (wave != 0) {
+    if (!PERSIST || wave != 0) {
       load_h(wa, wlane);
       load_h(wb, wlane + 256);
     }
@@ -280,7 +291,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
     }
 
     // ---- dependency: every earlier tile of this sequence has published
-    if (tid == 0) {
+    if (PERSIST && tid == 0) {
       const unsigned* cnt = ctrl + CTRL_CNT + seq * 16;
       unsigned spins = 0;
       int bad = 0;
@@ -295,10 +306,12 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
       }
       sCtl[1] = bad;
     }
-    __syncthreads();
-    if (sCtl[1]) break;
+    if (PERSIST) {
+      __syncthreads();
+      if (sCtl[1]) break;
+    }
     if (stamp && tid == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();
-    if (wave == 0) {
+    if (PERSIST && wave == 0) {
       load_h(wa, wlane);
       load_h(wb, wlane + 256);
     }
@@ -329,7 +342,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
           const int off = (((p.row0 + rl) * p.stats_ld) + p.part0) * 8;
           f32x4 s[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) s[q] = asf(ld16(rs, off + 16 * q));
+          for (int q = 0; q < 4; ++q) s[q] = asf(ld16<POL>(rs, off + 16 * q));
           float su = 0.f;
 #pragma unroll
           for (int q = 0; q < 4; ++q) su += s[q][0] + s[q][2];
@@ -354,7 +367,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
           for (int j = 0; j < 12; ++j) {
             const int u = vt + NTH * (b8 * 12 + j), row = u >> 7, q = u & 127;
             const int rl = row < T ? row : T - 1;
-            v[j] = asf(ld16(rs, (rl * p.ld + q * 4) * 4));
+            v[j] = asf(ld16<POL>(rs, (rl * p.ld + q * 4) * 4));
           }
           if (norm && b8 == 0) __syncthreads();   // parameters and row statistics are in LDS
 #pragma unroll
@@ -381,7 +394,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
         for (int j = 0; j < 12; ++j) {
           const int u = vt + NTH * j, row = u >> 6, ch = u & 63;
           const int rl = row < T ? row : T - 1;
-          v[j] = ld16(rs, (rl * p.ld + ch * 8) * 2);
+          v[j] = ld16<POL>(rs, (rl * p.ld + ch * 8) * 2);
         }
         if (norm) __syncthreads();
 #pragma unroll
@@ -490,7 +503,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int it = vt + NTH * j, row = it >> 4, c4 = it & 15;
-            resv[j] = asf(ld16(rr, ((row < T ? row : T - 1) * DM + c4 * 4) * 4));
+            resv[j] = asf(ld16<POL>(rr, ((row < T ? row : T - 1) * DM + c4 * 4) * 4));
           }
         }
 #pragma unroll
@@ -503,7 +516,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
             v = v + gld<f32x4>(eo.tbias + (size_t)rl * DM + eo.col0 + c4 * 4);
           }
           if (eo.residual || eo.tbias) *reinterpret_cast<f32x4*>(src + row * EPLD + c4 * 4) = v;
-          if (eo.o32 && row < T) st16(ro, (row * eo.ld32 + c4 * 4) * 4, asu(v));
+          if (eo.o32 && row < T) st16<POL>(ro, (row * eo.ld32 + c4 * 4) * 4, asu(v));
         }
         if ((eo.residual || eo.tbias) && (eo.o16 || eo.stats)) __syncthreads();
       }
@@ -515,7 +528,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
           if (it < TP * 8 && row < T) {
             const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + row * EPLD + c8 * 8);
             const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + row * EPLD + c8 * 8 + 4);
-            st16(ro, (row * eo.ld16 + c8 * 8) * 2, u32x4{pack2(x0[0], x0[1]), pack2(x0[2], x0[3]), pack2(x1[0], x1[1]), pack2(x1[2], x1[3])});
+            st16<POL>(ro, (row * eo.ld16 + c8 * 8) * 2, u32x4{pack2(x0[0], x0[1]), pack2(x0[2], x0[3]), pack2(x1[0], x1[1]), pack2(x1[2], x1[3])});
           }
         }
       }
@@ -545,7 +558,7 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
         m2 += __shfl_xor(m2, 2);
         if (part == 0 && row < T) {
           const __amdgpu_buffer_rsrc_t rs = rsrc_of(eo.stats);
-          st8(rs, ((row0 + row) * eo.stats_ld + eo.part) * 8, u32x2{__float_as_uint(s), __float_as_uint(m2)});
+          st8<POL>(rs, ((row0 + row) * eo.stats_ld + eo.part) * 8, u32x2{__float_as_uint(s), __float_as_uint(m2)});
         }
       }
     };
@@ -731,13 +744,15 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
     }
 
     // ---- publish: every wave's stores have completed, then one agent-scope add on the sequence's counter
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(ctrl + CTRL_CNT + seq * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
+    if (PERSIST) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(ctrl + CTRL_CNT + seq * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (stamp && tid == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();
+    if (!PERSIST) break;
   }
+  if (!PERSIST) return;
   // ---- the last workgroup to drain the queues (every tile has been published by then) leaves the control block
   // zeroed for the next launch: no memset between launches, nothing for a graph to reorder.  After an abort the
   // block stays as it is (the abort word is the caller's evidence; the caller re-zeroes it).
@@ -759,6 +774,17 @@ __global__ void __launch_bounds__(NTH, 2) rg_fwd_kernel(const rg_fwd_args a) {
 
 extern "C" int rg_fwd_ctrl_words(int B) { return CTRL_CNT + 2 * B * 16; }
 
+static int fwd_prepare(rg_handle* h, const void* fn, int* wgs_per_cu) {
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    h->err = "rg_denoiser_forward: cannot reserve LDS";
+    return RG_ERR_HIP;
+  }
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, NTH, LDS_BYTES) != hipSuccess || n < 1) n = 1;
+  *wgs_per_cu = n > 3 ? 3 : n;
+  return RG_OK;
+}
+
 extern "C" int rg_denoiser_forward(rg_handle* h, const rg_fwd_args* args_host, void* stream) {
   RG_REQUIRE(h, args_host, "null args");
   const rg_fwd_args& a = *args_host;
@@ -766,17 +792,33 @@ extern "C" int rg_denoiser_forward(rg_handle* h, const rg_fwd_args* args_host, v
   RG_REQUIRE(h, a.L >= 1 && a.B >= 1 && a.T >= 1 && a.T <= TP && a.step >= 0, "unsupported shape (T <= 48)");
   static int wgs_per_cu = 0;
   if (wgs_per_cu == 0) {
-    if (hipFuncSetAttribute((const void*)rg_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      h->err = "rg_denoiser_forward: cannot reserve LDS";
-      return RG_ERR_HIP;
-    }
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)rg_fwd_kernel, NTH, LDS_BYTES) != hipSuccess || n < 1) n = 1;
-    wgs_per_cu = n > 3 ? 3 : n;
+    const int rc = fwd_prepare(h, (const void*)rg_fwd_kernel<true>, &wgs_per_cu);
+    if (rc != RG_OK) return rc;
   }
   // one workgroup per resident slot; correctness does not depend on the grid size (any number of workgroups drains
   // the queues), only the overlap of one tile's latencies with another tile's work does
-  hipLaunchKernelGGL(rg_fwd_kernel, dim3(h->num_cus * wgs_per_cu), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
+  hipLaunchKernelGGL(rg_fwd_kernel<true>, dim3(h->num_cus * wgs_per_cu), dim3(NTH), LDS_BYTES, rg_stream(stream), a,
+                     (const int*)nullptr, 0);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_denoiser_forward_stages(rg_handle* h, const rg_fwd_args* args_host, const int* stage_tiles,
+                                          const int* stage_first_host, int n_stages, void* stream) {
+  RG_REQUIRE(h, args_host && stage_tiles && stage_first_host, "null pointer");
+  const rg_fwd_args& a = *args_host;
+  RG_REQUIRE(h, a.layers && a.x && a.xa && a.head, "null pointer");
+  RG_REQUIRE(h, a.L >= 1 && a.B >= 1 && a.T >= 1 && a.T <= TP && a.step >= 0 && n_stages >= 1, "unsupported shape (T <= 48)");
+  static int wgs_per_cu = 0;
+  if (wgs_per_cu == 0) {
+    const int rc = fwd_prepare(h, (const void*)rg_fwd_kernel<false>, &wgs_per_cu);
+    if (rc != RG_OK) return rc;
+  }
+  for (int s = 0; s < n_stages; ++s) {
+    const int n = stage_first_host[s + 1] - stage_first_host[s];
+    if (n <= 0) continue;
+    hipLaunchKernelGGL(rg_fwd_kernel<false>, dim3(n), dim3(NTH), LDS_BYTES, rg_stream(stream), a, stage_tiles, stage_first_host[s]);
+  }
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -194,9 +194,10 @@ def xcd_affine_order(n_groups, items_per_group, T, tile_rows=64, n_xcd=8):
 class DenoiserSession:
     """Buffers + conditioning state for B clips (R = 2B rows: conditional rows first, then the
     classifier-free rows).  Not re-entrant; one per (model, batch size, stream)."""
+    DEFAULT_ENGINE = "chain"
 
     def __init__(self, weights, B, persistent=None, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False,
-                 xcd_affine=True):
+                 xcd_affine=True, engine=None):
         """persistent: run `forward` as ONE persistent dataflow launch (rg_denoiser_forward) instead of ~90 dependent
         launches (bf16 production path, D = 512, FF = 1024, T <= 48).  Parity-green, but measured SLOWER than the
         launch chain on MI355X (1244 vs 881 us per forward at M = 1376, 1864 vs 1437 us at M = 4128: every tile pays
@@ -207,6 +208,11 @@ class DenoiserSession:
         forward finds rows more than LN_GUARD_SIGMAS standard deviations off centre (one read-back, once per session).
         styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain."""
         assert ln_mode in ("auto", "folded", "prologue")
+        # engine: "chain" = one launch per op (~90 per forward), "stages" = the fused tiles of fwd.py, one launch per
+        # stage (58), "persistent" = the same tiles in one launch; None = persistent if `persistent` else DEFAULT_ENGINE
+        if engine is None:
+            engine = "persistent" if persistent else ("chain" if persistent is False else self.DEFAULT_ENGINE)
+        assert engine in ("chain", "stages", "persistent")
         w = self.w = weights
         self.h = w.h
         self.B, self.R = B, 2 * B
@@ -264,9 +270,10 @@ class DenoiserSession:
         self.perm_ca = dv(order(self.R, 3 * ng, T))
         self.perm_cac = dv(order(B, 3 * ng, T))
         ok = F.supported(w, T)
-        if persistent and not ok:
-            raise capi.RgError("persistent forward: unsupported shape / precision")
-        self.pf = F.PersistentForward(self) if (ok and persistent) else None
+        if (persistent or engine != self.DEFAULT_ENGINE) and engine != "chain" and not ok:
+            raise capi.RgError("fused forward: unsupported shape / precision")
+        self.engine = engine if ok else "chain"
+        self.pf = F.PersistentForward(self, self.engine) if self.engine != "chain" else None
 
     # ------------------------------------------------------------------ once per clip
     def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None):

@@ -72,6 +72,29 @@ def build_schedule(B, L):
     return out
 
 
+def build_stage_schedule(B, L):
+    """Stage-major tile list for rg_denoiser_forward_stages: (tiles int32 [n, 4], first int32 [n_stages + 1]).
+    Inside a stage the slots are dealt to the 8 shards in turn (slot p -> shard p % 8 = the XCD the workgroup lands on
+    under round-robin dispatch), so the tiles of a sequence run on the same XCD in every stage and its rows are read
+    from the L2 they were written to; uneven shards are padded with type-255 slots."""
+    shards = [[] for _ in range(N_SHARD)]
+    for b in range(B):
+        shards[b % N_SHARD] += [b, B + b]
+    tiles, first = [], [0]
+    for typ, l in stage_list(L):
+        per = []
+        for seqs in shards:
+            per.append([(typ | (l << 8), s, nt, 0) for s in seqs if not (typ == Q3_CA and s >= B) for nt in range(TILES[typ])])
+        depth = max(len(p) for p in per)
+        for k in range(depth):
+            for q in range(N_SHARD):
+                tiles.append(per[q][k] if k < len(per[q]) else (0xff, 0, 0, 0))
+        while tiles and tiles[-1][0] == 0xff:      # trailing padding of the stage is not launched
+            tiles.pop()
+        first.append(len(tiles))
+    return np.asarray(tiles, dtype=np.int32).reshape(-1, 4), np.asarray(first, dtype=np.int32)
+
+
 def tiles_per_sequence(L, conditional):
     return sum(TILES[t] for t, _ in stage_list(L) if conditional or t != Q3_CA)
 
@@ -85,9 +108,11 @@ def supported(w, T):
 class PersistentForward:
     """Buffers + tables of one DenoiserSession for rg_denoiser_forward."""
 
-    def __init__(self, sess):
+    def __init__(self, sess, mode="persistent"):
+        """mode: "persistent" = one launch per forward (queues, hand-offs), "stages" = one launch per stage."""
+        assert mode in ("persistent", "stages")
         w = sess.w
-        self.sess, self.h = sess, sess.h
+        self.sess, self.h, self.mode = sess, sess.h, mode
         B, T, D, M, dev = sess.B, w.T, w.D, sess.M, w.dev
         bf = lambda *s: torch.empty(*s, device=dev, dtype=torch.bfloat16)
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
@@ -100,6 +125,9 @@ class PersistentForward:
         self.n_tiles = (len(self.sched_host) - SCHED_HEADER) // 4
         self.sched = torch.from_numpy(self.sched_host).to(dev)
         self.ctrl = torch.zeros(self.h.lib.rg_fwd_ctrl_words(B), device=dev, dtype=torch.int32)
+        st_tiles, self.stage_first = build_stage_schedule(B, w.L)
+        self.stage_tiles = torch.from_numpy(st_tiles).to(dev)
+        self._stage_first_c = (ctypes.c_int * len(self.stage_first))(*[int(v) for v in self.stage_first])
         p = lambda t: t.data_ptr()
         layers = (FwdLayer * w.L)()
         for l, lw in enumerate(w.layers):
@@ -130,7 +158,11 @@ class PersistentForward:
         a.x, a.step = x.data_ptr(), int(step)
         a.stamps = stamps.data_ptr() if stamps is not None else None
         s = torch.cuda.current_stream().cuda_stream
-        rc = self.h.lib.rg_denoiser_forward(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
+        if self.mode == "stages":
+            rc = self.h.lib.rg_denoiser_forward_stages(self.h._h, ctypes.byref(a), ctypes.c_void_p(self.stage_tiles.data_ptr()),
+                                                       self._stage_first_c, len(self.stage_first) - 1, ctypes.c_void_p(s))
+        else:
+            rc = self.h.lib.rg_denoiser_forward(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
         if rc != 0:
             raise capi.RgError("rg_denoiser_forward failed (%d): %s" % (rc, self.h.lib.rg_last_error(self.h._h).decode()))
         return self.sess.head

@@ -184,14 +184,16 @@ def test_persistent_forward_matches_launch_chain(rg, setup, B):
         mm[1, 5:9] = 0   # a clip with masked motion tokens
     qm = od.make_query_masks(mm)
     outs = {}
-    for persistent in (True, False):
-        sess = rg.denoiser.DenoiserSession(W, B, persistent=persistent)
-        assert (sess.pf is not None) == persistent
+    for persistent in (True, False, "stages"):
+        sess = rg.denoiser.DenoiserSession(W, B, engine={True: "persistent", False: "chain", "stages": "stages"}[persistent])
+        assert (sess.pf is not None) == bool(persistent)
         sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
         for step in (49, 7):
             outs[persistent, step] = sess.forward(x.cuda(), step).clone()
             torch.cuda.synchronize()
-        if persistent:
+        if persistent == "stages":   # same tile code, same arithmetic: the two fused engines agree bit for bit
+            assert torch.equal(outs["stages", 49], outs[True, 49]) and torch.equal(outs["stages", 7], outs[True, 7])
+        if persistent is True:
             assert not sess.pf.aborted()
             # replay: same inputs, same bits (the schedule is dynamic, the arithmetic per tile is not)
             again = sess.forward(x.cuda(), 7).clone()
