@@ -28,40 +28,66 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(rg_[a-z0-9_]+)\s*\(", text)))
 
 
+_SCALARS = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint, "int64_t": ctypes.c_int64,
+            "float": ctypes.c_float, "double": ctypes.c_double}
+
+
+def header_prototypes():
+    """name -> (restype, [argtypes]) for every function include/rg_gesture.h declares: pointers (device or host) are
+    void*, scalars keep their C width, so ctypes converts and range-checks every argument instead of guessing."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    text = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)   # struct bodies hold no prototypes
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int|void|const\s+char\s*\*)\s+(rg_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        argtypes = []
+        args = " ".join(args.split())
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                    continue
+                ty = " ".join(a.replace("const ", "").split()[:-1])
+                if ty not in _SCALARS:
+                    raise RgError("include/rg_gesture.h: cannot bind argument %r of %s" % (a, name))
+                argtypes.append(_SCALARS[ty])
+        restype = None if ret == "void" else (ctypes.c_char_p if "char" in ret else ctypes.c_int)
+        protos[name] = (restype, argtypes)
+    return protos
+
+
 def load_library():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RgError("HIP extension not built: %s is missing (run __graft_entry__.build())" % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
-        _lib.rg_last_error.restype = ctypes.c_char_p
-        _lib.rg_last_error.argtypes = [ctypes.c_void_p]
+        for name, (restype, argtypes) in header_prototypes().items():
+            fn = getattr(_lib, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = restype, argtypes
         _lib.rg_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
-        _lib.rg_destroy.argtypes = [ctypes.c_void_p]
-        _lib.rg_destroy.restype = None
     return _lib
 
 
 def _convert(a):
+    """Tensors -> device pointers; everything else is converted (and range-checked) by the prototype's argtypes."""
     if isinstance(a, torch.Tensor):
         if not a.is_cuda:
             raise RgError("device tensor expected, got a CPU tensor")
         if not a.is_contiguous():
             raise RgError("contiguous tensor expected")
-        return ctypes.c_void_p(a.data_ptr())
-    if a is None:
-        return ctypes.c_void_p(0)
+        return a.data_ptr()
     if isinstance(a, bool):
-        return ctypes.c_int(int(a))
-    if isinstance(a, int):
-        return ctypes.c_int64(a) if abs(a) >= 2 ** 31 else ctypes.c_int(a)
-    if isinstance(a, float):
-        return ctypes.c_float(a)
+        return int(a)
     return a
 
 
 class I64(int):
-    """Marks an integer argument that the C prototype declares as int64_t."""
+    """Kept for callers that mark int64_t arguments; the width now comes from the header's prototype."""
 
 
 class Handle:
@@ -94,8 +120,13 @@ class Handle:
         """Invoke rg_<name>(handle, *args, stream) and raise on a non-zero status."""
         fn = getattr(self.lib, "rg_" + name)
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-        cargs = [ctypes.c_int64(int(a)) if isinstance(a, I64) else _convert(a) for a in args]
-        rc = fn(self._h, *cargs, ctypes.c_void_p(s))
+        if fn.argtypes is None or len(fn.argtypes) != len(args) + 2:
+            raise RgError("rg_%s takes %s arguments besides handle and stream, got %d"
+                          % (name, "?" if fn.argtypes is None else len(fn.argtypes) - 2, len(args)))
+        try:
+            rc = fn(self._h, *[_convert(a) for a in args], s)
+        except ctypes.ArgumentError as e:
+            raise RgError("rg_%s: %s" % (name, e))
         if rc != 0:
             raise RgError("rg_%s failed (%d): %s" % (name, rc, self.lib.rg_last_error(self._h).decode()))
 

@@ -580,6 +580,46 @@ def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="d
     return out
 
 
+LMDB_DICTS = ("idx_2_text", "idx_2_sense", "idx_2_discbounds", "idx_2_gesture_labels", "idx_2_prominence", "idx_2_gestprom")
+
+
+def read_lmdb_dicts(lmdb_paths):
+    """The reference's six retrieval caches (raggesture.py:90-155 `LMDBDict`, :219-224: one LMDB environment per dict
+    under `lmdb_paths`, ascii keys in cursor order = sample-name order, values `pyarrow.serialize`d, tensors stored as
+    numpy arrays and converted back for idx_2_text) -> the metadata dict RetrievalDatabase takes, or None when the
+    caches cannot be read here (directory missing / empty, or `lmdb` / the legacy `pyarrow.deserialize` absent --
+    pyarrow >= 2 removed that serializer; this image has neither lmdb nor it).  Raises only on a corrupt cache."""
+    import os
+    try:
+        import lmdb
+        import pyarrow
+    except ImportError:
+        return None
+    if not hasattr(pyarrow, "deserialize") or lmdb_paths is None or not os.path.isdir(str(lmdb_paths)):
+        return None
+    out = {}
+    for name in LMDB_DICTS:
+        path = os.path.join(str(lmdb_paths), name)
+        if not os.path.isdir(path):
+            if name in ("idx_2_text", "idx_2_sense", "idx_2_discbounds", "idx_2_prominence"):
+                return None
+            continue
+        env = lmdb.open(path, readonly=True, lock=False)
+        d = {}
+        with env.begin(write=False) as txn:
+            for key, val in txn.cursor():
+                v = pyarrow.deserialize(val)
+                if name == "idx_2_text":   # torch_converter=True (:219)
+                    v = torch.from_numpy(v) if isinstance(v, np.ndarray) else \
+                        [torch.from_numpy(x) if isinstance(x, np.ndarray) else x for x in v] if isinstance(v, list) else v
+                d[key.decode("ascii")] = v
+        env.close()
+        if name in ("idx_2_text", "idx_2_sense") and not d:
+            return None      # fresh checkout: the reference rebuilds the caches from the dataset (:226-243)
+        out[name] = d
+    return out
+
+
 class RetrievalDatabase:
     """Drop-in for raggesture.py:157-884 `RetrievalDatabase` (inference; `discourse` and `gesture_type` methods).
 
@@ -591,12 +631,19 @@ class RetrievalDatabase:
 
     def __init__(self, num_retrieval=None, topk=None, latent_dim=512, text_latent_dim=768, max_seq_len=150,
                  motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", word_similarity=None,
-                 llm_output=None, stratified_db_creation=False, stratification_interval=15, **_cfg):
+                 llm_output=None, stratified_db_creation=False, stratification_interval=15, lmdb_paths=None,
+                 new_lmdb_cache=False, **_cfg):
+        """DB metadata, in this order: `metadata=` (the six dicts), the reference's LMDB caches under `lmdb_paths`
+        (when readable here and new_lmdb_cache is off, raggesture.py:219-243), `dataset.retrieval_samples` (raw
+        records -> build_db_dicts, what the reference does when its caches are empty)."""
+        if metadata is None and not new_lmdb_cache:
+            metadata = read_lmdb_dicts(lmdb_paths)
         if metadata is None:
             samples = getattr(dataset, "retrieval_samples", None)
             if samples is None:
-                raise capi.RgError("RetrievalDatabase needs `metadata=` or `dataset.retrieval_samples` "
-                                   "(the reference's LMDB caches cannot be read here: lmdb is not installed)")
+                raise capi.RgError("RetrievalDatabase needs `metadata=`, readable LMDB caches under lmdb_paths=%r (lmdb and "
+                                   "the legacy pyarrow.deserialize must be importable) or `dataset.retrieval_samples`"
+                                   % (lmdb_paths,))
             metadata = build_db_dicts(samples, stratified_db_creation, stratification_interval)
         self.dataset = dataset
         self.num_retrieval, self.topk = num_retrieval or 1, topk

@@ -37,3 +37,72 @@ def test_schedule_tables_match_the_oracle(rg):
     assert np.array_equal(np.asarray(s.c_next_a), np.sqrt(abn)) and np.array_equal(np.asarray(s.c_next_b), np.sqrt(f32(1) - abn))
     assert np.array_equal(np.asarray(s.c_recip), np.asarray(o.sqrt_recip_alphas_cumprod).astype(f32))
     assert np.array_equal(np.asarray(s.c_recipm1), np.asarray(o.sqrt_recipm1_alphas_cumprod).astype(f32))
+
+
+def test_lmdb_cache_reader_with_stub_modules(rg, tmp_path, monkeypatch):
+    """read_lmdb_dicts against the reference's cache layout (raggesture.py:90-155, 219-224) through in-memory stand-ins
+    for `lmdb` and the legacy `pyarrow.serialize / deserialize` (neither exists in this image: the reader then reports
+    "not readable" and RetrievalDatabase falls back to dataset.retrieval_samples)."""
+    import pickle
+    import sys
+    import types
+    import numpy as np
+    import torch
+    assert rg.retrieval.read_lmdb_dicts(str(tmp_path)) is None      # real environment: nothing to read with
+
+    stores = {}
+
+    class _Txn:
+        def __init__(self, d):
+            self.d = d
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+        def cursor(self):
+            return iter(sorted(self.d.items()))
+
+    class _Env:
+        def __init__(self, path):
+            self.d = stores[path]
+
+        def begin(self, write=False):
+            return _Txn(self.d)
+
+        def close(self):
+            pass
+
+    lmdb = types.ModuleType("lmdb")
+    lmdb.open = lambda path, **kw: _Env(path)
+    pa = types.ModuleType("pyarrow")
+    pa.deserialize = pickle.loads
+    monkeypatch.setitem(sys.modules, "lmdb", lmdb)
+    monkeypatch.setitem(sys.modules, "pyarrow", pa)
+
+    smp = rg.synth.synth_retrieval_samples(12, seed=4)
+    want = rg.retrieval.build_db_dicts(smp)
+    for name in rg.retrieval.LMDB_DICTS:
+        path = tmp_path / name
+        path.mkdir()
+        d = {}
+        for k, v in want[name].items():
+            if name == "idx_2_text":     # LMDBDict stores tensors as numpy (torch_converter=True)
+                v = [x.numpy() if torch.is_tensor(x) else x for x in v] if isinstance(v, (list, tuple)) else v.numpy()
+            d[k.encode("ascii")] = pickle.dumps(v)
+        stores[str(path)] = d
+    got = rg.retrieval.read_lmdb_dicts(str(tmp_path))
+    assert sorted(got) == sorted(rg.retrieval.LMDB_DICTS)
+    for name in rg.retrieval.LMDB_DICTS:
+        assert list(got[name].keys()) == sorted(want[name].keys())       # cursor order = sample-name order
+        if name != "idx_2_text":
+            assert got[name] == {k: want[name][k] for k in got[name]}
+    k0 = next(iter(got["idx_2_text"]))
+    a, b = got["idx_2_text"][k0], want["idx_2_text"][k0]
+    a0, b0 = (a[0], b[0]) if isinstance(a, (list, tuple)) else (a, b)
+    assert torch.is_tensor(a0) and np.array_equal(a0.numpy(), b0.numpy())
+    # an empty cache (fresh checkout) is "not readable": the caller rebuilds from the dataset, like the reference
+    stores[str(tmp_path / "idx_2_sense")] = {}
+    assert rg.retrieval.read_lmdb_dicts(str(tmp_path)) is None
