@@ -61,6 +61,14 @@ int rg_cfg_ddim_update(rg_handle* h, const float* out, const float* x, float* x_
                        const float* js, int B, int T, int D, float w_c, float w_u,
                        float c_recip, float c_recipm1, float c_a, float c_b, void* stream);
 
+/* The same CFG mix followed by one ancestral (DDPM) step, `inference_type="ddpm"`:
+ *   x_out = (c1 * x0 + c2 * x) + sigma * noise
+ *   (gaussian_diffusion.py:479-501 `q_posterior_mean_variance` with model_mean_type START_X, :560-570 fixed_large
+ *   variance, :795-803 `p_sample`: sigma = exp(0.5 * log_variance), 0 at the last step).  x_out may alias x. */
+int rg_cfg_ddpm_update(rg_handle* h, const float* out, const float* x, const float* noise, float* x_out,
+                       const float* js, int B, int T, int D, float w_c, float w_u, float c1, float c2, float sigma,
+                       void* stream);
+
 /* In-sequence replacement (outpainting / exemplar insertion / prev-latent chaining):
  *   m[r] = any(in_seq[r,:] != 0);  x[r,:] = m ? s_ab*in_seq[r,:] + s_1mab*noise[r,:] : x[r,:]
  *   (gaussian_diffusion.py:934-947 in `ddim_sample`, :459-477 `q_sample`).  rows = B*T. */

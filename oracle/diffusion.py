@@ -68,6 +68,10 @@ class SpacedSchedule:
         self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
         self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
         self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        # q(x_{t-1} | x_t, x_0) (gaussian_diffusion.py:427-440)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(1.0 - betas) / (1.0 - self.alphas_cumprod)
 
 
 def _ext(arr, i):
@@ -104,6 +108,26 @@ def ddim_sample(sch, model, x, i, noise, in_seq=None):
     mean_pred = x0 * torch.sqrt(ab_prev) + torch.sqrt(1 - ab_prev - sigma ** 2) * eps
     nonzero = 0.0 if i == 0 else 1.0
     return mean_pred + nonzero * sigma * n, x0
+
+
+def p_sample(sch, model, x, i, noise):
+    """reference: gaussian_diffusion.py:741-803 `p_sample` over :503-653 `p_mean_variance` with
+    model_mean_type START_X (pred_xstart = model output, mean = q_posterior_mean, :479-501) and
+    model_var_type FIXED_LARGE (log variance = log(append(posterior_variance[1], betas[1:])), :560-570)."""
+    t_orig = torch.full((x.shape[0],), sch.timestep_map[i], dtype=torch.long)
+    x0 = model(x, t_orig)
+    mean = _ext(sch.posterior_mean_coef1, i) * x0 + _ext(sch.posterior_mean_coef2, i) * x
+    log_var = _ext(np.log(np.append(sch.posterior_variance[1], sch.betas[1:])), i)
+    n = noise(x.shape)
+    nonzero = 0.0 if i == 0 else 1.0
+    return mean + nonzero * torch.exp(0.5 * log_var) * n, x0
+
+
+def p_sample_loop(sch, model, img, noise):
+    """reference: gaussian_diffusion.py:805-905 (img = th.randn(*shape) already drawn)."""
+    for i in range(sch.num_timesteps - 1, -1, -1):
+        img, _ = p_sample(sch, model, img, i, noise)
+    return img
 
 
 def ddim_reverse_sample(sch, model, x, i):

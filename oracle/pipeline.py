@@ -20,7 +20,7 @@ def part_indices(T):
 def motion_diffusion_forward(P, cfg, vae_cfgs, sch, data, tape, re_dict=None, use_inversion=False,
                              insertion_guidance=False, guidance_iters=None, guidance_lr=0.1,
                              use_prev_latent=False, prev_latent=None, outpaint=False,
-                             inversion_start_time=-1, trace=None):
+                             inversion_start_time=-1, trace=None, inference_type="ddim", visualize_inversion=False):
     """Returns dict(pred_upper, pred_lower, pred_facepose, pred_hands, pred_transl, pred_exps,
     prev_latentout, latent_in, start_noise, inverted)."""
     if use_prev_latent:
@@ -53,7 +53,7 @@ def motion_diffusion_forward(P, cfg, vae_cfgs, sch, data, tape, re_dict=None, us
 
     start_noise = None
     invl = None
-    inverted_all = []
+    inverted_all, recon_pairs = [], []
     if use_inversion:
         start_noise = tape.draw((B, T, D))
         n_lat = (T - 3) // 4
@@ -70,6 +70,9 @@ def motion_diffusion_forward(P, cfg, vae_cfgs, sch, data, tape, re_dict=None, us
                 inv = odf.ddim_reverse_sample_loop(sch, model_fn(xf_r, qm_r, ex["retr_motion_mask"]),
                                                    ex["retr_motion_latent"])
                 inverted_all.append(inv)
+                if visualize_inversion:   # diffusion_architecture.py:357-382: DDIM reconstruction from the last level
+                    recon_pairs.append((ex["retr_motion_latent"], odf.ddim_sample_loop(
+                        sch, model_fn(xf_r, qm_r, ex["retr_motion_mask"]), inv[-1].clone(), tape.draw)))
                 start_lat = inv[inversion_start_time]
                 r0, r1 = retr_se[q_idx]
                 q0, q1 = query_se[q_idx]
@@ -90,7 +93,9 @@ def motion_diffusion_forward(P, cfg, vae_cfgs, sch, data, tape, re_dict=None, us
 
     model = model_fn(xf, qm, motion_mask)
     img = start_noise if use_inversion else tape.draw((B, T, D))
-    if insertion_guidance:
+    if inference_type == "ddpm":   # diffusion_architecture.py:424-432: fresh start noise, ancestral sampling
+        out = odf.p_sample_loop(sch, model, tape.draw((B, T, D)) if use_inversion else img, tape.draw)
+    elif insertion_guidance:
         out = odf.ddim_guided_sample_loop(sch, model, img, tape.draw, guidance_iters, invl, guidance_lr,
                                           in_seq=prev_latent if use_prev_latent else None, trace=trace)
     elif use_prev_latent:
@@ -99,7 +104,16 @@ def motion_diffusion_forward(P, cfg, vae_cfgs, sch, data, tape, re_dict=None, us
         out = odf.ddim_sample_loop(sch, model, img, tape.draw,
                                    in_seq=retrieval_motion_latents if outpaint else None, trace=trace)
     up, lo, fa, ha, tr, ex, co = ovae.gesture_decode(P, vae_cfgs, out)
-    return dict(pred_upper=up, pred_lower=lo, pred_facepose=fa, pred_hands=ha, pred_transl=tr,
+    extra = {}
+    if use_inversion and visualize_inversion and inverted_all:
+        S = sch.num_timesteps
+        inv_lat = torch.stack([torch.cat(list(inv), dim=0) for inv in inverted_all], dim=0).reshape(-1, T, D)
+        pair_lat = torch.stack([torch.cat(list(pr), dim=0) for pr in recon_pairs], dim=0).reshape(-1, T, D)
+        for name, lat, k in (("inverted_output", inv_lat, S), ("reconspair_output", pair_lat, 2)):
+            dec = ovae.gesture_decode(P, vae_cfgs, lat)
+            for kname, t in zip(("upper", "lower", "facepose", "hands", "transl", "exps"), dec[:6]):
+                extra["%s_%s" % (name, kname)] = t.reshape(len(inverted_all), k, t.shape[1], -1)
+    return dict(extra, pred_upper=up, pred_lower=lo, pred_facepose=fa, pred_hands=ha, pred_transl=tr,
                 pred_exps=ex, pred_contact=co, prev_latentout=out, latent_in=motion,
                 latent_mask=motion_mask, start_noise=start_noise, inverted=inverted_all,
                 inverted_latent_list=invl)

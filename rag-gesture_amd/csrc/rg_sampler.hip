@@ -62,6 +62,24 @@ __global__ void __launch_bounds__(kBlock) cfg_ddim_kernel(const float4* __restri
   }
 }
 
+// CFG mix + ancestral (DDPM) step: mean = c1 * x0 + c2 * x, sample = mean + sigma * noise (sigma = 0 at the last step).
+__global__ void __launch_bounds__(kBlock) cfg_ddpm_kernel(const float4* __restrict__ out, const float4* __restrict__ x,
+                                                         const float4* __restrict__ noise, float4* __restrict__ xo,
+                                                         const float* __restrict__ js, int64_t n4, int td4, int d4,
+                                                         float w_c, float w_u, float c1, float c2, float sigma) {
+  for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    int t = (int)((i % td4) / d4);
+    float jc = js[t];
+    float ju = 1.0f / jc;
+    float4 oc = out[i], ou = out[i + n4], a = x[i], z = noise[i], r;
+    r.x = (c1 * cfg_one(oc.x, ou.x, jc, ju, w_c, w_u) + c2 * a.x) + sigma * z.x;
+    r.y = (c1 * cfg_one(oc.y, ou.y, jc, ju, w_c, w_u) + c2 * a.y) + sigma * z.y;
+    r.z = (c1 * cfg_one(oc.z, ou.z, jc, ju, w_c, w_u) + c2 * a.z) + sigma * z.z;
+    r.w = (c1 * cfg_one(oc.w, ou.w, jc, ju, w_c, w_u) + c2 * a.w) + sigma * z.w;
+    xo[i] = r;
+  }
+}
+
 // One wave per token row: the wave first decides m = any(in_seq[row] != 0) with a ballot,
 // then rewrites the row.  dim is a multiple of 4.
 __global__ void __launch_bounds__(kBlock) inseq_replace_kernel(float* __restrict__ x,
@@ -181,6 +199,18 @@ extern "C" int rg_cfg_ddim_update(rg_handle* h, const float* out, const float* x
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(rg_grid_1d(n4, kBlock)), dim3(kBlock), 0, rg_stream(stream),
                      (const float4*)out, (const float4*)x, (float4*)x_out, (float4*)x0_out, js, n4, T * D / 4,
                      D / 4, w_c, w_u, c_recip, c_recipm1, c_a, c_b);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_cfg_ddpm_update(rg_handle* h, const float* out, const float* x, const float* noise, float* x_out,
+                                  const float* js, int B, int T, int D, float w_c, float w_u, float c1, float c2,
+                                  float sigma, void* stream) {
+  RG_REQUIRE(h, out && x && noise && x_out && js, "null pointer");
+  RG_REQUIRE(h, B > 0 && T > 0 && D > 0 && D % 4 == 0, "bad shape");
+  int64_t n4 = (int64_t)B * T * D / 4;
+  hipLaunchKernelGGL(cfg_ddpm_kernel, dim3(rg_grid_1d(n4, kBlock)), dim3(kBlock), 0, rg_stream(stream), (const float4*)out,
+                     (const float4*)x, (const float4*)noise, (float4*)x_out, js, n4, T * D / 4, D / 4, w_c, w_u, c1, c2, sigma);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -493,3 +493,10 @@ class DenoiserSession:
         wc, wu = sch.cfg_weights(w.cfg["scale_func_cfg"], step)
         self.h.call("cfg_ddim_update", self.head, x, x_out, x0_out, w.js, self.B, w.T, w.D, wc, wu,
                     float(sch.c_recip[step]), float(sch.c_recipm1[step]), float(c_a), float(c_b))
+
+    def cfg_ddpm(self, x, x_out, step, noise):
+        """CFG mix of self.head + one ancestral step (inference_type="ddpm"; gaussian_diffusion.py:795-803)."""
+        w, sch = self.w, self.w.schedule
+        wc, wu = sch.cfg_weights(w.cfg["scale_func_cfg"], step)
+        self.h.call("cfg_ddpm_update", self.head, x, noise, x_out, w.js, self.B, w.T, w.D, wc, wu,
+                    float(sch.post_c1[step]), float(sch.post_c2[step]), float(sch.ddpm_sigma[step]))

@@ -219,7 +219,7 @@ class MotionDiffusion(torch.nn.Module):
                                            respace=dt.get("respace"))
         assert dt.get("model_mean_type", "start_x") == "start_x" and dt.get("classifier_free_guidance_scale", 0) == 0
         self.inference_type = inference_type
-        assert inference_type == "ddim", "only the DDIM inference path is implemented (config: inference_type='ddim')"
+        assert inference_type in ("ddim", "ddpm"), "inference_type is 'ddim' (shipped config) or 'ddpm'"
         self.device, self.precision = torch.device(device), precision
         self.training = False
         self.session_options, self.vae_options = dict(session_options or {}), dict(vae_options or {})
@@ -431,7 +431,7 @@ class MotionDiffusion(torch.nn.Module):
         use_outpaint = inference_kwargs.pop("outpaint", False)
         use_inversion = inference_kwargs.pop("use_inversion", False)
         inversion_start_time = inference_kwargs.pop("inversion_start_time", -1)
-        inference_kwargs.pop("visualize_inversion", False)  # diagnostic decode of all levels: out of scope
+        visualize_inversion = inference_kwargs.pop("visualize_inversion", False)
         use_insertion_guidance = inference_kwargs.pop("insertion_guidance", False)
         guidance_iters = inference_kwargs.pop("guidance_iters", [10] * 50)
         if isinstance(guidance_iters, str):     # the tools' --guidance_iters names
@@ -538,12 +538,33 @@ class MotionDiffusion(torch.nn.Module):
             x = start_noise
         else:
             x = tape.draw((B, T, D)).to(dev).contiguous()
+        if use_inversion and visualize_inversion and not isinstance(tape, _TorchNoise):
+            # the reconstruction check of every exemplar (diffusion_architecture.py:366-379) is a 50-step DDIM loop that
+            # draws randn_like(x) per step (sigma = 0: never used): keep an explicit tape aligned
+            for b in range(B):
+                for _ in retrieval_dict["retr_uncropped_latents"][b]:
+                    for _ in range(S):
+                        tape.draw((1, T, D))
         in_seq = None
         if use_prev_latent and prev_latent is not None:
             in_seq = prev_latent
         elif use_outpaint:
             in_seq = retrieval_motion_latents
-        need_noise = in_seq is not None or use_insertion_guidance
+        ddpm = self.inference_type == "ddpm"
+        ddpm_noise = None
+        if ddpm:
+            # diffusion_architecture.py:424-432: p_sample_loop with a FRESH randn start (the inversion / in_seq results
+            # above are computed and ignored by this branch, as in the reference); one randn_like(x) per step
+            if use_inversion:   # start_noise was drawn (and spliced) for nothing; p_sample_loop draws its own start
+                x = tape.draw((B, T, D)).to(dev).contiguous()
+            if isinstance(tape, _TorchNoise):
+                ddpm_noise = tape.draw((S, B, T, D))
+            else:
+                ddpm_noise = torch.empty(S, B, T, D, device=dev)
+                for i in range(S - 1, -1, -1):
+                    ddpm_noise[i].copy_(tape.draw((B, T, D)).to(dev))
+            in_seq = None
+        need_noise = (in_seq is not None or use_insertion_guidance) and not ddpm
         inseq_noise = None
         if need_noise:
             # the reference draws randn_like(in_seq) then randn_like(x) on every step (the latter is
@@ -560,10 +581,11 @@ class MotionDiffusion(torch.nn.Module):
                     if has:
                         inseq_noise[i].copy_(tape.draw((B, T, D)).to(dev))
                     tape.draw((B, T, D))
-        elif not isinstance(tape, _TorchNoise):
+        elif not isinstance(tape, _TorchNoise) and not ddpm:
             for _ in range(S):
                 tape.draw((B, T, D))
         x_out = torch.empty(B, T, D, device=dev)
+        vis_inv, vis_pairs = [], []   # visualize_inversion: per exemplar all levels [S,T,D] and (start, reconstruction)
 
         # ---- lanes: [exemplar inversion -> splice -> sampling] per clip group, concurrently
         for lane, stream, b0, b1 in plan:
@@ -598,6 +620,14 @@ class MotionDiffusion(torch.nn.Module):
                             h.call("splice_rows", inv[lvl], start_noise, T, D, n_lat, e, b, r0, r1, q0, q1)
                             if use_insertion_guidance:
                                 h.call("splice_rows_rep", inv, invl, T, D, n_lat, e, b, r0, r1, q0, q1, S, Ep, B)
+                        if visualize_inversion:
+                            # sanity check of the reference (diffusion_architecture.py:357-382): every inversion level
+                            # and the DDIM reconstruction from the last level, decoded after the sampling below
+                            (rec,) = self._graph_run(("recon", Ep, lane, T), dict(x=inv[S - 1]), lambda s, esess=esess: (
+                                sampler.ddim_sample_loop(esess, s["x"]),))
+                            for e in range(E):
+                                vis_inv.append(inv[:, e])
+                                vis_pairs.append(torch.stack([x_e[e], rec[e]]))
                     if use_insertion_guidance and use_prev_latent and prev_latent is not None:
                         for idx in (up_i, ha_i, fa_i, lt_i):
                             invl[:, b0:b1, idx[0], :] = 0
@@ -610,7 +640,10 @@ class MotionDiffusion(torch.nn.Module):
                 sl = lambda t, dim: None if t is None else (t[b0:b1] if dim == 0 else t[:, b0:b1])
                 loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(inseq_noise, 1), invl=sl(invl, 1))
                 with self._phase("sampling"):
-                    if use_insertion_guidance:
+                    if ddpm:
+                        (xl,) = self._graph_run(("ddpm", Bl, lane, T), dict(x=sl(x, 0), noise=sl(ddpm_noise, 1)),
+                                                lambda s, sess=sess: (sampler.p_sample_loop(sess, s["x"], s["noise"]),))
+                    elif use_insertion_guidance:
                         gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
                         key = ("guided", Bl, lane, T, in_seq is not None, gi, lr)
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess, gi=gi, lr=lr: (
@@ -630,4 +663,20 @@ class MotionDiffusion(torch.nn.Module):
         results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
         results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
         results["pred_contact"] = co
+        if use_inversion and visualize_inversion and vis_inv:
+            # diffusion_architecture.py:488-571: decoded inversion levels [n_exemplars, S, frames, *] and decoded
+            # (exemplar, reconstruction) pairs [n_exemplars, 2, frames, *]
+            n_ex = len(vis_inv)
+            keys = ("upper", "lower", "facepose", "hands", "transl", "exps")
+            for name, lat, k in (("inverted_output", torch.stack(vis_inv).reshape(n_ex * S, T, D), S),
+                                 ("reconspair_output", torch.stack(vis_pairs).reshape(n_ex * 2, T, D), 2)):
+                lat = self.model.post_process(lat.contiguous())
+                parts = [[] for _ in keys]
+                for c0 in range(0, lat.shape[0], 128):            # decoded in slabs of 128 like the reference (:496-528)
+                    dec = gre.decode(lat[c0:c0 + 128].contiguous())
+                    for j in range(6):
+                        parts[j].append(dec[j])
+                for j, kname in enumerate(keys):
+                    t = torch.cat(parts[j], dim=0)
+                    results["%s_%s" % (name, kname)] = t.reshape(n_ex, k, t.shape[1], -1)
         return results

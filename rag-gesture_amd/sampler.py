@@ -34,6 +34,16 @@ def ddim_sample_loop(sess, x, in_seq=None, inseq_noise=None):
     return x
 
 
+def p_sample_loop(sess, x, noise):
+    """Ancestral sampling (gaussian_diffusion.py:805-905 `p_sample_loop`, fixed_large variance): x = start noise
+    [B,T,D] (updated in place and returned), noise [S,B,T,D] = the randn_like(x) draw of every step."""
+    S = sess.w.schedule.num_timesteps
+    for i in range(S - 1, -1, -1):
+        sess.forward(x, i)
+        sess.cfg_ddpm(x, x, i, noise[i])
+    return x
+
+
 def ddim_reverse_sample_loop(sess, x, out):
     """DDIM inversion of x [B,T,D] (clean -> noise); out [S,B,T,D] receives every level
     (out[k] = latent at alphas_cumprod_next[k]), x is updated in place to out[S-1]."""

@@ -134,3 +134,27 @@ def test_end_to_end_L2(golden_dir, rg, rtag, ikw, need_re):
     assert ((lat - ref)[:, KEEP].norm() / ref[:, KEEP].norm()) <= 2e-2
     for k in ("pred_transl", "pred_exps"):
         assert ((out[k] - g["%s_%s" % (rtag, k)]).norm() / g["%s_%s" % (rtag, k)].norm()) <= 2e-2
+
+
+def test_ddpm_and_visualize_inversion_vs_reference(golden_dir, rg):
+    """inference_type="ddpm" (p_sample_loop, fixed_large variance) and inference_kwargs["visualize_inversion"]
+    (decoded inversion levels + DDIM reconstructions): oracle against the real reference's outputs
+    (tests/golden/make_ddpm_golden.py)."""
+    torch.set_num_threads(8)
+    g = _load(golden_dir, "e2e_ddpm_L2.npz")
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    sch = odf.SpacedSchedule()
+    with torch.no_grad():
+        out = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, sch, rg.synth.synth_batch(2, seed=4321), rg.synth.NoiseTape(2024),
+                                             inference_type="ddpm")
+    for k in ("prev_latentout", "pred_upper", "pred_hands", "pred_transl", "pred_exps"):
+        assert (out[k] - g["ddpm_" + k]).abs().max() <= 5e-4, k
+    with torch.no_grad():
+        out = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, sch, rg.synth.synth_batch(2, seed=4321), rg.synth.NoiseTape(2024),
+                                             re_dict=opipe.synthetic_re_dict(2, seed=77), use_inversion=True, visualize_inversion=True)
+    assert (out["prev_latentout"] - g["visinv_prev_latentout"]).abs().max() <= 5e-4
+    assert out["inverted_output_upper"].shape == (4, 50, 150, 39) and out["reconspair_output_exps"].shape == (4, 2, 150, 100)
+    assert (out["inverted_output_transl"][:, [0, 24, 49]] - g["visinv_inverted_output_transl_lv"]).abs().max() <= 2e-3
+    assert (out["reconspair_output_transl"] - g["visinv_reconspair_output_transl"]).abs().max() <= 2e-3

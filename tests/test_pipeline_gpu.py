@@ -266,3 +266,42 @@ def test_full_depth_end_to_end_vs_reference_golden(rg, golden_dir, rtag, ikw, ne
     print("L8 encdec", rtag, precision, "latent %.3e transl %.3e upper(rot) %.3e" % (e, et, eu))
     assert e <= (1e-2 if precision == "fp32" else 3e-2)
     assert et <= 5e-2 and eu <= 5e-2
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_ddpm_inference_type_vs_reference_golden(rg, golden_dir, precision):
+    """inference_type="ddpm": ancestral sampling (rg_cfg_ddpm_update) against the real reference
+    (diffusion_architecture.py:424-432, gaussian_diffusion.py:741-905)."""
+    g = np.load(os.path.join(golden_dir, "e2e_ddpm_L2.npz"))
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    mc = dict(rg.synth.reference_style_model_cfg(cfg, vae_cfgs), inference_type="ddpm")
+    model = rg.build_architecture(mc, database=None, precision=precision)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    out = model(**dict(rg.synth.synth_batch(2, seed=4321), retrieval_method="discourse",
+                       inference_kwargs=dict(noise_tape=rg.synth.NoiseTape(2024))))
+    torch.cuda.synchronize()
+    e = relerr(out["prev_latentout"].cpu()[:, KEEP], torch.from_numpy(g["ddpm_prev_latentout"])[:, KEEP])
+    et = relerr(out["pred_transl"].cpu(), torch.from_numpy(g["ddpm_pred_transl"]))
+    print("ddpm", precision, "final latent rel err %.3e, transl %.3e" % (e, et))
+    assert e <= (2e-3 if precision == "fp32" else 3e-2) and et <= 5e-2
+
+
+def test_visualize_inversion_vs_reference_golden(rg, models, golden_dir):
+    """inference_kwargs["visualize_inversion"]: decoded inversion levels [n_exemplars, 50, 150, *] and decoded
+    (exemplar, DDIM reconstruction) pairs (diffusion_architecture.py:357-382, 488-571), noise tape kept aligned."""
+    g = np.load(os.path.join(golden_dir, "e2e_ddpm_L2.npz"))
+    model = models[("L2", "fp32")]
+    data = rg.synth.synth_batch(2, seed=4321)
+    data["re_dict"] = opipe.synthetic_re_dict(2, seed=77)
+    out = model(**dict(data, retrieval_method="discourse",
+                       inference_kwargs=dict(use_inversion=True, visualize_inversion=True, noise_tape=rg.synth.NoiseTape(2024))))
+    torch.cuda.synchronize()
+    e = relerr(out["prev_latentout"].cpu()[:, KEEP], torch.from_numpy(g["visinv_prev_latentout"])[:, KEEP])
+    assert e <= 2e-3
+    assert out["inverted_output_upper"].shape == (4, 50, 150, 39) and out["reconspair_output_hands"].shape == (4, 2, 150, 90)
+    et = relerr(out["inverted_output_transl"][:, [0, 24, 49]].cpu(), torch.from_numpy(g["visinv_inverted_output_transl_lv"]))
+    er = relerr(out["reconspair_output_transl"].cpu(), torch.from_numpy(g["visinv_reconspair_output_transl"]))
+    eu = rot_relerr(out["reconspair_output_upper"].cpu().reshape(-1, 150, 39), torch.from_numpy(g["visinv_reconspair_output_upper"]).reshape(-1, 150, 39))
+    print("visualize_inversion fp32: latent %.3e, inverted transl %.3e, recon transl %.3e, recon upper(rot) %.3e" % (e, et, er, eu))
+    assert et <= 3e-2 and er <= 3e-2 and eu <= 3e-2
