@@ -352,7 +352,7 @@ int rg_denoiser_forward_stages(rg_handle* h, const rg_fwd_args* args_host, const
 int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* o,
            int ldo, int B, int H, int Sq, int Sk, int hd, void* stream);
 /* Same operation on the matrix cores for the bf16 path (K, V rounded to bf16, Q and the softmax
- * probabilities as bf16 hi + lo pairs, fp32 accumulation): hd in {16, 32, 64, 128}, Sk <= 192, row
+ * probabilities as bf16 hi + lo pairs, fp32 accumulation): hd in {16, 32, 64, 128}, Sk <= 192 (Sk <= 512 at hd = 64: wav2vec2 windows), row
  * strides multiples of 4 floats.  out_is_bf16 = 1: o is bf16 [B*Sq, ldo] (the A operand of the out-projection). */
 int rg_mha_bf16(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, void* o, int ldo,
                 int out_is_bf16, int B, int H, int Sq, int Sk, int hd, void* stream);
@@ -360,6 +360,27 @@ int rg_mha_bf16(rg_handle* h, const float* q, int ldq, const float* k, int ldk, 
 /* nn.LayerNorm(dim), eps 1e-5, fp32 rows (detr_utils.py norm1/norm2/norm3, encoder/decoder norm). */
 int rg_layernorm(rg_handle* h, const float* x, const float* gamma, const float* beta, float* out, int rows, int dim,
                  void* out_bf16, void* stream);
+
+/* LayerNorm(x + residual) with the caller's eps (residual may be NULL): the post-norm steps of the conditioning encoders
+ * (BERT eps 1e-12, wav2vec2 1e-5; transformers BertSelfOutput / Wav2Vec2EncoderLayer).  out_bf16: optional bf16 copy. */
+int rg_layernorm_res(rg_handle* h, const float* x, const float* residual, const float* gamma, const float* beta, float* out,
+                     int rows, int dim, float eps, void* out_bf16, void* stream);
+
+/* ---------------------------------------------------------------- conditioning feature extraction
+ * tools/longform_synthesis.py:64-94 computes, per 10-second window, BERT-base-cased hidden states (sum of the last four
+ * layers) of the window's transcript and the wav2vec2-base-960h last hidden state [499, 768] of its audio.  Both encoders
+ * run on rg_gemm / rg_mha_bf16 / rg_layernorm_res (host: rag-gesture_amd/features.py); these are the remaining pieces:
+ *   rg_embed_sum3: out[t] = word[ids[t]] + type0 + pos[t]  (BertEmbeddings before its LayerNorm; ids int64 on device)
+ *   rg_time_groupnorm_gelu: x [T][C] fp32 -> GELU(GroupNorm_{groups = C}(x)) as bf16 and / or fp32 (either output may
+ *     be NULL; normalisation over TIME per channel: layer 0 of the wav2vec2 feature extractor, feat_extract_norm =
+ *     "group"); workspace: 2 * C floats
+ *   rg_im2col_grouped: out[g][t][k * C/groups + ci] = x[t + k - pad][g * C/groups + ci] (zero outside [0, T)), bf16: the
+ *     patch matrices of the positional convolution (Conv1d(768, 768, 128, padding 64, groups 16)), one GEMM per group. */
+int rg_embed_sum3(rg_handle* h, const int64_t* ids, const float* word, const float* pos, const float* type0, float* out,
+                  int L, int dim, void* stream);
+int rg_time_groupnorm_gelu(rg_handle* h, const float* x, const float* gamma, const float* beta, void* out_bf16,
+                           float* out_f32, int T, int C, float eps, float* workspace, void* stream);
+int rg_im2col_grouped(rg_handle* h, const float* x, void* out_bf16, int T, int C, int groups, int ksize, int pad, void* stream);
 
 /* out[i] = a[i] + b[i % period]: positional embeddings / `with_pos_embed` (detr_utils.py:357-358). */
 int rg_add_rows(rg_handle* h, const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream);

@@ -104,7 +104,8 @@ typedef __attribute__((ext_vector_type(4))) float mh_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int mh_u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int mh_u32x2;
 
-constexpr int MH_MAX_SK = 192;
+constexpr int MH_MAX_SK = 192;   // key capacity of the default instantiation (VAE stacks, BERT windows)
+constexpr int MH_BIG_SK = 512;   // wav2vec2 windows (499 frames): 32 score blocks in registers, 140 KiB of K / V^T in LDS
 
 __device__ __forceinline__ unsigned short mh_bf16_bits(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ float mh_bf16_val(float f) { return (float)(__bf16)f; }
@@ -113,7 +114,7 @@ __device__ __forceinline__ unsigned int mh_pack(float a, float b) {
 }
 
 // HD_ = head dim padded to a multiple of 32 (the MFMA k-step); HDR = real head dim (16 -> zero padded)
-template <int HD_, int HDR>
+template <int HD_, int HDR, int MAXSK = MH_MAX_SK>
 __global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                       int ldk, const float* __restrict__ v, int ldv,
                                                       float* __restrict__ o, int ldo, int H, int Sq, int Sk, float scale,
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__
   constexpr int KST = HD_ + 8;                 // bf16 elements per K row (pad: 16 key rows hit 16 bank groups)
   constexpr int KS = HD_ / 32;                 // k-steps of S^T = K Q^T
   constexpr int ND = HDR / 16;                 // 16-column blocks of O
-  constexpr int NB = MH_MAX_SK / 16;           // key blocks held in registers
+  constexpr int NB = MAXSK / 16;               // key blocks held in registers
   const int Skp = (Sk + 31) & ~31;             // keys padded to whole PV k-steps (P = 0, V^T = 0 there)
   const int VST = Skp + 8;                     // bf16 elements per V^T row
   unsigned short* sK = reinterpret_cast<unsigned short*>(smraw);           // [Skp][KST]
@@ -254,17 +255,17 @@ __global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__
   }
 }
 
-template <int HD_, int HDR>
+template <int HD_, int HDR, int MAXSK = MH_MAX_SK>
 static int launch_mha_mfma(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            float* o, int ldo, int B, int H, int Sq, int Sk, int out_bf16, hipStream_t s) {
   const int Skp = (Sk + 31) & ~31;
   const size_t lds = ((size_t)Skp * (HD_ + 8) + (size_t)HD_ * (Skp + 8)) * sizeof(unsigned short);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mha_mfma_kernel<HD_, HDR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)mha_mfma_kernel<HD_, HDR, MAXSK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL((mha_mfma_kernel<HD_, HDR>), dim3(B * H, (Sq + 63) / 64), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, o, ldo,
+  hipLaunchKernelGGL((mha_mfma_kernel<HD_, HDR, MAXSK>), dim3(B * H, (Sq + 63) / 64), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, o, ldo,
                      H, Sq, Sk, 1.0f / sqrtf((float)HDR), out_bf16);
   return 0;
 }
@@ -294,6 +295,36 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     const float v = (xr[i] - mean) * rstd * g[i] + b[i];
     orow[i] = v;
     if (out_bf16) out_bf16[(size_t)row * dim + i] = __builtin_bit_cast(unsigned short, (__bf16)v);   // next GEMM's A operand
+  }
+}
+
+// LN(x + r) with a caller-supplied eps (post-norm encoder layers of BERT / wav2vec2); one wave per row
+__global__ void __launch_bounds__(256) layernorm_res_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const float* __restrict__ g, const float* __restrict__ b,
+                                                           float* __restrict__ out, int rows, int dim, float eps,
+                                                           unsigned short* __restrict__ out_bf16) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * dim;
+  const float* rr = res ? res + (size_t)row * dim : nullptr;
+  float s = 0.f;
+  for (int i = lane; i < dim; i += 64) s += xr[i] + (rr ? rr[i] : 0.f);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)dim;
+  float ss = 0.f;
+  for (int i = lane; i < dim; i += 64) {
+    const float d = xr[i] + (rr ? rr[i] : 0.f) - mean;
+    ss += d * d;
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) ss += __shfl_xor(ss, off);
+  const float rstd = 1.0f / sqrtf(ss / (float)dim + eps);
+  float* orow = out + (size_t)row * dim;
+  for (int i = lane; i < dim; i += 64) {
+    const float v = (xr[i] + (rr ? rr[i] : 0.f) - mean) * rstd * g[i] + b[i];
+    orow[i] = v;
+    if (out_bf16) out_bf16[(size_t)row * dim + i] = __builtin_bit_cast(unsigned short, (__bf16)v);
   }
 }
 
@@ -577,11 +608,14 @@ extern "C" int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int
 extern "C" int rg_mha_bf16(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            void* o, int ldo, int out_is_bf16, int B, int H, int Sq, int Sk, int hd, void* stream) {
   RG_REQUIRE(h, q && k && v && o, "null pointer");
-  RG_REQUIRE(h, B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= MH_MAX_SK, "bad shape (Sk <= 192)");
+  RG_REQUIRE(h, B > 0 && H > 0 && Sq > 0 && Sk > 0 && (Sk <= MH_MAX_SK || (Sk <= MH_BIG_SK && hd == 64)),
+             "bad shape (Sk <= 192, or Sk <= 512 at head dim 64)");
   RG_REQUIRE(h, hd == 128 || hd == 64 || hd == 32 || hd == 16, "head dim must be 16, 32, 64 or 128");
   RG_REQUIRE(h, ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "row strides must be multiples of 4 floats");
   hipStream_t s = rg_stream(stream);
   if (hd == 128) launch_mha_mfma<128, 128>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else if (hd == 64 && Sk > MH_MAX_SK)
+    launch_mha_mfma<64, 64, MH_BIG_SK>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
   else if (hd == 64) launch_mha_mfma<64, 64>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
   else if (hd == 32) launch_mha_mfma<32, 32>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
   else launch_mha_mfma<32, 16>(h, q, ldq, k, ldk, v, ldv, reinterpret_cast<float*>(o), ldo, B, H, Sq, Sk, out_is_bf16, s);
@@ -595,6 +629,16 @@ extern "C" int rg_layernorm(rg_handle* h, const float* x, const float* gamma, co
   RG_REQUIRE(h, rows > 0 && dim > 0, "bad shape");
   hipLaunchKernelGGL(layernorm_kernel, dim3(((int64_t)rows * 64 + 255) / 256), dim3(256), 0, rg_stream(stream), x, gamma,
                      beta, out, rows, dim, 1e-5f, reinterpret_cast<unsigned short*>(out_bf16));
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_layernorm_res(rg_handle* h, const float* x, const float* residual, const float* gamma, const float* beta,
+                                float* out, int rows, int dim, float eps, void* out_bf16, void* stream) {
+  RG_REQUIRE(h, x && gamma && beta && out, "null pointer");
+  RG_REQUIRE(h, rows > 0 && dim > 0 && eps >= 0.f, "bad shape");
+  hipLaunchKernelGGL(layernorm_res_kernel, dim3(((int64_t)rows * 64 + 255) / 256), dim3(256), 0, rg_stream(stream), x, residual,
+                     gamma, beta, out, rows, dim, eps, reinterpret_cast<unsigned short*>(out_bf16));
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }
