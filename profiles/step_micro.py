@@ -9,7 +9,10 @@ W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, sch,
 STEPS = 10
 ENGINES = sys.argv[1:] or ["chain", "stages", "persistent"]
 for B, engine in [(b, e) for b in (8, 16, 24, 48) for e in ENGINES]:
-    sess = rg.denoiser.DenoiserSession(W, B, engine=engine, ln_mode="folded")
+    kw = {}
+    if engine.startswith("chain+"):      # chain variants: e.g. chain+tile64 (64x64 GEMM tiles for the N = 512 launches at every M)
+        kw = dict(tile64="force") if "tile64" in engine else {}
+    sess = rg.denoiser.DenoiserSession(W, B, engine=engine.split("+")[0], ln_mode="folded", **kw)
     d = rg.synth.synth_batch(B, seed=1)
     mask = torch.ones(B, 43)
     mask[:, [10, 21, 32]] = 0

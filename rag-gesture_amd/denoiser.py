@@ -258,7 +258,7 @@ class DenoiserSession:
         # fixed part of these launches, not the K loop, decides -- off unless tile64=True
         self.tn = 0
         if self.xa_bf is not None and tile64 and D % 64 == 0 and \
-                ((M + 63) // 64) * (D // 64) <= w.h.lib.rg_num_cus(w.h._h):
+                (tile64 == "force" or ((M + 63) // 64) * (D // 64) <= w.h.lib.rg_num_cus(w.h._h)):
             self.tn = 64
             self.st_b, self.st_f = self._st_b, self._st_f
         ng = D // 128

@@ -48,10 +48,12 @@ def ddim_reverse_sample_loop(sess, x, out):
     """DDIM inversion of x [B,T,D] (clean -> noise); out [S,B,T,D] receives every level
     (out[k] = latent at alphas_cumprod_next[k]), x is updated in place to out[S-1]."""
     sch = sess.w.schedule
+    cur = x
     for i in range(sch.num_timesteps):
-        sess.forward(x, i)
-        sess.cfg_ddim(x, x, i, sch.c_next_a[i], sch.c_next_b[i])
-        out[i].copy_(x)
+        sess.forward(cur, i)
+        sess.cfg_ddim(cur, out[i], i, sch.c_next_a[i], sch.c_next_b[i])   # the update writes level i in place of a copy
+        cur = out[i]
+    x.copy_(cur)
     return out
 
 
