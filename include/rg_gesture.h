@@ -125,7 +125,12 @@ typedef struct rg_a_segment {
 
 typedef struct rg_gemm_desc {
   int M, N, K;
-  int a_is_bf16;          // 1: A is bf16 [M, lda]; 0: A is built from fp32 segments
+  int a_is_bf16;          // 1: A is bf16 [M, lda] (nseg = 0; or nseg = 1 with seg[0].mode = RG_A_STYL: the rows are the
+                          //    bf16 copy of a block output y and the operand is SiLU((y - mean) * rstd * gain + offset):
+                          //    the StylizationBlock front half with gain = gamma (1 + scale), offset = beta (1 + scale)
+                          //    + shift folded by the caller into seg[0].gamma / .beta (16-byte aligned, K floats each;
+                          //    .scale_shift NULL, .src unused) and mean / rstd from seg[0].stats; applied once per
+                          //    element in LDS by the LDS-DMA kernel: K <= 512, K % 64 == 0); 0: fp32 segments
   const void* A;          // bf16 A (a_is_bf16)
   int lda;
   int a_row_mod;          // >0: A row index = row % a_row_mod (row-duplicating GEMMs)
@@ -204,10 +209,11 @@ int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* 
  * LayerNorm statistics stats[R*T][D/128][2] (sum, sumsq over each 128-column head group).
  * perm (device, nperm ints, or NULL): launch order -> work item (row * D/128 + head group, -1 = idle
  * block); lets the caller place a row group on the XCD whose L2 already holds its rows.
- * use_mfma = 1: P^T V and Q A on the matrix cores (bf16 hi + lo operand pairs, fp32 accumulate: the bf16
- * production path); 0: exact fp32 VALU products (precision = "fp32"). */
-int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
-                    float* stats, int R, int T, int D, const int* perm, int nperm, int use_mfma, void* stream);
+ * mode 1: P^T V and Q A on the matrix cores (bf16 hi + lo operand pairs, fp32 accumulate: the bf16
+ * production path); 0: exact fp32 VALU products (precision = "fp32"); 2: as 1 and y leaves as bf16 [R*T, ldy]
+ * (T <= 48): the A operand of the SA-out GEMM, which applies the stylization in LDS (rg_gemm_desc.seg). */
+int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, void* y, int ldy,
+                    float* stats, int R, int T, int D, const int* perm, int nperm, int mode, void* stream);
 
 /* rg_sa_attention (matrix-core form) + the stylization front half of the self-attention block
  * (efficient_attention.py:32-46, stylization_block.py:30-47) in one launch, one 16-wave workgroup per batch row:

@@ -21,6 +21,8 @@ model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
 model.eval()
 if "LANES" in os.environ:
     model.lanes = int(os.environ["LANES"])
+if "SAMPLE_LANES" in os.environ:
+    model.sample_lanes = int(os.environ["SAMPLE_LANES"])
 data = rg.synth.synth_batch(B, seed=1234, device=dev)
 qs = [rg.synth.synth_query(i) for i in range(B)]
 data["discourse"] = [q["discourse"] for q in qs]

@@ -1,0 +1,29 @@
+"""A/B of the schedule knobs on the guided B = 16 workload (bench.py's Workload, graph-replayed steps): clip lanes of the
+exemplar inversion, clip lanes of the sampling loops, stylization inside the GEMMs.  ms per step, median of 5."""
+import importlib, os, statistics, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+bench.torch = torch
+rg = importlib.import_module("rag-gesture_amd")
+dev = torch.device("cuda", 0)
+bench.Workload.database_index = lambda self: self.model.model.database.index
+wl = bench.Workload(rg, "guided", 16, dev, 0, 32768)
+db = wl.database
+CASES = [dict(lanes=2, sample_lanes=None), dict(lanes=2, sample_lanes=1), dict(lanes=1, sample_lanes=None),
+         dict(lanes=3, sample_lanes=1), dict(lanes=2, sample_lanes=None, styl=True), dict(lanes=2, sample_lanes=1, styl=True)]
+for case in CASES:
+    m = wl.model
+    m.lanes, m.sample_lanes = case["lanes"], case["sample_lanes"]
+    m.session_options = dict(m.session_options or {}, styl_in_gemm=bool(case.get("styl")))
+    m._sessions.clear(); m._graphs.clear()
+    for _ in range(2):
+        wl.step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):       # like bench.py: 5 steps back to back, one synchronisation at the end
+        t0 = time.perf_counter()
+        for _ in range(5):
+            wl.step()
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3 / 5)
+    print(case, "%.1f ms per step (min %.1f)" % (statistics.median(ts), min(ts)), flush=True)

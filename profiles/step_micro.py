@@ -6,13 +6,20 @@ rg = importlib.import_module("rag-gesture_amd")
 cfg = rg.synth.default_model_cfg(num_layers=8)
 sch = rg.schedule.Schedule()
 W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, sch, "cuda")
-STEPS = 10
-ENGINES = sys.argv[1:] or ["chain", "stages", "persistent"]
-for B, engine in [(b, e) for b in (8, 16, 24, 48) for e in ENGINES]:
+STEPS = int(os.environ.get("STEPS", "10"))       # forward steps per captured graph
+LN_MODE = os.environ.get("LN_MODE", "folded")
+BS = (8, 16, 24, 48)
+argv = sys.argv[1:]
+if argv and argv[0].startswith("--B="):          # e.g. --B=16,48
+    BS, argv = tuple(int(v) for v in argv[0][4:].split(",")), argv[1:]
+ENGINES = argv or ["chain", "stages", "persistent"]
+for B, engine in [(b, e) for b in BS for e in ENGINES]:
     kw = {}
     if engine.startswith("chain+"):      # chain variants: e.g. chain+tile64 (64x64 GEMM tiles for the N = 512 launches at every M)
         kw = dict(tile64="force") if "tile64" in engine else {}
-    sess = rg.denoiser.DenoiserSession(W, B, engine=engine.split("+")[0], ln_mode="folded", **kw)
+        if "stylgemm" in engine:         # chain+stylgemm: the stylization passes inside the SA-out / FFN-out GEMMs
+            kw["styl_in_gemm"] = True
+    sess = rg.denoiser.DenoiserSession(W, B, engine=engine.split("+")[0], ln_mode=LN_MODE, **kw)
     d = rg.synth.synth_batch(B, seed=1)
     mask = torch.ones(B, 43)
     mask[:, [10, 21, 32]] = 0
@@ -36,4 +43,5 @@ for B, engine in [(b, e) for b in (8, 16, 24, 48) for e in ENGINES]:
             e0.record(); g.replay(); e1.record()
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) * 1e3 / STEPS)
-    print("B=%2d (M=%4d) %-10s: %.1f us per forward step" % (B, 2 * B * 43, engine, best), flush=True)
+    print("B=%2d (M=%4d) %-10s: %.1f us per forward step  (graph of %d steps, ln_mode %s -> %s, ratio %s)"
+          % (B, 2 * B * 43, engine, best, STEPS, LN_MODE, sess.ln_mode, sess.ln_ratio), flush=True)

@@ -92,7 +92,9 @@ __device__ unsigned long long* g_stamp_buf3 = nullptr;
 #endif
 
 // TCAP = token capacity of the softmax's register column (48 or 64): T = 43 needs 24 values per lane, not 32
-template <bool MFMA_, int TCAP = TMAX>
+// YBF: y leaves as bf16 (the A operand of the SA-out GEMM, which stylizes it in LDS); the statistics are those of the
+// fp32 values
+template <bool MFMA_, int TCAP = TMAX, bool YBF = false>
 __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __restrict__ qkv, int ldqkv, int D,
                                                           const float* __restrict__ src_mask, float* __restrict__ y,
                                                           int ldy, float* __restrict__ stats, int T,
@@ -282,12 +284,25 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
     RG_STAMP3(7);
     // coalesced y store (8 rows x 128 B per wave-instruction) and per-token statistics from the tile
     {
+      if constexpr (YBF) {   // 16 rows x 64 B per wave-instruction
+        unsigned short* yout = reinterpret_cast<unsigned short*>(y) + (size_t)b * T * ldy + h * HD;
+        for (int r0 = 0; r0 < T; r0 += 16) {
+          const int r = r0 + (lane >> 2);
+          if (r < T) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(sq + r * HD + (lane & 3) * 8);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(sq + r * HD + (lane & 3) * 8 + 4);
+            *reinterpret_cast<u32x4*>(yout + (size_t)r * ldy + (lane & 3) * 8) =
+                u32x4{pk(x0[0], x0[1]), pk(x0[2], x0[3]), pk(x1[0], x1[1]), pk(x1[2], x1[3])};
+          }
+        }
+      } else {
       float* yout = y + (size_t)b * T * ldy + h * HD;
       for (int r0 = 0; r0 < T; r0 += 8) {
         const int r = r0 + (lane >> 3);
         if (r < T)
           *reinterpret_cast<f32x4*>(yout + (size_t)r * ldy + (lane & 7) * 4) =
               *reinterpret_cast<const f32x4*>(sq + r * HD + (lane & 7) * 4);
+      }
       }
       float* mystat = sstat + wave * 2 * Tp;
       if (lane < T) {
@@ -1201,17 +1216,24 @@ extern "C" int rg_debug_set_stamp_buffer3(void* dev_ptr) {
 }
 #endif
 
-extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, float* y, int ldy,
-                               float* stats, int R, int T, int D, const int* perm, int nperm, int use_mfma,
+extern "C" int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, void* y_out, int ldy,
+                               float* stats, int R, int T, int D, const int* perm, int nperm, int mode,
                                void* stream) {
+  float* y = reinterpret_cast<float*>(y_out);
+  const bool use_mfma = mode != 0;
   RG_REQUIRE(h, qkv && src_mask && y && stats, "null pointer");
+  RG_REQUIRE(h, mode >= 0 && mode <= 2, "mode: 0 fp32 VALU, 1 matrix cores, 2 matrix cores with a bf16 y");
+  RG_REQUIRE(h, mode != 2 || (T <= 48 && ldy % 8 == 0), "bf16 y: T <= 48 and ldy % 8 == 0");
   RG_REQUIRE(h, T >= 33 && T <= TMAX && D % (HD * WAVES) == 0 && ldqkv % 4 == 0 && R > 0, "bad shape (33 <= T <= 64)");
   const int Tp = (T + 7) & ~7;
   const size_t lds = (WAVES * 2 * Tp + Tp + WAVES * (3 * Tp * HD)) * sizeof(float);
   RG_REQUIRE(h, !perm || nperm >= R * (D / (HD * WAVES)), "perm shorter than the work list");
   RG_REQUIRE(h, !use_mfma || (ldy % 4 == 0), "ldy must be a multiple of 4 floats");
   const dim3 grid(perm ? nperm : R * (D / (HD * WAVES)));
-  if (use_mfma && T <= 48)
+  if (mode == 2)
+    hipLaunchKernelGGL((sa_attention_kernel<true, 48, true>), grid, dim3(256), lds, rg_stream(stream), qkv, ldqkv, D, src_mask,
+                       y, ldy, stats, T, perm);
+  else if (use_mfma && T <= 48)
     hipLaunchKernelGGL((sa_attention_kernel<true, 48>), grid, dim3(256), lds, rg_stream(stream), qkv, ldqkv, D, src_mask, y,
                        ldy, stats, T, perm);
   else if (use_mfma)

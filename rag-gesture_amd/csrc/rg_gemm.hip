@@ -415,6 +415,16 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   RG_REQUIRE(h, d->softmax_cols % 32 == 0, "softmax_cols must be a multiple of 32");
   if (d->a_is_bf16) {
     RG_REQUIRE(h, d->A != nullptr && (d->lda % 8) == 0, "bf16 A must have lda % 8 == 0");
+    if (d->nseg != 0) {   // stylized bf16 A: seg[0] carries the LayerNorm statistics and parameters (header)
+      RG_REQUIRE(h, rg_gemm_a_styl(d), "bf16 A takes nseg = 0, or nseg = 1 with a RG_A_STYL segment");
+      const rg_a_segment& sg = d->seg[0];
+      RG_REQUIRE(h, sg.stats && sg.gamma && sg.beta && !sg.scale_shift && sg.nparts > 0 && sg.nparts <= RG_MAX_LN_PARTS &&
+                        ((uintptr_t)sg.gamma % 16) == 0 && ((uintptr_t)sg.beta % 16) == 0,
+                 "stylized A needs stats (<= 8 partials per row) and 16-byte aligned folded gain / offset vectors");
+      RG_REQUIRE(h, d->K <= SEG_MAX && d->K % 64 == 0 && d->a_row_mod == 0 && d->gb_group == 0 && d->tile_n != 64 &&
+                        !d->W_lo && rg_gemm_dma_eligible(d),
+                 "stylized A: K <= 512, K % 64 == 0, 16-byte aligned rows, default tiles");
+    }
   } else {
     RG_REQUIRE(h, (d->nseg >= 1 && d->nseg <= RG_MAX_SEG && d->seg_len > 0 && d->seg_len % 64 == 0) ||
                       (d->nseg == 1 && d->seg_len >= d->K),
@@ -424,6 +434,7 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
       RG_REQUIRE(h, d->seg[s].src != nullptr, "null segment source");
       if (d->seg[s].mode != RG_A_IDENT)
         RG_REQUIRE(h, d->seg[s].stats && d->seg[s].gamma && d->seg[s].beta && d->seg[s].nparts > 0 &&
+                          d->seg[s].nparts <= RG_MAX_LN_PARTS &&
                           d->seg_len % 8 == 0 && d->K % 8 == 0 && d->seg_len <= SEG_MAX,
                    "LN/STYL segment needs stats, gamma, beta and seg_len <= 512");
       if (d->seg[s].mode == RG_A_STYL) RG_REQUIRE(h, d->seg[s].scale_shift, "STYL segment needs scale_shift");

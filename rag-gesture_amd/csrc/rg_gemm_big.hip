@@ -152,7 +152,7 @@ void big_launch(const rg_gemm_desc* d, hipStream_t s) {
 }  // namespace
 
 bool rg_gemm_big_eligible(const rg_gemm_desc* d) {
-  return d->a_is_bf16 && !d->W_lo && d->K % 64 == 0 && d->K >= 128 && (d->lda % 8) == 0 && ((uintptr_t)d->A % 16) == 0 &&
+  return d->a_is_bf16 && !rg_gemm_a_styl(d) && !d->W_lo && d->K % 64 == 0 && d->K >= 128 && (d->lda % 8) == 0 && ((uintptr_t)d->A % 16) == 0 &&
          (d->gb_group == 0 || (d->gb_stride % 8 == 0 && d->gb_group % 256 == 0));
 }
 

@@ -65,8 +65,15 @@ __device__ __forceinline__ void wait_tiles(int younger) {
 // BN_ = tile width: 128, or 64 for single-round N = 512 GEMMs at small M.  There a workgroup is alone on its CU
 // and pulls its weight panel from the Infinity Cache at the per-CU rate (~33 GB/s: every XCD sees a panel once,
 // L2 reuse is nil at 1-2 M-tiles per XCD); 64-wide tiles put twice as many CUs on the same bytes.
-template <bool A_BF16, bool SPLIT, int NS, int NW, int BN_ = BN>
+// STYL (bf16 A only; p.seg[0] carries stats / gamma / beta / scale_shift, K <= SEG_MAX): the A rows are the bf16 copy of a
+// block output y and the operand is SiLU(LN(y) * (1 + scale) + shift) (StylizationBlock front half).  A landed K-tile
+// is rewritten in place in LDS, ONCE per element by the whole workgroup (8 values per thread and K-tile), one tile ahead
+// of the MFMAs and between the same two barriers -- instead of a separate elementwise launch in front of the GEMM
+// (4.9 us per launch at M = 1376) or of the fragment-read prologue of the fp32-A kernel, which redoes the two
+// transcendentals in every wave column (x4) and fetches fp32 rows.
+template <bool A_BF16, bool SPLIT, int NS, int NW, int BN_ = BN, bool STYL = false>
 __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p) {
+  static_assert(!STYL || (A_BF16 && !SPLIT && NS >= 3), "STYL: bf16 A, one weight plane, ring of >= 3");
   constexpr int NTH = NW * 64;
   constexpr int WN = NW / 2;            // waves along N (2 along M)
   constexpr int TN = (BN_ / WN) / 16;   // 16-column MFMA tiles per wave: 4 (NW=4) or 2 (NW=8) at BN_ = 128
@@ -79,7 +86,11 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
   constexpr int STAGE = A_STAGE + W_PLANES * W_TILE_;
   constexpr int ACH = A_BF16 ? (NW == 4 ? 2 : 1) : CPW;        // A chunks per wave
   constexpr int PER_TILE = ACH + CPW_W * W_PLANES;                 // DMA instructions per wave per K-tile
-  float* sPar = reinterpret_cast<float*>(smem + NS * STAGE);     // [nseg][4][SEG_MAX]
+  // behind the ring: sStat [BM][parts][2] = the partial (sum, sumsq) row statistics of this tile's rows (folded
+  // LayerNorm of the epilogue, or the STYL pass), DMA'd like the operand tiles; then the per-variant tables
+  const int st_parts = dma_stat_parts(p);
+  float* sStat = reinterpret_cast<float*>(smem + NS * STAGE);
+  float* sPar = sStat + BM * 2 * st_parts;                       // [nseg][4][SEG_MAX]
   float* sRow = sPar + (A_BF16 ? 0 : p.nseg) * 4 * SEG_MAX;      // [RG_MAX_SEG][64][2] = (rstd, -mean*rstd)
   SegInfo* sSeg = reinterpret_cast<SegInfo*>(sRow + RG_MAX_SEG * BM * 2);
 
@@ -166,6 +177,29 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
   // latency overlaps the table setup and the K loop instead of adding to it
   ResidualPrefetch pre;
   if (tid < NT) prefetch_residual(p, tid, m0, n0, pre, BN_);
+  // Row statistics and (STYL) the folded gain / offset vectors go into LDS by DMA as well, IN FRONT of the operand
+  // tiles in every wave's queue: the counted waits below then cover them, and no register-destination load (whose
+  // first use the compiler would wait for with vmcnt(0), draining the ring's prefetch) is involved.
+  //   sStat: 2 * parts wave-instructions of 64 floats (4 B per lane; rows clamped into the matrix)
+  //   sGB  : [2][SEG_MAX] gain, offset: K / 256 wave-instructions of 16 B per lane each
+  float* sGB = sPar;
+  {
+    const float* stat_src = STYL ? p.seg[0].stats : p.ln_stats;
+    const int n_stat = 2 * st_parts;                       // instructions
+    const int n_vec = STYL ? (p.K + 255) / 256 : 0;        // per vector
+    for (int i = wave; i < n_stat + 2 * n_vec; i += NW) {
+      if (i < n_stat) {
+        const int f = i * 64 + lane, row = f / (2 * st_parts), w = f - row * 2 * st_parts;
+        const int gr = min(m0 + row, p.M - 1);
+        __builtin_amdgcn_global_load_lds((const void*)(stat_src + (size_t)gr * 2 * st_parts + w), (lds_void*)(sStat + i * 64), 4, 0,
+                                         0);
+      } else if constexpr (STYL) {
+        const int v = (i - n_stat) / n_vec, piece = (i - n_stat) % n_vec;
+        const float* src = (v == 0 ? p.seg[0].gamma : p.seg[0].beta) + min(piece * 256 + lane * 4, p.K - 4);
+        __builtin_amdgcn_global_load_lds((const void*)src, (lds_void*)(sGB + v * SEG_MAX + piece * 256), 16, 0, 0);
+      }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NS - 1; ++t)
     if (t < nk) issue(t, true);
@@ -193,17 +227,9 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
           }
         }
         if (tid < BM) {
-          const float* sp = sg.stats + (size_t)a_row(tid) * sg.nparts * 2;
-          float su = 0.f, sq = 0.f;
-          for (int q = 0; q < sg.nparts; ++q) {
-            su += sp[2 * q];
-            sq += sp[2 * q + 1];
-          }
-          const float inv = 1.0f / (float)p.seg_len;
-          const float mu = su * inv;
-          float var = sq * inv - mu * mu;
-          var = var < 0.f ? 0.f : var;
-          const float rs = rsqrtf(var + 1e-5f);
+          float raw[2 * RG_MAX_LN_PARTS], mu, rs;
+          load_row_stats(sg.stats + (size_t)a_row(tid) * sg.nparts * 2, sg.nparts, raw);
+          reduce_row_stats(raw, sg.nparts, p.seg_len, mu, rs);
           sRow[(s * BM + tid) * 2] = rs;
           sRow[(s * BM + tid) * 2 + 1] = -mu * rs;
         }
@@ -316,11 +342,59 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
     }
   };
 
+  // STYL: the A K-tile `kt` (8 KiB: 512 chunks of 16 B; chunk c = row c >> 3, physical slot c & 7, which holds the
+  // logical 8-column group slot ^ ((row >> 1) & 7)) rewritten in place.  A thread owns the same chunk(s) of every
+  // K-tile, i.e. the same row(s): their (mean, rstd) live in its registers.
+  constexpr int CH = (BM * 8) / NTH;     // chunks per thread and K-tile: 1 (8 waves) or 2 (4 waves)
+  float row_mu[CH], row_rs[CH];
+  auto transform = [&](int kt) {
+    unsigned char* st = smem + (kt % NS) * STAGE;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int c = tid + j * NTH;
+      const int row = c >> 3;
+      const int k = kt * BK + (((c & 7) ^ ((row >> 1) & 7)) << 3);
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(st + c * 16);
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(sGB + k), g1 = *reinterpret_cast<const f32x4*>(sGB + k + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(sGB + SEG_MAX + k);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(sGB + SEG_MAX + k + 4);
+      const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+      const float b[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = __uint_as_float(raw[e] << 16);
+        v[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = silu_f(fmaf((v[e] - row_mu[j]) * row_rs[j], g[e], b[e]));
+      *reinterpret_cast<u32x4*>(st + c * 16) = u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    }
+  };
+
+  if constexpr (STYL) {
+    // Iteration t: [this wave's pieces of tile t+1 landed, its rewrite of tile t written] -> barrier -> issue tile
+    // t+NS-1 into stage (t-1) % NS -> rewrite tile t+1, MFMAs of tile t (different stages).
+    RG_STAMP(1);
+    wait_tiles<PER_TILE, NS - 2>(min(NS - 2, nk - 1));
+    __builtin_amdgcn_s_barrier();          // statistics, gain / offset and everyone's pieces of tile 0 have landed
+#pragma unroll
+    for (int j = 0; j < CH; ++j) lds_row_stats(sStat + ((tid + j * NTH) >> 3) * 2 * st_parts, st_parts, p.K, row_mu[j], row_rs[j]);
+    transform(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) wait_tiles<PER_TILE, NS - 3>(min(NS - 3, nk - 2 - kt));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + NS - 1 < nk) issue(kt + NS - 1, false);
+      if (kt + 1 < nk) transform(kt + 1);
+      compute(kt);
+    }
+  }
   // ---- ring pipeline.  Iteration t: [wait until this wave's pieces of tile t have landed]
   //      -> barrier (everyone's pieces landed; everyone is done reading stage (t-1) % NS)
   //      -> issue tile t+NS-1 into stage (t-1) % NS -> MFMAs of tile t.
   RG_STAMP(1);
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; !STYL && kt < nk; ++kt) {
     const int younger = min(NS - 2, nk - 1 - kt);   // tiles issued after tile kt and still in flight
     wait_tiles<PER_TILE, NS - 2>(younger);
     __builtin_amdgcn_s_barrier();
@@ -346,18 +420,20 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
         sC[(wr * 32 + i * 16 + fq * 4 + e) * SC_LD + wc * (TN * 16) + j * 16 + frow] = acc[i][j][e];
   __syncthreads();
   RG_STAMP(61);
-  if (tid < NT) epilogue(p, sC, tid, m0, n0, tile_n, nt, &pre, BN_);
+  if (tid < NT) epilogue(p, sC, tid, m0, n0, tile_n, nt, &pre, BN_, (!STYL && st_parts > 0) ? sStat : nullptr);
   RG_STAMP(62);
 }
 
 constexpr size_t LDS_MAX = 160 * 1024;
+// bytes of the row-statistics block behind the ring (bf16-A kernels: as many partials as the descriptor uses)
+size_t stat_bytes(const rg_gemm_desc* d) { return (size_t)BM * 2 * sizeof(float) * dma_stat_parts(*d); }
 
 template <bool A_BF16, bool SPLIT>
-size_t dma_lds_bytes(int nseg, int ns) {
+size_t dma_lds_bytes(int nseg, int ns, size_t LN_ROWS) {
   const size_t a_stage = A_BF16 ? A_TILE : 2 * A_TILE;
   const size_t stage = a_stage + (SPLIT ? 2 : 1) * W_TILE;
   const size_t tables = A_BF16 ? 0 : ((size_t)nseg * 4 * SEG_MAX * 4 + RG_MAX_SEG * BM * 2 * 4 + RG_MAX_SEG * sizeof(SegInfo));
-  return ns * stage + tables;
+  return ns * stage + LN_ROWS + tables;
 }
 
 template <bool A_BF16, bool SPLIT, int NS, int NW>
@@ -368,7 +444,7 @@ void dma_launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     attr = true;
   }
-  const size_t lds = dma_lds_bytes<A_BF16, SPLIT>(d->nseg, NS);
+  const size_t lds = dma_lds_bytes<A_BF16, SPLIT>(d->nseg, NS, stat_bytes(d));
   hipLaunchKernelGGL((gemm_dma_kernel<A_BF16, SPLIT, NS, NW>), grid, dim3(NW * 64), lds, s, *d);
 }
 
@@ -381,7 +457,7 @@ void dma_launch_narrow_ns(const rg_gemm_desc* d, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
     attr = true;
   }
-  size_t lds = (size_t)NS * (A_TILE + 64 * ROW_BYTES);
+  size_t lds = (size_t)NS * (A_TILE + 64 * ROW_BYTES) + stat_bytes(d);
   const size_t epi = (size_t)BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + 63) / 64;
@@ -395,18 +471,35 @@ void dma_launch_narrow_ns(const rg_gemm_desc* d, hipStream_t s) {
 // launch at most): neither the barrier count nor the cache level of the source sets the per-tile time.
 void dma_launch_narrow(const rg_gemm_desc* d, hipStream_t s) { dma_launch_narrow_ns<4>(d, s); }
 
+// bf16 A with the in-LDS stylization pass (p.seg[0]): a ring of 5 where one workgroup owns the CU (the rewrite runs one
+// tile ahead, so one stage less is in flight than the ring is deep), 3 stages + tables = 76.5 KiB where two share it
+template <int NS, int NW>
+void dma_launch_styl(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, NS, NW, BN, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    attr = true;
+  }
+  size_t lds = (size_t)NS * (A_TILE + W_TILE) + stat_bytes(d) + 2 * SEG_MAX * sizeof(float);
+  const size_t epi = (size_t)BM * SC_LD * sizeof(float);
+  if (epi > lds) lds = epi;
+  hipLaunchKernelGGL((gemm_dma_kernel<true, false, NS, NW, BN, true>), grid, dim3(NW * 64), lds, s, *d);
+}
+
 // ring depth for this descriptor (0: does not fit the 160 KiB LDS at all).  Grids with more
 // workgroups than CUs use a 2-stage ring (<= 80 KiB) so two workgroups share a CU and hide each
 // other's DMA latency; smaller grids are a pure latency chain and take the deepest ring that fits.
 int dma_depth(const rg_gemm_desc* d, int num_cus) {
   const int wgs = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
   if (!d->W_lo && wgs > num_cus) {
-    const size_t need2 = d->a_is_bf16 ? dma_lds_bytes<true, false>(0, 2) : dma_lds_bytes<false, false>(d->nseg, 2);
+    const size_t need2 = d->a_is_bf16 ? dma_lds_bytes<true, false>(0, 2, stat_bytes(d)) : dma_lds_bytes<false, false>(d->nseg, 2, stat_bytes(d));
     if (need2 <= LDS_MAX / 2) return 2;
   }
   for (int ns = (d->W_lo ? 3 : 4); ns >= 3; --ns) {
-    const size_t need = d->W_lo ? dma_lds_bytes<false, true>(d->nseg, ns)
-                                : (d->a_is_bf16 ? dma_lds_bytes<true, false>(0, ns) : dma_lds_bytes<false, false>(d->nseg, ns));
+    const size_t need = d->W_lo ? dma_lds_bytes<false, true>(d->nseg, ns, stat_bytes(d))
+                                : (d->a_is_bf16 ? dma_lds_bytes<true, false>(0, ns, stat_bytes(d))
+                                                : dma_lds_bytes<false, false>(d->nseg, ns, stat_bytes(d)));
     if (need <= LDS_MAX) return ns;
   }
   return 0;
@@ -433,8 +526,13 @@ void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, int waves, void* str
   }
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + BN - 1) / BN;
   dim3 grid(mt * nt);
-  const int ns = dma_depth(d, num_cus);
   hipStream_t s = rg_stream(stream);
+  if (rg_gemm_a_styl(d)) {
+    if ((int)grid.x <= num_cus) dma_launch_styl<5, 8>(d, grid, s);
+    else dma_launch_styl<3, 4>(d, grid, s);
+    return;
+  }
+  const int ns = dma_depth(d, num_cus);
   // measured (MI355X, graph-replayed): 8 waves win ~7% on single-round grids with plain or bf16 A
   // (7.8 vs 8.4 us at 2752x512x512); with the LN/stylization prologue or multi-round grids the
   // extra per-wave prologue math / lower workgroup residency loses 15-50%

@@ -48,6 +48,9 @@ __device__ __forceinline__ float gelu_fast(float v) {
   return 0.5f * v + 0.5f * fabsf(v) * e;
 }
 
+// bf16 A whose rows are stylized inside the LDS-DMA kernel (see rg_gemm_desc.seg in the header)
+inline bool rg_gemm_a_styl(const rg_gemm_desc* d) { return d->a_is_bf16 && d->nseg == 1 && d->seg[0].mode == RG_A_STYL; }
+
 struct SegInfo {      // LDS copy of one rg_a_segment (dynamic indexing of kernargs would go to scratch)
   const float* src;
   int ld, mode;
@@ -66,10 +69,68 @@ __device__ __forceinline__ void tile_of_block(int bid, int mt, int nt, int& tile
 // Every thread owns 32 consecutive columns of one row of sC (= one attention head).
 // Residual values of this thread's 32 outputs, optionally loaded before the K loop so that their
 // (cold) latency is hidden under the main loop instead of being exposed in the epilogue.
+constexpr int RG_MAX_LN_PARTS = 8;   // partial (sum, sumsq) pairs per row a kernel requests in one batch
+
 struct ResidualPrefetch {
   bool valid = false;
   float r[32];
 };
+
+// All partial (sum, sumsq) pairs of one row in ONE batch of independent loads (a loop over a runtime count compiles to
+// one load + s_waitcnt per pair: nparts dependent round trips of ~1-2 us each).  nparts <= RG_MAX_LN_PARTS.
+__device__ __forceinline__ void load_row_stats(const float* sp, int nparts, float (&raw)[2 * RG_MAX_LN_PARTS]) {
+  // unconditional loads (index clamped into the row's partials, surplus values deselected afterwards): a guarded load
+  // would put every request into a basic block of its own, with its own s_waitcnt
+#pragma unroll
+  for (int q = 0; q < RG_MAX_LN_PARTS; ++q) {
+    const float2 t = *reinterpret_cast<const float2*>(sp + 2 * (q < nparts ? q : nparts - 1));
+    raw[2 * q] = t.x;
+    raw[2 * q + 1] = t.y;
+  }
+}
+// (sum, sumsq) partials of one row in LDS -> (mean, rstd)
+__device__ __forceinline__ void lds_row_stats(const float* sp, int nparts, int K, float& mu, float& rs) {
+  float su = 0.f, sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < RG_MAX_LN_PARTS; ++q) {
+    const float2 t = *reinterpret_cast<const float2*>(sp + 2 * (q < nparts ? q : nparts - 1));
+    su += q < nparts ? t.x : 0.f;
+    sq += q < nparts ? t.y : 0.f;
+  }
+  const float inv = 1.0f / (float)K;
+  mu = su * inv;
+  float var = sq * inv - mu * mu;
+  var = var < 0.f ? 0.f : var;
+  rs = rsqrtf(var + 1e-5f);
+}
+
+// statistics partials per row that the LDS-DMA kernel stages for a descriptor with a bf16 A operand
+__host__ __device__ inline int dma_stat_parts(const rg_gemm_desc& d) {
+  if (d.a_is_bf16 && d.nseg == 1 && d.seg[0].mode == RG_A_STYL) return d.seg[0].nparts;
+  return (d.ln_stats && d.ln_nparts <= RG_MAX_LN_PARTS) ? d.ln_nparts : 0;
+}
+
+// Pin a loaded value to this point of the program: the compiler otherwise hoists its first arithmetic use up to the
+// load (and waits for the round trip there, in front of everything issued afterwards).
+__device__ __forceinline__ void use_here(float& x) { asm volatile("" : "+v"(x)); }
+
+// (the deselection lives here, not next to the loads: the first use of a loaded value is where the compiler waits)
+__device__ __forceinline__ void reduce_row_stats(float (&raw)[2 * RG_MAX_LN_PARTS], int nparts, int K, float& mu,
+                                                 float& rs) {
+#pragma unroll
+  for (int q = 0; q < 2 * RG_MAX_LN_PARTS; ++q) use_here(raw[q]);
+  float su = 0.f, sq = 0.f;
+#pragma unroll
+  for (int q = 0; q < RG_MAX_LN_PARTS; ++q) {
+    su += q < nparts ? raw[2 * q] : 0.f;
+    sq += q < nparts ? raw[2 * q + 1] : 0.f;
+  }
+  const float inv = 1.0f / (float)K;
+  mu = su * inv;
+  float var = sq * inv - mu * mu;
+  var = var < 0.f ? 0.f : var;
+  rs = rsqrtf(var + 1e-5f);
+}
 
 __device__ __forceinline__ void prefetch_residual(const rg_gemm_desc& p, int tid, int m0, int n0, ResidualPrefetch& pre,
                                                   int width = BN) {
@@ -88,8 +149,11 @@ __device__ __forceinline__ void prefetch_residual(const rg_gemm_desc& p, int tid
 
 // `width` = columns of sC that belong to this tile (128, or 64 for the narrow-tile kernel: the threads of the
 // upper two column groups then only take part in the shuffles); nt / tile_n count tiles of that width.
+// ln_row: null, or LDS [BM][ln_nparts][2]: the partial statistics of this tile's rows for the folded LayerNorm (the LDS-DMA
+// kernel fetches them with its operand tiles); otherwise they are fetched here, all partials of the row in one batch.
 __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC, int tid, int m0, int n0, int tile_n,
-                                         int nt, const ResidualPrefetch* pre = nullptr, int width = BN) {
+                                         int nt, const ResidualPrefetch* pre = nullptr, int width = BN,
+                                         const float* ln_row = nullptr) {
   const int erow = tid >> 2;           // 0..63
   const int ecol = (tid & 3) * 32;     // 0,32,64,96 : one 32-column head per thread
   const int grow = m0 + erow;
@@ -105,16 +169,25 @@ __device__ __forceinline__ void epilogue(const rg_gemm_desc& p, const float* sC,
   const bool full = (gcol + 32 <= Nlim);
   if (p.ln_stats) {   // LayerNorm of the A rows, folded: rstd * (acc - mean * c1[n]); the bias below carries beta
     const float* sp = p.ln_stats + (size_t)(row_ok ? grow : 0) * p.ln_nparts * 2;
-    float su = 0.f, sq = 0.f;
-    for (int q = 0; q < p.ln_nparts; ++q) {
-      su += sp[2 * q];
-      sq += sp[2 * q + 1];
+    float mu, rs;
+    if (ln_row) {
+      lds_row_stats(ln_row + erow * 2 * p.ln_nparts, p.ln_nparts, p.K, mu, rs);
+    } else if (p.ln_nparts <= RG_MAX_LN_PARTS) {
+      float raw[2 * RG_MAX_LN_PARTS];
+      load_row_stats(sp, p.ln_nparts, raw);
+      reduce_row_stats(raw, p.ln_nparts, p.K, mu, rs);
+    } else {
+      float su = 0.f, sq = 0.f;
+      for (int q = 0; q < p.ln_nparts; ++q) {
+        su += sp[2 * q];
+        sq += sp[2 * q + 1];
+      }
+      const float inv = 1.0f / (float)p.K;
+      mu = su * inv;
+      float var = sq * inv - mu * mu;
+      var = var < 0.f ? 0.f : var;
+      rs = rsqrtf(var + 1e-5f);
     }
-    const float inv = 1.0f / (float)p.K;
-    const float mu = su * inv;
-    float var = sq * inv - mu * mu;
-    var = var < 0.f ? 0.f : var;
-    const float rs = rsqrtf(var + 1e-5f);
     if (full) {   // whole 32-column group inside the matrix: eight 16-B loads instead of 32 guarded ones
 #pragma unroll
       for (int q = 0; q < 8; ++q) {

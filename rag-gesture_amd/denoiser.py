@@ -146,6 +146,16 @@ class DenoiserWeights:
                 q = "temporal_decoder_blocks.%d.%s.proj_out.emb_layers.1." % (l, blk)
                 self.h.call("linear_f32", emb, f32(g(q + "weight")), f32(g(q + "bias")), tmp, S, 2 * D, self.TE, 1, 0)
                 self.ss[:, l, bi].copy_(tmp)
+        # --- stylization folded per (step, layer) for the GEMMs that stylize their bf16 A rows in LDS (rg_gemm_desc.seg):
+        # gain = gamma (1 + scale), offset = beta (1 + scale) + shift; block 0 = self attention, 1 = FFN
+        if precision == "bf16":
+            self.styl_gain = torch.empty(S, L, 2, D, device=self.dev)
+            self.styl_off = torch.empty(S, L, 2, D, device=self.dev)
+            for l, lw in enumerate(self.layers):
+                for j, (bi, gk, bk) in enumerate(((0, "sa_sg", "sa_sb"), (4, "ff_sg", "ff_sb"))):
+                    sc1 = 1.0 + self.ss[:, l, bi, :D]
+                    self.styl_gain[:, l, j] = lw[gk] * sc1
+                    self.styl_off[:, l, j] = lw[bk] * sc1 + self.ss[:, l, bi, D:]
         # --- classifier-free rows (bf16 path): cross-attention output == value bias for every token
         # (cond_type 0), so its stylized bf16 form is a (step, layer, cond, masked?) table
         if precision == "bf16":
@@ -197,7 +207,7 @@ class DenoiserSession:
     DEFAULT_ENGINE = "chain"
 
     def __init__(self, weights, B, persistent=None, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False,
-                 xcd_affine=True, engine=None):
+                 xcd_affine=True, engine=None, styl_in_gemm=False):
         """persistent: run `forward` as ONE persistent dataflow launch (rg_denoiser_forward) instead of ~90 dependent
         launches (bf16 production path, D = 512, FF = 1024, T <= 48).  Parity-green, but measured SLOWER than the
         launch chain on MI355X (1244 vs 881 us per forward at M = 1376, 1864 vs 1437 us at M = 4128: every tile pays
@@ -206,6 +216,11 @@ class DenoiserSession:
         layer fewer; its bf16 operand is the UN-normalised row, so the error grows with |row mean| / std),
         "prologue" = LayerNorm in a pre-pass (exact for any offset), "auto" = folded unless the session's first
         forward finds rows more than LN_GUARD_SIGMAS standard deviations off centre (one read-back, once per session).
+        styl_in_gemm (bf16 launch chain): the stylization in front of the SA-out and FFN-out GEMMs (LN, scale/shift, SiLU)
+        runs inside those GEMMs, on the landed bf16 A tiles in LDS, instead of as two elementwise launches per layer.
+        Parity-green and measured SLOWER (907 vs 887 us per forward at M = 1376, 134.3 vs 131.7 ms per guided step): every
+        one of the 4 column-tile workgroups of a row tile redoes the two transcendentals per element, on a third of the
+        CUs the standalone pass spreads them over -- 16 launches fewer do not pay for it.  Off by default.
         styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain."""
         assert ln_mode in ("auto", "folded", "prologue")
         # engine: "chain" = one launch per op (~90 per forward), "stages" = the fused tiles of fwd.py, one launch per
@@ -247,6 +262,11 @@ class DenoiserSession:
                 # sampling 50.4 vs 48.1 ms, inversion equal), so it is off unless asked for
                 if sa_fused and D == 512:
                     self.v_sa = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+        self.styl_gemm = bool(styl_in_gemm and self.abf is not None and self.v_sa is None and D <= 512 and D % 64 == 0
+                              and T <= 48)
+        if self.styl_gemm:
+            self.y_sa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+            self.yf_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.qmask_c = torch.ones(3, B, T, device=dev)
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
@@ -366,6 +386,9 @@ class DenoiserSession:
         sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c     # sa_: written by the embed GEMM (128-wide tiles)
         sa_w = self._st_a if self.tn else self.st_a           # ... and by every FFN-out GEMM (self.tn-wide tiles)
         tn = self.tn
+        styl_gemm = self.styl_gemm
+        if styl_gemm:      # the stylizing GEMMs run 128-wide tiles: their statistics come in the 128-column split
+            sb_, sa_w = self._parts128(self._st_b), self.st_a
         # h = joint_embed(x) + positional tables, duplicated for the two CFG branches
         G.gemm(h, M=M, N=D, K=D, W=w.w_embed, out=xa, segs=[G.Seg(x.view(B * T, D))], seg_len=D, a_row_mod=B * T,
                bias=w.b_embed, tbias=w.tbias, tb_period=T, stats_out=sa_, out2=self.xa_bf)
@@ -397,6 +420,9 @@ class DenoiserSession:
             if fused_sa:
                 h.call("sa_stylize", self.qkv, 3 * D, self.v_sa, D, self.src_mask, lw["sa_sg"], lw["sa_sb"], ss[0], self.abf, D,
                        R, T, D, self.perm_sa1, self.perm_sa1.numel())
+            elif styl_gemm:
+                h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa_bf, D, self.st_sa, R, T, D,
+                       self.perm_sa, self.perm_sa.numel(), 2)
             else:
                 h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
                        self.perm_sa, self.perm_sa.numel(), 1 if w.precision == "bf16" else 0)
@@ -404,6 +430,11 @@ class DenoiserSession:
             if fused_sa:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
                        out2=self.hcat[:, 3 * D:], tile_n=tn)
+            elif styl_gemm:
+                # A = bf16 y; LN, scale/shift and SiLU once per element on the landed tiles in LDS (rg_gemm_desc.seg)
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.y_sa_bf, bias=lw["b_sao"], residual=xa,
+                       a_styl=G.Seg(None, mode=G.A_STYL, stats=self.st_sa, gamma=w.styl_gain[step, l, 0], beta=w.styl_off[step, l, 0]),
+                       stats_out=sb_, out2=self.hcat[:, 3 * D:])
             elif self.abf is not None:
                 # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
                 # pre-pass instead of once per column tile and wave pair inside the GEMM's A prologue
@@ -465,14 +496,23 @@ class DenoiserSession:
                 G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, A=self.abf, bias=lw["b_ff1"], act=1)
             else:
                 G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, segs=[G.Seg(xc)], seg_len=D, bias=lw["b_ff1"], act=1)
-            if w.precision == "bf16":
+            if styl_gemm:
+                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf_bf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f,
+                       tile_n=tn)
+            elif w.precision == "bf16":
                 G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f,
                        tile_n=tn)
             else:
                 G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, segs=[G.Seg(self.g)], seg_len=w.FF,
                        bias=lw["b_ff2"], stats_out=self.st_f)
             ff_seg = G.Seg(self.yf, mode=G.A_STYL, stats=self.st_f, gamma=lw["ff_sg"], beta=lw["ff_sb"], scale_shift=ss[4])
-            if self.abf is not None:
+            if styl_gemm:
+                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.yf_bf, bias=lw["b_ffo"], residual=xc,
+                       a_styl=G.Seg(None, mode=G.A_STYL, stats=self.st_f, gamma=w.styl_gain[step, l, 1], beta=w.styl_off[step, l, 1]),
+                       stats_out=sa_w, out2=self.xa_bf)
+                sa_ = sa_w
+                self._guard_stats(sa_)
+            elif self.abf is not None:
                 G.stylize(h, [ff_seg], D, M, self.abf)
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_w,
                        out2=self.xa_bf, tile_n=tn)

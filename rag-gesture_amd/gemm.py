@@ -70,19 +70,26 @@ class Seg:
     def __init__(self, src, ld=None, mode=A_IDENT, stats=None, gamma=None, beta=None, scale_shift=None,
                  col_offset=0):
         self.src, self.mode, self.stats, self.gamma, self.beta, self.ss = src, mode, stats, gamma, beta, scale_shift
-        self.ld = src.stride(-2) if ld is None else ld
+        self.ld = (src.stride(-2) if src is not None else 0) if ld is None else ld
         self.col_offset = col_offset
 
 
 def make_desc(*, M, N, K, W, out, A=None, segs=None, seg_len=None, bias=None, tbias=None, tb_period=0,
               residual=None, act=0, softmax_cols=0, stats_out=None, a_row_mod=0, gb_group=0, gb_stride=0,
-              ldo=None, ldr=None, out2=None, ln_stats=None, ln_c1=None, lda=None, split_col=0, tile_n=0):
+              ldo=None, ldr=None, out2=None, ln_stats=None, ln_c1=None, lda=None, split_col=0, tile_n=0, a_styl=None):
+    """a_styl: a Seg (src None; stats, gamma = gamma (1 + scale), beta = beta (1 + scale) + shift) that makes the kernel
+    stylize the bf16 rows of A in LDS: operand = SiLU((A - mean) * rstd * gamma + beta)."""
     d = GemmDesc()
     d.M, d.N, d.K = M, N, K
     if A is not None:
         d.a_is_bf16 = 1
         d.A = _p(A, torch.bfloat16)
         d.lda = A.stride(-2) if lda is None else lda
+        if a_styl is not None:
+            e = d.seg[0]
+            d.nseg, d.seg_len, e.mode = 1, K, A_STYL
+            e.stats, e.nparts = _p(a_styl.stats, torch.float32), a_styl.stats.shape[-2]
+            e.gamma, e.beta = _p(a_styl.gamma, torch.float32), _p(a_styl.beta, torch.float32)   # folded gain / offset
     else:
         d.a_is_bf16 = 0
         d.nseg = len(segs)

@@ -209,7 +209,7 @@ class MotionDiffusion(torch.nn.Module):
     def __init__(self, model=None, loss_recon=None, loss_gen=None, loss_contact=None, loss_laplace=None,
                  diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
-                 body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, session_options=None,
+                 body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
@@ -229,6 +229,7 @@ class MotionDiffusion(torch.nn.Module):
         self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
         self.profile_phases, self.phase_ms = False, {}
         self.lanes = int(lanes)
+        self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
@@ -405,8 +406,8 @@ class MotionDiffusion(torch.nn.Module):
                 chosen.append(c)
         return chosen  # fewer than n if the runtime offers fewer independent queues
 
-    def _lane_plan(self, B):
-        """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips."""
+    def _lane_plan(self, B, n_lanes=None):
+        """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips (n_lanes <= self.lanes of them)."""
         want = max(1, int(self.lanes))
         if self._lanes_calibrated != want:
             # `want` lane streams + one more for the retrieval search, all on hardware queues of their own (the
@@ -416,7 +417,7 @@ class MotionDiffusion(torch.nn.Module):
             if not self._lane_streams:
                 self._lane_streams = [torch.cuda.Stream(device=self.device)]
             self._lanes_calibrated = want
-        n = max(1, min(want, B, len(self._lane_streams)))
+        n = max(1, min(want if n_lanes is None else int(n_lanes), want, B, len(self._lane_streams)))
         cuts = [(B * i) // n for i in range(n + 1)]
         return [(i, self._lane_streams[i], cuts[i], cuts[i + 1]) for i in range(n)]
 
@@ -469,11 +470,12 @@ class MotionDiffusion(torch.nn.Module):
 
         # the conditioning projections (K/V of every layer) need the inputs only: they run on the lane streams
         # while the main stream encodes the motion
-        plan = self._lane_plan(B)
+        plan = self._lane_plan(B)                            # exemplar inversion
+        plan_s = self._lane_plan(B, self.sample_lanes)       # sampling loops
         main = torch.cuda.current_stream()
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
         with self._phase("conditions"):
-            for lane, stream, b0, b1 in plan:
+            for lane, stream, b0, b1 in plan_s:
                 stream.wait_stream(main)
                 with torch.cuda.stream(stream):
                     self._set_conditions(b1 - b0, "sample", lane, word[b0:b1], audio[b0:b1], spk[b0:b1],
@@ -590,7 +592,6 @@ class MotionDiffusion(torch.nn.Module):
         # ---- lanes: [exemplar inversion -> splice -> sampling] per clip group, concurrently
         for lane, stream, b0, b1 in plan:
             Bl = b1 - b0
-            sess = self._session(Bl, "sample", lane)
             stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 if use_inversion:
@@ -633,9 +634,15 @@ class MotionDiffusion(torch.nn.Module):
                             invl[:, b0:b1, idx[0], :] = 0
         # second pass: the sampling loops.  Every lane's inversion is queued before the first sampling graph is
         # launched (a graph launch costs the host ~1.5 ms: lane 1 would otherwise start 3 ms behind lane 0)
-        for lane, stream, b0, b1 in plan:
+        inverted = [(stream, stream.record_event()) for _, stream, _, _ in plan]
+        for lane, stream, b0, b1 in plan_s:
             Bl = b1 - b0
             sess = self._session(Bl, "sample", lane)
+            stream.wait_stream(main)
+            if plan_s != plan:                   # a sampling lane then reads rows spliced by several inversion lanes
+                for other, ev in inverted:
+                    if other is not stream:
+                        stream.wait_event(ev)
             with torch.cuda.stream(stream):
                 sl = lambda t, dim: None if t is None else (t[b0:b1] if dim == 0 else t[:, b0:b1])
                 loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(inseq_noise, 1), invl=sl(invl, 1))
@@ -653,7 +660,7 @@ class MotionDiffusion(torch.nn.Module):
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess: (sampler.ddim_sample_loop(
                             sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
                     x_out[b0:b1].copy_(xl)
-        for _, stream, _, _ in plan:
+        for _, stream, _, _ in plan + plan_s:
             main.wait_stream(stream)
         x = x_out
         output = self.model.post_process(x)
