@@ -9,15 +9,15 @@ rg = importlib.import_module("rag-gesture_amd")
 dev = torch.device("cuda", 0)
 wl = bench.Workload(rg, "guided", 16, dev, 0, 32768)
 m = wl.model
-m.sample_lanes = int(os.environ.get("SAMPLE_LANES", "1"))
+m.sample_lanes = int(os.environ["SAMPLE_LANES"]) if "SAMPLE_LANES" in os.environ else None
 for _ in range(5):
     wl.step()
 torch.cuda.synchronize()
 torch.zeros(7, device=dev).fill_(1.0)          # marker kernel (FillFunctor on 7 elements)
 torch.cuda.synchronize()
-key = [k for k in m._graphs if k[0] == "guided"][0]
-graph = m._graphs[key][0]
-for _ in range(3):
-    with torch.cuda.stream(m._lane_streams[0]):
-        graph.replay()
-    torch.cuda.synchronize()
+keys = [k for k in m._graphs if k[0] in os.environ.get("GRAPHS", "guided").split(",")]
+for key in keys[:1]:                       # one lane's graph alone
+    for _ in range(3):
+        with torch.cuda.stream(m._lane_streams[0]):
+            m._graphs[key][0].replay()
+        torch.cuda.synchronize()
