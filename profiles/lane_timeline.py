@@ -21,6 +21,7 @@ model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
 model.eval()
 if "LANES" in os.environ:
     model.lanes = int(os.environ["LANES"])
+model.async_results = bool(int(os.environ.get("PIPELINED", "0")))
 if "SAMPLE_LANES" in os.environ:
     model.sample_lanes = int(os.environ["SAMPLE_LANES"])
 data = rg.synth.synth_batch(B, seed=1234, device=dev)
@@ -36,17 +37,17 @@ t_step = [0.0]
 ev_step = [None]
 
 
-def traced(key, inputs, fn):
+def traced(key, inputs, fn, owner=None):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     h0 = time.perf_counter()
     e0.record()
-    out = orig(key, inputs, fn)
+    out = orig(key, inputs, fn, owner=owner)
     e1.record()
     log.append((key, (h0 - t_step[0]) * 1e3, (time.perf_counter() - t_step[0]) * 1e3, e0, e1))
     return out
 
 
-def one_step(trace=False):
+def one_step(trace=False, sync=True):
     d = dict(data)
     d["trans"] = trans0.clone()
     model.model.database.test_indexes.clear()
@@ -59,10 +60,13 @@ def one_step(trace=False):
         t_step[0] = time.perf_counter()
     out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
     t_host = (time.perf_counter() - t_step[0]) * 1e3
+    if not sync:
+        return t_host, None
     torch.cuda.synchronize()
     return t_host, (time.perf_counter() - t_step[0]) * 1e3
 
 
+one_step()
 one_step()
 one_step()
 model._graph_run = traced
@@ -71,5 +75,20 @@ for rep in range(2):
     t_host, t_all = one_step(trace=True)
     print("step: host returns from forward at %.1f ms, device done at %.1f ms (lanes=%d)" % (t_host, t_all, model.lanes))
     for key, h0, h1, e0, e1 in log:
+        print("   %-44s host call %6.1f -> %6.1f ms | device %6.1f -> %6.1f ms (%.1f)" % (
+            str(key)[:44], h0, h1, ev_step[0].elapsed_time(e0), ev_step[0].elapsed_time(e1), e0.elapsed_time(e1)))
+
+if os.environ.get("BACK_TO_BACK"):
+    # three steps without a synchronisation in between: where does step n + 1 start relative to step n's end?
+    one_step(trace=True, sync=False)
+    marks = [len(log)]
+    for _ in range(2):
+        one_step(sync=False)
+        marks.append(len(log))
+    torch.cuda.synchronize()
+    print("three steps back to back, all done at %.1f ms" % ((time.perf_counter() - t_step[0]) * 1e3))
+    for i, (key, h0, h1, e0, e1) in enumerate(log):
+        if i in marks:
+            print("   ---- next step")
         print("   %-44s host call %6.1f -> %6.1f ms | device %6.1f -> %6.1f ms (%.1f)" % (
             str(key)[:44], h0, h1, ev_step[0].elapsed_time(e0), ev_step[0].elapsed_time(e1), e0.elapsed_time(e1)))

@@ -10,16 +10,18 @@ dev = torch.device("cuda", 0)
 bench.Workload.database_index = lambda self: self.model.model.database.index
 wl = bench.Workload(rg, "guided", 16, dev, 0, 32768)
 db = wl.database
-CASES = [dict(lanes=2, sample_lanes=None), dict(lanes=2, sample_lanes=1), dict(lanes=1, sample_lanes=None),
-         dict(lanes=3, sample_lanes=1), dict(lanes=2, sample_lanes=None, styl=True), dict(lanes=2, sample_lanes=1, styl=True)]
+CASES = [dict(lanes=2, pipelined=False), dict(lanes=2, pipelined=True), dict(lanes=2, sample_lanes=1, pipelined=True),
+         dict(lanes=3, pipelined=True), dict(lanes=2, pipelined=True, inflight=3), dict(lanes=2, pipelined=False)]
 if len(sys.argv) > 1:
     CASES = [eval("dict(%s)" % a) for a in sys.argv[1:]]
 for case in CASES:
     m = wl.model
     m.lanes, m.sample_lanes = case["lanes"], case.get("sample_lanes")
     m.session_options = dict(m.session_options or {}, styl_in_gemm=bool(case.get("styl")))
+    m.async_results = bool(case.get("pipelined"))
+    m.max_inflight = int(case.get("inflight", 2))
     m._sessions.clear(); m._graphs.clear()
-    for _ in range(2):
+    for _ in range(3):
         wl.step()
     torch.cuda.synchronize()
     ts = []

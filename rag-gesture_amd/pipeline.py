@@ -203,6 +203,15 @@ class MotionDiffusion(torch.nn.Module):
       precision   "bf16" (production) | "fp32" (bf16x3 operands, parity checks)
       lanes       concurrent clip groups per forward, each on its own hardware queue (measured on MI355X: 2 lanes
                   149.7 vs 156 ms guided B=16, 71.3 vs 73.0 ms base B=32; 3-4 lanes no better)
+      async_results     False: forward() returns tensors that are valid on the caller's stream (the reference's semantics).
+                        True: forward() returns as soon as the batch is queued; `results["done_event"]` marks its completion
+                        (wait for it on the consuming stream, `wait_results(results)` does so on the current one; or queue
+                        the consumer on `results["done_stream"]`, which needs no wait).  The
+                        front end of the next batch (conditions, VAE encodes, retrieval: ~13 ms of a 131 ms guided step)
+                        and the decode of this one then run beside the dependent inversion -> sampling chain instead of in
+                        front of / behind it.  Batches alternate between `slots` sets of sessions and graph buffers so that
+                        a front end never writes what the chain in flight still reads; at most `max_inflight` batches
+                        are queued before forward() blocks on the oldest.
       session_options   keyword arguments of denoiser.DenoiserSession (ln_mode, persistent, ...)
       vae_options       keyword arguments of vae.GestureRepEncoder (part_streams, chain)"""
 
@@ -210,7 +219,7 @@ class MotionDiffusion(torch.nn.Module):
                  diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
-                 vae_options=None, **kwargs):
+                 vae_options=None, async_results=False, slots=2, max_inflight=2, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -230,6 +239,9 @@ class MotionDiffusion(torch.nn.Module):
         self.profile_phases, self.phase_ms = False, {}
         self.lanes = int(lanes)
         self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
+        # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
+        self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
+        self._slot, self._inflight, self._graph_owner = 0, collections.deque(), {}
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
@@ -274,10 +286,25 @@ class MotionDiffusion(torch.nn.Module):
             out[prefix + "model." + k] = v
         return out
 
-    def _graph_run(self, key, inputs, fn):
+    _RECORD = True
+
+    @staticmethod
+    def _used_on(stream, *tensors):
+        """The caching allocator must not hand a tensor's memory out again before `stream` (not the stream it was
+        allocated on) is done with it: every tensor that crosses streams is marked, so that freeing it on the host while a
+        lane is still behind (asynchronous submission: by a whole batch) is safe."""
+        if not MotionDiffusion._RECORD:
+            return
+        for t in tensors:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
+
+    def _graph_run(self, key, inputs, fn, owner=None):
         """Run fn(static_inputs) -> outputs through a cached HIP graph: `inputs` (dict of device
         tensors or None) are copied into static buffers, the captured launch sequence is replayed
-        and clones of the outputs are returned.  Falls back to eager launches if use_graphs is off."""
+        and clones of the outputs are returned.  Falls back to eager launches if use_graphs is off.
+        owner: key of the session whose buffers the graph is bound to (evicted together)."""
+        self._used_on(torch.cuda.current_stream(), *inputs.values())
         if not self.use_graphs:
             return fn(inputs)
         ent = self._graphs.pop(key, None)
@@ -285,7 +312,11 @@ class MotionDiffusion(torch.nn.Module):
             self._graphs[key] = ent                               # most recently used goes last
         if ent is None:
             while len(self._graphs) >= self.MAX_GRAPHS:
-                del self._graphs[next(iter(self._graphs))]
+                old = next(iter(self._graphs))
+                del self._graphs[old]
+                self._graph_owner.pop(old, None)
+            if owner is not None:
+                self._graph_owner[key] = owner
             torch.cuda.synchronize()  # other lanes may have work in flight: capture from a quiet device
             static = {k: (None if v is None else torch.empty(v.shape, dtype=v.dtype, device=v.device).copy_(v))
                       for k, v in inputs.items()}
@@ -307,6 +338,17 @@ class MotionDiffusion(torch.nn.Module):
                 static[k].copy_(v)
         graph.replay()
         return tuple(o.clone() for o in outs)
+
+    @staticmethod
+    def wait_results(results, stream=None):
+        """Asynchronous submission: make `stream` (default: the current one) wait for the batch behind `results` and mark
+        its tensors as used there; a no-op for synchronous results.  Returns `results`."""
+        ev = results.get("done_event") if isinstance(results, dict) else None
+        if ev is not None:
+            stream = torch.cuda.current_stream() if stream is None else stream
+            stream.wait_event(ev)
+            MotionDiffusion._used_on(stream, *[v for v in results.values() if torch.is_tensor(v)])
+        return results
 
     def train(self, mode=True):
         if mode:
@@ -336,17 +378,17 @@ class MotionDiffusion(torch.nn.Module):
     def to(self, *a, **k):
         return self
 
-    MAX_SESSIONS, MAX_GRAPHS = 24, 96   # LRU caps (a session holds ~45 MB of activations per 16 clips, a graph its statics)
+    MAX_SESSIONS, MAX_GRAPHS = 48, 192   # LRU caps (a session holds ~45 MB of activations per 16 clips, a graph its statics)
 
     def _session(self, B, role="sample", lane=0):
-        key = (B, role, lane)
+        key = (B, role, lane, self._slot)
         if key not in self._sessions:
             while len(self._sessions) >= self.MAX_SESSIONS:      # evict the least recently used session and its graphs
                 old = next(iter(self._sessions))
                 del self._sessions[old]
-                for gk in [g for g in self._graphs if g[0] in ("cond", "invert", "sample", "guided") and g[1] == old[0]
-                           and old[2] in g[2:4]]:
-                    del self._graphs[gk]
+                for gk in [g for g, o in self._graph_owner.items() if o == old]:
+                    self._graphs.pop(gk, None)
+                    del self._graph_owner[gk]
             self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B, **self.session_options)
         else:
             self._sessions[key] = self._sessions.pop(key)        # most recently used goes last
@@ -366,8 +408,8 @@ class MotionDiffusion(torch.nn.Module):
             sess.set_conditions(st["word"], st["audio"], st["spk"], st["mask"], {c: st["q_" + c] for c in denoiser.CONDS})
             return ()
 
-        self._graph_run(("cond", B, role, lane, tuple(ins["word"].shape), tuple(ins["audio"].shape),
-                         tuple(ins["spk"].shape)), ins, run)
+        self._graph_run(("cond", B, role, lane, self._slot, tuple(ins["word"].shape), tuple(ins["audio"].shape),
+                         tuple(ins["spk"].shape)), ins, run, owner=(B, role, lane, self._slot))
         return sess
 
     def _concurrent_streams(self, n):
@@ -465,7 +507,9 @@ class MotionDiffusion(torch.nn.Module):
         # cross-attention query masks: the reference's index arithmetic gives rows 10, 20, 30
         # ([(T-3)//4, 2*(T-3)//4, 3*(T-3)//4], diffusion_architecture.py:155), not the separators.
         qmask = torch.ones_like(motion_mask)
-        qmask[:, [(T - 3) // 4, 2 * (T - 3) // 4, 3 * (T - 3) // 4]] = 0
+        for r in ((T - 3) // 4, 2 * (T - 3) // 4, 3 * (T - 3) // 4):
+            qmask[:, r] = 0      # (a LIST index would go through a synchronous host-to-device copy of the index tensor,
+            #                       which on ROCm waits for every stream of the device: the host then cannot queue ahead)
         query_masks = {c: qmask for c in denoiser.CONDS}
 
         # the conditioning projections (K/V of every layer) need the inputs only: they run on the lane streams
@@ -473,11 +517,18 @@ class MotionDiffusion(torch.nn.Module):
         plan = self._lane_plan(B)                            # exemplar inversion
         plan_s = self._lane_plan(B, self.sample_lanes)       # sampling loops
         main = torch.cuda.current_stream()
+        # asynchronous submission: this batch's sessions / graph buffers are those of its slot; its front end (everything
+        # up to the lanes) stays on the caller's stream and the search stream, because the lane streams may still be
+        # busy with the previous batch's chain
+        run_async = self.async_results and self.slots > 1 and not getattr(self, "profile_phases", False)
+        self._slot = (self._slot + 1) % self.slots if run_async else 0
+        gre.concurrent_parts(not run_async)   # one launch chain per VAE graph when graphs are queued behind a running batch
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
         with self._phase("conditions"):
             for lane, stream, b0, b1 in plan_s:
-                stream.wait_stream(main)
-                with torch.cuda.stream(stream):
+                cstream = main if run_async else stream
+                cstream.wait_stream(main)
+                with torch.cuda.stream(cstream):
                     self._set_conditions(b1 - b0, "sample", lane, word[b0:b1], audio[b0:b1], spk[b0:b1],
                                          motion_mask[b0:b1], {c: qmask[b0:b1] for c in denoiser.CONDS})
         with self._phase("vae_encode"):
@@ -500,8 +551,9 @@ class MotionDiffusion(torch.nn.Module):
                 sel = [e for e, (b, _, _, placed) in enumerate(ex) if placed is not None and b0 <= b < b1]
                 if not sel:
                     continue
-                stream.wait_event(fork)   # main's state before the exemplar VAE encode was queued
-                with torch.cuda.stream(stream):
+                cstream = main if run_async else stream
+                cstream.wait_event(fork)   # main's state before the exemplar VAE encode was queued
+                with torch.cuda.stream(cstream):
                     Ep = bucket(len(sel))
                     st = lambda k: pad_rows(torch.stack([recs[e][k] for e in sel]).to(dev), Ep)
                     eqm = {c: pad_rows(torch.stack([qmask[ex[e][0]] for e in sel]), Ep) for c in denoiser.CONDS}
@@ -593,6 +645,7 @@ class MotionDiffusion(torch.nn.Module):
         for lane, stream, b0, b1 in plan:
             Bl = b1 - b0
             stream.wait_stream(main)
+            self._used_on(stream, start_noise, invl, qmask)
             with torch.cuda.stream(stream):
                 if use_inversion:
                     ex = [(b, q_idx) for b in range(b0, b1) for q_idx in retrieval_dict["retr_uncropped_latents"][b].keys()]
@@ -602,7 +655,11 @@ class MotionDiffusion(torch.nn.Module):
                         E = len(ex)
                         Ep = bucket(E)
                         lat = lambda b, q: retrieval_dict["retr_uncropped_latents"][b][q]
-                        cat = lambda key: pad_rows(torch.cat([lat(b, q)[key].to(dev) for b, q in ex], dim=0), Ep)
+
+                        def cat(key, stream=stream):
+                            parts = [lat(b, q)[key].to(dev) for b, q in ex]
+                            self._used_on(stream, *parts)
+                            return pad_rows(torch.cat(parts, dim=0), Ep)
                         esess = self._session(Ep, "invert", lane)
                         with self._phase("exemplar_conditions"):
                             if early_cond.get(lane) != E:   # not already projected while the exemplars were encoded
@@ -611,8 +668,9 @@ class MotionDiffusion(torch.nn.Module):
                                                      cat("retr_motion_mask"), eqm)
                             x_e = cat("retr_motion_latent").float().contiguous()
                         with self._phase("inversion"):
-                            (inv,) = self._graph_run(("invert", Ep, lane, T), dict(x=x_e), lambda s, esess=esess, Ep=Ep: (
-                                sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, Ep, T, D, device=dev)),))
+                            (inv,) = self._graph_run(("invert", Ep, lane, T, self._slot), dict(x=x_e), lambda s, esess=esess, Ep=Ep: (
+                                sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, Ep, T, D, device=dev)),),
+                                owner=(Ep, "invert", lane, self._slot))
                         for e, (b, q_idx) in enumerate(ex):
                             r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
                             q0, q1 = retrieval_dict["query_startends"][b][q_idx]
@@ -624,8 +682,8 @@ class MotionDiffusion(torch.nn.Module):
                         if visualize_inversion:
                             # sanity check of the reference (diffusion_architecture.py:357-382): every inversion level
                             # and the DDIM reconstruction from the last level, decoded after the sampling below
-                            (rec,) = self._graph_run(("recon", Ep, lane, T), dict(x=inv[S - 1]), lambda s, esess=esess: (
-                                sampler.ddim_sample_loop(esess, s["x"]),))
+                            (rec,) = self._graph_run(("recon", Ep, lane, T, self._slot), dict(x=inv[S - 1]), lambda s, esess=esess: (
+                                sampler.ddim_sample_loop(esess, s["x"]),), owner=(Ep, "invert", lane, self._slot))
                             for e in range(E):
                                 vis_inv.append(inv[:, e])
                                 vis_pairs.append(torch.stack([x_e[e], rec[e]]))
@@ -637,8 +695,9 @@ class MotionDiffusion(torch.nn.Module):
         inverted = [(stream, stream.record_event()) for _, stream, _, _ in plan]
         for lane, stream, b0, b1 in plan_s:
             Bl = b1 - b0
-            sess = self._session(Bl, "sample", lane)
+            sess, okey = self._session(Bl, "sample", lane), (Bl, "sample", lane, self._slot)
             stream.wait_stream(main)
+            self._used_on(stream, x, in_seq, inseq_noise, invl, ddpm_noise, x_out)
             if plan_s != plan:                   # a sampling lane then reads rows spliced by several inversion lanes
                 for other, ev in inverted:
                     if other is not stream:
@@ -648,42 +707,62 @@ class MotionDiffusion(torch.nn.Module):
                 loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(inseq_noise, 1), invl=sl(invl, 1))
                 with self._phase("sampling"):
                     if ddpm:
-                        (xl,) = self._graph_run(("ddpm", Bl, lane, T), dict(x=sl(x, 0), noise=sl(ddpm_noise, 1)),
-                                                lambda s, sess=sess: (sampler.p_sample_loop(sess, s["x"], s["noise"]),))
+                        (xl,) = self._graph_run(("ddpm", Bl, lane, T, self._slot), dict(x=sl(x, 0), noise=sl(ddpm_noise, 1)),
+                                                lambda s, sess=sess: (sampler.p_sample_loop(sess, s["x"], s["noise"]),), owner=okey)
                     elif use_insertion_guidance:
                         gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
-                        key = ("guided", Bl, lane, T, in_seq is not None, gi, lr)
+                        key = ("guided", Bl, lane, T, self._slot, in_seq is not None, gi, lr)
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess, gi=gi, lr=lr: (
-                            sampler.ddim_guided_sample_loop(sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),))
+                            sampler.ddim_guided_sample_loop(sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),),
+                            owner=okey)
                     else:
-                        key = ("sample", Bl, lane, T, in_seq is not None)
+                        key = ("sample", Bl, lane, T, self._slot, in_seq is not None)
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess: (sampler.ddim_sample_loop(
-                            sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),))
+                            sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),), owner=okey)
                     x_out[b0:b1].copy_(xl)
+        # ---- tail: latent post-processing and VAE decode once every lane is done: on the caller's stream, or, with
+        # asynchronous submission (where that one is already queueing the next batch), on the first sampling lane's stream
+        tail = plan_s[0][1] if run_async else main
         for _, stream, _, _ in plan + plan_s:
-            main.wait_stream(stream)
-        x = x_out
-        output = self.model.post_process(x)
-        results["prev_latentout"] = output
-        with self._phase("vae_decode"):
-            up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B), dict(z=output), lambda s: gre.decode(s["z"]))
-        results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
-        results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
-        results["pred_contact"] = co
-        if use_inversion and visualize_inversion and vis_inv:
-            # diffusion_architecture.py:488-571: decoded inversion levels [n_exemplars, S, frames, *] and decoded
-            # (exemplar, reconstruction) pairs [n_exemplars, 2, frames, *]
-            n_ex = len(vis_inv)
-            keys = ("upper", "lower", "facepose", "hands", "transl", "exps")
-            for name, lat, k in (("inverted_output", torch.stack(vis_inv).reshape(n_ex * S, T, D), S),
-                                 ("reconspair_output", torch.stack(vis_pairs).reshape(n_ex * 2, T, D), 2)):
-                lat = self.model.post_process(lat.contiguous())
-                parts = [[] for _ in keys]
-                for c0 in range(0, lat.shape[0], 128):            # decoded in slabs of 128 like the reference (:496-528)
-                    dec = gre.decode(lat[c0:c0 + 128].contiguous())
-                    for j in range(6):
-                        parts[j].append(dec[j])
-                for j, kname in enumerate(keys):
-                    t = torch.cat(parts[j], dim=0)
-                    results["%s_%s" % (name, kname)] = t.reshape(n_ex, k, t.shape[1], -1)
+            if stream is not tail:
+                tail.wait_stream(stream)
+        self._used_on(tail, x_out, *vis_inv, *vis_pairs)
+        with torch.cuda.stream(tail):
+            x = x_out
+            output = self.model.post_process(x)
+            results["prev_latentout"] = output
+            with self._phase("vae_decode"):
+                up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B, gre.part_streams is None), dict(z=output), lambda s: gre.decode(s["z"]))
+            results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
+            results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
+            results["pred_contact"] = co
+            if use_inversion and visualize_inversion and vis_inv:
+                # diffusion_architecture.py:488-571: decoded inversion levels [n_exemplars, S, frames, *] and decoded
+                # (exemplar, reconstruction) pairs [n_exemplars, 2, frames, *]
+                n_ex = len(vis_inv)
+                keys = ("upper", "lower", "facepose", "hands", "transl", "exps")
+                for name, lat, k in (("inverted_output", torch.stack(vis_inv).reshape(n_ex * S, T, D), S),
+                                     ("reconspair_output", torch.stack(vis_pairs).reshape(n_ex * 2, T, D), 2)):
+                    lat = self.model.post_process(lat.contiguous())
+                    parts = [[] for _ in keys]
+                    for c0 in range(0, lat.shape[0], 128):            # decoded in slabs of 128 like the reference (:496-528)
+                        dec = gre.decode(lat[c0:c0 + 128].contiguous())
+                        for j in range(6):
+                            parts[j].append(dec[j])
+                    for j, kname in enumerate(keys):
+                        t = torch.cat(parts[j], dim=0)
+                        results["%s_%s" % (name, kname)] = t.reshape(n_ex, k, t.shape[1], -1)
+        done = torch.cuda.Event()
+        done.record(tail)
+        self._used_on(main, *[v for v in results.values() if torch.is_tensor(v)])   # the caller reads them on its stream
+        if run_async:
+            # done_stream: where the results were produced; work queued there needs no wait (ROCm maps streams onto 4
+            # hardware queues: a consumer stream of its own that waits for done_event can block whichever of the
+            # caller's / search / lane streams shares its queue, and with it the next batch's front end)
+            results["done_event"], results["done_stream"] = done, tail
+            self._inflight.append(done)
+            while len(self._inflight) > self.max_inflight:
+                self._inflight.popleft().synchronize()
+        elif tail is not main:
+            main.wait_event(done)
         return results

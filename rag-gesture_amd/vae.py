@@ -283,6 +283,14 @@ class GestureRepEncoder:
         # the four body-part VAEs are independent launch chains of small kernels: each runs on a stream of its own
         # (forked from / joined into the caller's stream, also inside a graph capture); part_streams=False: one chain
         self.part_streams = [torch.cuda.Stream(device=self.dev) for _ in PARTS] if part_streams else None
+        self._part_streams_cfg = self.part_streams
+
+    def concurrent_parts(self, on):
+        """Switch the fan-out over part streams on (if the encoder was built with it) or off.  Off is what a caller needs
+        who queues these graphs BEHIND long-running work: a captured fork / join replays on internal streams, whose
+        waits occupy the runtime's (4) hardware queues from the moment the graph is queued -- every other stream of the
+        process then stalls until that earlier work is done (measured: all 16 probed streams, profiles/dbg/host_block4.py)."""
+        self.part_streams = self._part_streams_cfg if on else None
 
     def _fan_out(self, jobs):
         """Run the per-part jobs (callables) concurrently: job i on part stream i, all ordered after the work already
@@ -324,7 +332,7 @@ class GestureRepEncoder:
             return self.encode_device(up, lo, fa, ha, tr, fac, con, eps_list)
         ins = dict(up=up, lo=lo, fa=fa, ha=ha, tr=tr, fac=fac, con=con, e0=eps_list[0], e1=eps_list[1],
                    e2=eps_list[2], e3=eps_list[3])
-        return self.graph_runner(("enc", up.shape[0]), ins, lambda s: self.encode_device(
+        return self.graph_runner(("enc", up.shape[0], self.part_streams is None), ins, lambda s: self.encode_device(
             s["up"], s["lo"], s["fa"], s["ha"], s["tr"], s["fac"], s["con"], [s["e0"], s["e1"], s["e2"], s["e3"]]))
 
     def latent_mask(self, motion_mask):

@@ -1,0 +1,82 @@
+"""Asynchronous submission (MotionDiffusion(async_results=True)): batches queued back to back, the host never waiting, must
+give the same bits as one synchronous forward per batch -- the front end of batch n+1 runs beside the chain of batch n on
+other sessions / graph buffers (slots), and every tensor that crosses streams is protected from the caching allocator."""
+import importlib
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+KEYS = ("pred_upper", "pred_lower", "pred_facepose", "pred_hands", "pred_transl", "pred_exps", "prev_latentout")
+GI = [2] * 25 + [0] * 25
+
+
+@pytest.fixture(scope="module")
+def rg():
+    return importlib.import_module("rag-gesture_amd")
+
+
+def _batches(rg, B, n, dev):
+    out = []
+    for i in range(n):
+        d = rg.synth.synth_batch(B, seed=900 + i, device=dev)
+        qs = [rg.synth.synth_query(50 * i + j) for j in range(B)]
+        d["discourse"] = [q["discourse"] for q in qs]
+        d["prominence"] = [q["prominence"] for q in qs]
+        d["text_features"] = [q["text_features"].to(dev) for q in qs]
+        d["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
+        out.append(d)
+    return out
+
+
+@pytest.mark.parametrize("guided", [True, False])
+def test_async_pipeline_equals_synchronous_forwards(rg, guided):
+    dev = torch.device("cuda", 0)
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    db = rg.synth.SyntheticDataset(512, seed=11, device=dev, feat_device=dev) if guided else None
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=guided), database=db, device=dev)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+    B, N = 4, 5
+    batches = _batches(rg, B, N, dev)
+    ikw = lambda i: dict(dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1) if guided else {},
+                         noise_tape=rg.synth.NoiseTape(3000 + i))
+
+    def run(i):
+        d = dict(batches[i])
+        d["trans"] = batches[i]["trans"].clone()
+        return model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw(i)))
+
+    ref = []
+    for i in range(N):
+        out = run(i)
+        torch.cuda.synchronize()
+        ref.append({k: out[k].clone() for k in KEYS})
+    model.async_results = True
+    consumer = torch.cuda.Stream()
+    got = []
+    for rep in range(2):                    # second pass: every slot's graphs exist, nothing synchronises the device
+        got = []
+        for i in range(N):
+            out = run(i)
+            assert "done_event" in out
+            if i % 2:
+                with torch.cuda.stream(consumer):           # a consumer stream of its own: waits for the completion event
+                    model.wait_results(out)
+                    got.append({k: out[k].clone() for k in KEYS})
+            else:
+                with torch.cuda.stream(out["done_stream"]):  # or the stream the batch ends on: ordered, no wait
+                    got.append({k: out[k].clone() for k in KEYS})
+            del out                          # results and temporaries die on the host while the lanes are a batch behind
+            junk = [torch.full((B, 43, 512), float(i), device=dev) for _ in range(8)]   # reuse freed blocks on the caller's stream
+            del junk
+    torch.cuda.synchronize()
+    for i in range(N):
+        for k in KEYS:
+            assert torch.equal(got[i][k], ref[i][k]), (i, k, (got[i][k] - ref[i][k]).abs().max().item())
+    # synchronous mode again: no event, tensors valid on the caller's stream
+    model.async_results = False
+    out = run(0)
+    assert "done_event" not in out
+    assert torch.equal(out["pred_upper"], ref[0]["pred_upper"])
