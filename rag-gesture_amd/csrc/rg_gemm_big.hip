@@ -159,8 +159,12 @@ bool rg_gemm_big_eligible(const rg_gemm_desc* d) {
 // Auto policy (measured, MI355X, graph-replayed, rotating operands): at M = 4128 the 128x256 tile is 4-8 %
 // faster than 64x128 for N = 1024 / 1536 (18.1 vs 18.9, 19.2 vs 20.8 us) and 1.4x faster once the grid has
 // many rounds (23952 x 8192 x 512: 469 vs 666 us); below ~4k rows or for N = 512 it loses (too few workgroups).
+// Round 2: against the 64x128 kernel at two 8-wave workgroups per CU (rg_gemm_dma.hip) it also loses at M = 4128
+// (denoiser forward 1385 vs 1354 us with / without it: 3 rounds of 64x128 tiles at N = 1536), so it is kept for grids of
+// 8 rounds and more.
 int rg_gemm_big_width(const rg_gemm_desc* d, int num_cus) {
   if (d->M < 4096 || d->N < 1024) return 0;
+  if ((long)((d->M + 63) / 64) * ((d->N + 127) / 128) < 8L * num_cus) return 0;
   const int mt = (d->M + BBM - 1) / BBM;
   const int wg256 = mt * ((d->N + 255) / 256);
   return wg256 >= num_cus / 2 ? 256 : 128;

@@ -71,8 +71,8 @@ __device__ __forceinline__ void wait_tiles(int younger) {
 // of the MFMAs and between the same two barriers -- instead of a separate elementwise launch in front of the GEMM
 // (4.9 us per launch at M = 1376) or of the fragment-read prologue of the fp32-A kernel, which redoes the two
 // transcendentals in every wave column (x4) and fetches fp32 rows.
-template <bool A_BF16, bool SPLIT, int NS, int NW, int BN_ = BN, bool STYL = false>
-__global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p) {
+template <bool A_BF16, bool SPLIT, int NS, int NW, int BN_ = BN, bool STYL = false, int MINW = 1>
+__global__ void __launch_bounds__(NW * 64, MINW) gemm_dma_kernel(const rg_gemm_desc p) {
   static_assert(!STYL || (A_BF16 && !SPLIT && NS >= 3), "STYL: bf16 A, one weight plane, ring of >= 3");
   constexpr int NTH = NW * 64;
   constexpr int WN = NW / 2;            // waves along N (2 along M)
@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
   // residual values for the epilogue and the first operand tiles are requested up front: their
   // latency overlaps the table setup and the K loop instead of adding to it
   ResidualPrefetch pre;
-  if (tid < NT) prefetch_residual(p, tid, m0, n0, pre, BN_);
+  if constexpr (MINW == 1)   // (the two-per-CU variant has 128 VGPRs: its residual is fetched in the epilogue)
+    if (tid < NT) prefetch_residual(p, tid, m0, n0, pre, BN_);
   // Row statistics and (STYL) the folded gain / offset vectors go into LDS by DMA as well, IN FRONT of the operand
   // tiles in every wave's queue: the counted waits below then cover them, and no register-destination load (whose
   // first use the compiler would wait for with vmcnt(0), draining the ring's prefetch) is involved.
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(NW * 64) gemm_dma_kernel(const rg_gemm_desc p)
         sC[(wr * 32 + i * 16 + fq * 4 + e) * SC_LD + wc * (TN * 16) + j * 16 + frow] = acc[i][j][e];
   __syncthreads();
   RG_STAMP(61);
-  if (tid < NT) epilogue(p, sC, tid, m0, n0, tile_n, nt, &pre, BN_, (!STYL && st_parts > 0) ? sStat : nullptr);
+  if (tid < NT) epilogue(p, sC, tid, m0, n0, tile_n, nt, MINW == 1 ? &pre : nullptr, BN_, (!STYL && st_parts > 0) ? sStat : nullptr);
   RG_STAMP(62);
 }
 
@@ -487,6 +488,18 @@ void dma_launch_styl(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((gemm_dma_kernel<true, false, NS, NW, BN, true>), grid, dim3(NW * 64), lds, s, *d);
 }
 
+// 8 waves, ring of 3 (76.5 KiB), at most 128 VGPRs (no residual prefetch): two workgroups per CU
+void dma_launch_pair(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, 3, 8, BN, false, 4>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
+    attr = true;
+  }
+  const size_t lds = dma_lds_bytes<true, false>(0, 3, stat_bytes(d));
+  hipLaunchKernelGGL((gemm_dma_kernel<true, false, 3, 8, BN, false, 4>), grid, dim3(512), lds, s, *d);
+}
+
 // ring depth for this descriptor (0: does not fit the 160 KiB LDS at all).  Grids with more
 // workgroups than CUs use a 2-stage ring (<= 80 KiB) so two workgroups share a CU and hide each
 // other's DMA latency; smaller grids are a pure latency chain and take the deepest ring that fits.
@@ -533,6 +546,12 @@ void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, int waves, void* str
     return;
   }
   const int ns = dma_depth(d, num_cus);
+  // bf16 A, more workgroups than CUs: two 8-wave workgroups per CU (ring of 3, <= 128 VGPRs) instead of two 4-wave ones
+  // (ring of 2): 16 waves per CU hide each other's round trips (M = 4128 forward 1456 -> 1385 us); waves = 16 forces it
+  if (d->a_is_bf16 && !d->W_lo && (waves == 16 || (waves == 0 && ns == 2))) {
+    dma_launch_pair(d, grid, s);
+    return;
+  }
   // measured (MI355X, graph-replayed): 8 waves win ~7% on single-round grids with plain or bf16 A
   // (7.8 vs 8.4 us at 2752x512x512); with the LN/stylization prologue or multi-round grids the
   // extra per-wave prologue math / lower workgroup residency loses 15-50%
@@ -567,7 +586,7 @@ void rg_gemm_dma_launch(const rg_gemm_desc* d, int num_cus, int waves, void* str
 
 extern "C" int rg_set_gemm_waves(rg_handle* h, int waves) {
   RG_REQUIRE(h, h != nullptr, "null handle");
-  RG_REQUIRE(h, waves == 0 || waves == 4 || waves == 8, "waves must be 0, 4 or 8");
+  RG_REQUIRE(h, waves == 0 || waves == 4 || waves == 8 || waves == 16, "waves must be 0, 4, 8 or 16 (8 waves, two workgroups per CU)");
   h->gemm_waves = waves;
   return RG_OK;
 }

@@ -151,3 +151,49 @@ def test_narrow_tiles_bf16_A_epilogue_features(rg, h, M, K):
     out128 = torch.empty(M, N, device="cuda")
     G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out128, A=a.cuda().bfloat16(), bias=b.cuda(), residual=res.cuda())
     assert torch.equal(out128, out)
+
+
+@pytest.mark.parametrize("waves,path,M,N,K", [
+    (0, 0, 1376, 512, 512),     # one round: ring of 4, 8 waves
+    (0, 0, 4128, 512, 512),     # 260 workgroups: two 8-wave workgroups per CU (ring of 3, 128 VGPRs)
+    (0, 0, 4128, 1536, 512),    # 780 workgroups: the same variant over three rounds
+    (16, 0, 688, 512, 2048),    # that variant forced on a small grid
+    (4, 0, 4128, 1024, 512),    # 4-wave workgroups, ring of 2
+    (0, 4, 4128, 1536, 512),    # the 128x256 big-tile kernel
+    (0, 0, 16640, 4096, 512),   # >= 8 rounds of 64x128 tiles: the big-tile kernel by policy
+])
+def test_bf16_A_kernel_variants_epilogue_features(rg, h, waves, path, M, N, K):
+    """Every kernel the dispatch can pick for a bf16 A operand, with the whole fused epilogue: LayerNorm folded through
+    row statistics (fetched by DMA in the LDS-DMA kernels), bias, residual, partial output statistics, bf16 copy."""
+    G = rg.gemm
+    x = _rand((M, K), 31) + 0.3                       # rows with a mean: the folded LayerNorm has something to remove
+    gam, bet = _rand((K,), 32) * 0.2 + 1.0, _rand((K,), 33) * 0.1
+    w, b, res = _rand((N, K), 34, 0.05), _rand((N,), 35), _rand((M, N), 36)
+    # W' = W diag(gamma), c1 = rowsum(W'), bias' = b + W beta  (denoiser.py builds the same at load time)
+    wp = G.pack_weight(w * gam[None, :], "cuda")
+    c1 = wp.hi[:N, :K].float().sum(-1).contiguous()
+    bias = (b + w @ bet).cuda()
+    xs = x.cuda()
+    parts = K // 128
+    st_in = torch.stack([xs.view(M, parts, 128).sum(-1), (xs * xs).view(M, parts, 128).sum(-1)], dim=-1).contiguous()
+    out = torch.empty(M, N, device="cuda")
+    o2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    st = torch.zeros(M, N // 128, 2, device="cuda")
+    h.lib.rg_set_gemm_waves(h._h, waves)
+    h.lib.rg_set_gemm_path(h._h, path)
+    try:
+        G.gemm(h, M=M, N=N, K=K, W=wp, out=out, A=xs.bfloat16(), bias=bias, residual=res.cuda(), stats_out=st, out2=o2,
+               ln_stats=st_in, ln_c1=c1)
+        torch.cuda.synchronize()
+    finally:
+        h.lib.rg_set_gemm_waves(h._h, 0)
+        h.lib.rg_set_gemm_path(h._h, 0)
+    mu, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    rs = torch.rsqrt(var + 1e-5)
+    ref = rs * (F.linear(bf(x), wp.hi[:N, :K].float().cpu()) - mu * c1.cpu()[None, :]) + bias.cpu() + res
+    scale = max(1.0, ref.abs().max().item())
+    assert (out.cpu() - ref).abs().max() <= 3e-3 * scale
+    assert (o2.float().cpu() - out.cpu()).abs().max() <= 2e-2 * scale
+    o = out.cpu().view(M, N // 128, 128)
+    assert (st.cpu()[..., 0] - o.sum(-1)).abs().max() <= 4e-3 * scale
+    assert (st.cpu()[..., 1] - (o * o).sum(-1)).abs().max() <= 4e-2 * scale * scale
