@@ -60,6 +60,12 @@ int rg_ddim_update(rg_handle* h, const float* x, const float* x0, float* x_out, 
 int rg_cfg_ddim_update(rg_handle* h, const float* out, const float* x, float* x_out, float* x0_out,
                        const float* js, int B, int T, int D, float w_c, float w_u,
                        float c_recip, float c_recipm1, float c_a, float c_b, void* stream);
+/* The same on a sub-range of a batch: out_cond / out_uncond point at the conditional and the classifier-free rows of the
+ * same B clips (they are not B*T*D apart when the denoiser batch holds more sequences); x_out2 (may be NULL) receives a
+ * second copy of the updated latent (the inversion stores every level and keeps the working rows in place). */
+int rg_cfg_ddim_update_rows(rg_handle* h, const float* out_cond, const float* out_uncond, const float* x, float* x_out,
+                            float* x_out2, const float* js, int B, int T, int D, float w_c, float w_u,
+                            float c_recip, float c_recipm1, float c_a, float c_b, void* stream);
 
 /* The same CFG mix followed by one ancestral (DDPM) step, `inference_type="ddpm"`:
  *   x_out = (c1 * x0 + c2 * x) + sigma * noise
@@ -181,6 +187,13 @@ int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
  * timestep only and is tabulated at load time.  m_cond = M disables this. */
 int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16, int ldo,
                int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask, void* stream);
+/* rg_stylize for a batch whose sequences sit at TWO diffusion steps (the sampling rows of one batch of clips and the
+ * inversion rows of the next batch's exemplars in the same launches): rows are [2 CFG halves][nseq sequences][T tokens];
+ * sequences >= split of either half take their (scale | shift) from scale_shift_b_host[s] (HOST array of nseg device
+ * pointers) instead of segs[s].scale_shift.  split >= nseq: one group, as rg_stylize. */
+int rg_stylize_groups(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16, int ldo,
+                      int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask,
+                      const float* const* scale_shift_b_host, int T, int nseq, int split, void* stream);
 
 /* Kernel selection hook for tests / tuning: 0 = auto, 1 = generic register-staged kernel only (any
  * shape), 2 = prefer the LDS-DMA ring kernel, 3 = prefer the depth-4 register-staged kernel, 4 = prefer the
@@ -248,6 +261,12 @@ int rg_ca_attention(rg_handle* h, const float* q3, const float* Apre, const floa
 int rg_ca_stylize(rg_handle* h, const float* q3, const void* At_bf16, const float* qmask, const float* gamma,
                   const float* beta, const float* scale_shift, const void* unc_tab_bf16, void* out_bf16, int ldo,
                   int Rc, int Ru, int T, int D, int ncond, void* stream);
+/* The same for two groups of sequences at different diffusion steps: row groups >= split of the conditional rows take
+ * scale_shift_b, those >= split of the classifier-free rows unc_tab_b (see rg_stylize_groups). */
+int rg_ca_stylize_groups(rg_handle* h, const float* q3, const void* At_bf16, const float* qmask, const float* gamma,
+                         const float* beta, const float* scale_shift, const void* unc_tab_bf16, void* out_bf16, int ldo,
+                         int Rc, int Ru, int T, int D, int ncond, const float* scale_shift_b, const void* unc_tab_b_bf16,
+                         int split, void* stream);
 
 /* At[m] = (bf16(A[m]^T), bf16(A[m]^T - hi)) for n_mat fp32 32x32 matrices: the B-operand layout rg_ca_stylize reads. */
 int rg_split_transpose_bf16(rg_handle* h, const float* A, void* At_bf16, int n_mat, void* stream);

@@ -571,6 +571,10 @@ struct StylizeArgs {
   int m_cond, unc_nseg;
   const unsigned short* unc_tab;
   const float* qmask;   // [nseg][M] or null
+  // two groups of sequences at different diffusion steps in one batch (rows are [2 CFG halves][nseq sequences][T tokens]):
+  // sequences >= split of either half take scale_shift from ss_b instead of seg[s].scale_shift; split >= nseq: one group
+  const float* ss_b[RG_MAX_SEG];
+  int T, nseq, split;
 };
 
 __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
@@ -592,6 +596,12 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
   }
   const float* src = sg.src + (size_t)row * sg.ld;
   const bool norm = sg.mode != RG_A_IDENT, styl = sg.mode == RG_A_STYL;
+  if (a.split < a.nseq && (row / a.T) % a.nseq >= a.split) {   // wave-uniform: a wave owns one row
+    if (s == 0) sg.scale_shift = a.ss_b[0];
+    if (s == 1) sg.scale_shift = a.ss_b[1];
+    if (s == 2) sg.scale_shift = a.ss_b[2];
+    if (s == 3) sg.scale_shift = a.ss_b[3];
+  }
   float mu = 0.f, rs = 1.f;
   bool have_stats = !norm;
   for (int k = lane * 8; k < a.seg_len; k += 512) {
@@ -668,6 +678,10 @@ struct CaStylizeArgs {
   const unsigned short* unc_tab;  // [2][ncond*D] bf16
   unsigned short* out;    // bf16 [(Rc+Ru)*T][ldo]
   int ldo, Rc, Ru, T, D, ncond;
+  // row groups (sequences) >= split of either half are at another diffusion step: their scale/shift and table
+  const float* scale_shift_b;
+  const unsigned short* unc_tab_b;
+  int split;
 };
 
 // At[m][0][l][d] = bf16(A[m][d][l]), At[m][1][l][d] = bf16(A[m][d][l] - float(hi)) for n_mat 32x32 matrices
@@ -973,12 +987,13 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
       const int n = i / vec, k8 = (i % vec) * 8;
       const int flag = sflag[(k8 / D) * T + n];
       *reinterpret_cast<u4*>(orow + (size_t)n * a.ldo + k8) =
-          *reinterpret_cast<const u4*>(a.unc_tab + (size_t)flag * ncond * D + k8);
+          *reinterpret_cast<const u4*>((u >= a.split ? a.unc_tab_b : a.unc_tab) + (size_t)flag * ncond * D + k8);
     }
     return;
   }
   RG_STAMP3(0);
   const int b = blockIdx.x / ncond, c = blockIdx.x % ncond;
+  const float* scale_shift = b >= a.split ? a.scale_shift_b : a.scale_shift;
   float* sstat = sm;                           // [CS_WAVES][Tp][2]
   float* srow = sstat + CS_WAVES * 2 * Tp;     // [Tp][2] (mean, rstd)
   float* smask = srow + 2 * Tp;                // [Tp]
@@ -1017,7 +1032,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
   const int col0 = (threadIdx.x & 255) * 2;
   float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f;
   if (col0 < D) {
-    const float* ss = a.scale_shift + (size_t)c * 2 * D;
+    const float* ss = scale_shift + (size_t)c * 2 * D;
     const float2 gg = *reinterpret_cast<const float2*>(a.gamma + c * D + col0);
     const float2 bb = *reinterpret_cast<const float2*>(a.beta + c * D + col0);
     const float2 sc = *reinterpret_cast<const float2*>(ss + col0);
@@ -1138,7 +1153,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
   const int rq = threadIdx.x >> 8;   // NTH / 256 = 4 row phases
   for (int col = col0; col < D; col += 512) {
     if (col != col0) {
-      const float* ss = a.scale_shift + (size_t)c * 2 * D;
+      const float* ss = scale_shift + (size_t)c * 2 * D;
       g0 = a.gamma[c * D + col]; g1 = a.gamma[c * D + col + 1];
       b0 = a.beta[c * D + col]; b1 = a.beta[c * D + col + 1];
       sc0 = 1.0f + ss[col]; sc1 = 1.0f + ss[col + 1];
@@ -1167,7 +1182,15 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
 extern "C" int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16,
                           int ldo, int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask,
                           void* stream) {
+  return rg_stylize_groups(h, segs_host, nseg, seg_len, M, out_bf16, ldo, m_cond, unc_nseg, unc_tab_bf16, qmask, nullptr, 1, 1,
+                           1, stream);
+}
+
+extern "C" int rg_stylize_groups(rg_handle* h, const rg_a_segment* segs_host, int nseg, int seg_len, int M, void* out_bf16,
+                                 int ldo, int m_cond, int unc_nseg, const void* unc_tab_bf16, const float* qmask,
+                                 const float* const* scale_shift_b_host, int T, int nseq, int split, void* stream) {
   RG_REQUIRE(h, segs_host && out_bf16, "null pointer");
+  RG_REQUIRE(h, T > 0 && nseq > 0 && split >= 0 && (split >= nseq || scale_shift_b_host), "bad sequence groups");
   RG_REQUIRE(h, m_cond >= 0 && m_cond <= M && unc_nseg >= 0 && unc_nseg <= nseg && (m_cond == M || unc_nseg == 0 || unc_tab_bf16),
              "classifier-free rows need unc_tab");
   RG_REQUIRE(h, nseg >= 1 && nseg <= RG_MAX_SEG && seg_len % 8 == 0 && M > 0 && ldo % 8 == 0, "bad shape");
@@ -1185,6 +1208,8 @@ extern "C" int rg_stylize(rg_handle* h, const rg_a_segment* segs_host, int nseg,
   a.m_cond = m_cond; a.unc_nseg = unc_nseg;
   a.unc_tab = reinterpret_cast<const unsigned short*>(unc_tab_bf16);
   a.qmask = qmask;
+  a.T = T; a.nseq = nseq; a.split = split;
+  for (int s = 0; s < RG_MAX_SEG; ++s) a.ss_b[s] = (split < nseq && s < nseg) ? scale_shift_b_host[s] : nullptr;
   const int64_t waves = (int64_t)M * nseg;
   hipLaunchKernelGGL(stylize_kernel, dim3((unsigned)((waves * 64 + 255) / 256)), dim3(256), 0, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
@@ -1283,7 +1308,17 @@ extern "C" int rg_linear_f32(rg_handle* h, const float* a, const float* w, const
 extern "C" int rg_ca_stylize(rg_handle* h, const float* q3, const void* At_bf16, const float* qmask, const float* gamma,
                              const float* beta, const float* scale_shift, const void* unc_tab_bf16, void* out_bf16,
                              int ldo, int Rc, int Ru, int T, int D, int ncond, void* stream) {
+  return rg_ca_stylize_groups(h, q3, At_bf16, qmask, gamma, beta, scale_shift, unc_tab_bf16, out_bf16, ldo, Rc, Ru, T, D, ncond,
+                              nullptr, nullptr, Rc + Ru, stream);
+}
+
+extern "C" int rg_ca_stylize_groups(rg_handle* h, const float* q3, const void* At_bf16, const float* qmask, const float* gamma,
+                                    const float* beta, const float* scale_shift, const void* unc_tab_bf16, void* out_bf16,
+                                    int ldo, int Rc, int Ru, int T, int D, int ncond, const float* scale_shift_b,
+                                    const void* unc_tab_b_bf16, int split, void* stream) {
   RG_REQUIRE(h, q3 && At_bf16 && gamma && beta && scale_shift && out_bf16, "null pointer");
+  RG_REQUIRE(h, split >= 0 && ((split >= Rc && split >= Ru) || (scale_shift_b && (Ru == 0 || unc_tab_b_bf16))),
+             "row groups from `split` on need their own scale_shift / table");
   RG_REQUIRE(h, Rc > 0 && Ru >= 0 && (Ru == 0 || unc_tab_bf16), "classifier-free rows need the table");
   RG_REQUIRE(h, T > 0 && T <= TMAX && D % (HD * CS_WAVES) == 0 && ncond > 0 && ldo % 8 == 0, "bad shape");
   const int Tp = (T + 7) & ~7;
@@ -1299,6 +1334,7 @@ extern "C" int rg_ca_stylize(rg_handle* h, const float* q3, const void* At_bf16,
   a.unc_tab = reinterpret_cast<const unsigned short*>(unc_tab_bf16);
   a.out = reinterpret_cast<unsigned short*>(out_bf16);
   a.ldo = ldo; a.Rc = Rc; a.Ru = Ru; a.T = T; a.D = D; a.ncond = ncond;
+  a.scale_shift_b = scale_shift_b; a.unc_tab_b = reinterpret_cast<const unsigned short*>(unc_tab_b_bf16); a.split = split;
   hipLaunchKernelGGL(ca_stylize_kernel, dim3(Rc * ncond + Ru), dim3(CS_WAVES * 64), lds, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
   return RG_OK;

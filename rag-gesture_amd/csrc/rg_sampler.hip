@@ -38,9 +38,11 @@ __device__ __forceinline__ float cfg_one(float oc, float ou, float jc, float ju,
   return oc * w_c * jc + ou * w_u * ju;
 }
 
-__global__ void __launch_bounds__(kBlock) cfg_ddim_kernel(const float4* __restrict__ out,
+// out / out_u: conditional and classifier-free rows of the denoiser output for the same clips; xo2: optional second copy of
+// the updated latent (the inversion keeps every level AND feeds the next step from the session's contiguous rows)
+__global__ void __launch_bounds__(kBlock) cfg_ddim_kernel(const float4* __restrict__ out, const float4* __restrict__ out_u,
                                                          const float4* __restrict__ x,
-                                                         float4* __restrict__ xo, float4* __restrict__ x0o,
+                                                         float4* __restrict__ xo, float4* __restrict__ xo2, float4* __restrict__ x0o,
                                                          const float* __restrict__ js, int64_t n4, int td4,
                                                          int d4, float w_c, float w_u, float c_recip,
                                                          float c_recipm1, float c_a, float c_b) {
@@ -48,7 +50,7 @@ __global__ void __launch_bounds__(kBlock) cfg_ddim_kernel(const float4* __restri
     int t = (int)((i % td4) / d4);
     float jc = js[t];
     float ju = 1.0f / jc;
-    float4 oc = out[i], ou = out[i + n4], a = x[i], p, r;
+    float4 oc = out[i], ou = out_u[i], a = x[i], p, r;
     p.x = cfg_one(oc.x, ou.x, jc, ju, w_c, w_u);
     p.y = cfg_one(oc.y, ou.y, jc, ju, w_c, w_u);
     p.z = cfg_one(oc.z, ou.z, jc, ju, w_c, w_u);
@@ -58,6 +60,7 @@ __global__ void __launch_bounds__(kBlock) cfg_ddim_kernel(const float4* __restri
     r.z = ddim_one(a.z, p.z, c_recip, c_recipm1, c_a, c_b);
     r.w = ddim_one(a.w, p.w, c_recip, c_recipm1, c_a, c_b);
     xo[i] = r;
+    if (xo2) xo2[i] = r;
     if (x0o) x0o[i] = p;
   }
 }
@@ -197,8 +200,21 @@ extern "C" int rg_cfg_ddim_update(rg_handle* h, const float* out, const float* x
   RG_REQUIRE(h, B > 0 && T > 0 && D > 0 && D % 4 == 0, "bad shape");
   int64_t n4 = (int64_t)B * T * D / 4;
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(rg_grid_1d(n4, kBlock)), dim3(kBlock), 0, rg_stream(stream),
-                     (const float4*)out, (const float4*)x, (float4*)x_out, (float4*)x0_out, js, n4, T * D / 4,
-                     D / 4, w_c, w_u, c_recip, c_recipm1, c_a, c_b);
+                     (const float4*)out, (const float4*)out + n4, (const float4*)x, (float4*)x_out, (float4*)nullptr,
+                     (float4*)x0_out, js, n4, T * D / 4, D / 4, w_c, w_u, c_recip, c_recipm1, c_a, c_b);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_cfg_ddim_update_rows(rg_handle* h, const float* out_cond, const float* out_uncond, const float* x,
+                                       float* x_out, float* x_out2, const float* js, int B, int T, int D, float w_c, float w_u,
+                                       float c_recip, float c_recipm1, float c_a, float c_b, void* stream) {
+  RG_REQUIRE(h, out_cond && out_uncond && x && x_out && js, "null pointer");
+  RG_REQUIRE(h, B > 0 && T > 0 && D > 0 && D % 4 == 0, "bad shape");
+  int64_t n4 = (int64_t)B * T * D / 4;
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(rg_grid_1d(n4, kBlock)), dim3(kBlock), 0, rg_stream(stream),
+                     (const float4*)out_cond, (const float4*)out_uncond, (const float4*)x, (float4*)x_out, (float4*)x_out2,
+                     (float4*)nullptr, js, n4, T * D / 4, D / 4, w_c, w_u, c_recip, c_recipm1, c_a, c_b);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

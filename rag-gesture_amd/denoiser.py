@@ -296,19 +296,29 @@ class DenoiserSession:
         self.pf = F.PersistentForward(self, self.engine) if self.engine != "chain" else None
 
     # ------------------------------------------------------------------ once per clip
-    def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None):
+    def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None, offset=0, finalize=True):
         """word [B,Nt,768], audio [B,Na,768], speaker_ids [B,Ns] int64, motion_mask [B,T];
         query_masks: dict cond -> [B,T] or None (no query masking).
+        offset: the n = word.shape[0] <= B clips given are the session's clips [offset, offset + n) (a session that holds
+        two batches side by side is filled in two calls; finalize=False on all but the last).
         reference: raggesture.py:957-1013 (conditions), diffusion_architecture.py:146-166 (masks)."""
-        w, h, B, D = self.w, self.h, self.B, self.w.D
+        w, h, D = self.w, self.h, self.w.D
         dev = w.dev
-        self.src_mask.copy_(motion_mask.to(dev).float().repeat(2, 1))
-        if query_masks is None:
-            self.qmask.fill_(1.0)
-        else:
-            for ci, c in enumerate(CONDS):
-                self.qmask[ci].copy_(query_masks[c].to(dev).float().repeat(2, 1))
-        self.qmask_c.copy_(self.qmask[:, :B])
+        Bs, B = self.B, word.shape[0]          # session clips, clips of this call
+        o0, o1 = offset, offset + B
+        assert 0 <= o0 and o1 <= Bs
+        mm = motion_mask.to(dev).float()
+        self.src_mask[o0:o1].copy_(mm)
+        self.src_mask[Bs + o0:Bs + o1].copy_(mm)
+        for ci, c in enumerate(CONDS):
+            if query_masks is None:
+                self.qmask[ci, o0:o1].fill_(1.0)
+                self.qmask[ci, Bs + o0:Bs + o1].fill_(1.0)
+            else:
+                qm = query_masks[c].to(dev).float()
+                self.qmask[ci, o0:o1].copy_(qm)
+                self.qmask[ci, Bs + o0:Bs + o1].copy_(qm)
+        self.qmask_c[:, o0:o1].copy_(self.qmask[:, o0:o1])
         srcs = []
         for name, x, wt, bt in (("xf_text", word, w.w_text, w.b_text), ("xf_audio", audio, w.w_audio, w.b_audio)):
             x = x.to(dev).float().contiguous()
@@ -339,21 +349,30 @@ class DenoiserSession:
                 G.gemm(h, M=B * n_tok, N=2 * D, K=D, W=lw["w_kv"][ci], out=kv,
                        segs=[G.Seg(xf, mode=G.A_LN, stats=st, gamma=lw["tn_g"][ci], beta=lw["tn_b"][ci])],
                        seg_len=D, bias=lw["b_kv"][ci], ldo=2 * D)
-                h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci], B, n_tok, D)
-        if self.abf is not None:
-            h.call("split_transpose_bf16", self.a_pre, self.a_pre_t, w.L * 3 * B * w.H)
-        self._keep = srcs
+                h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci, o0:o1], B, n_tok, D)
+        if self.abf is not None and finalize:
+            h.call("split_transpose_bf16", self.a_pre, self.a_pre_t, w.L * 3 * Bs * w.H)
+        self._keep = (getattr(self, "_keep", []) if offset else []) + srcs
 
     # ------------------------------------------------------------------ per step
-    def forward(self, x, step):
+    def forward(self, x, step, step_b=None, split=None):
         """x [B,T,D] fp32 (device) at respaced step index `step`; returns the head output
-        [2B,T,D] (rows [0,B) conditional, [B,2B) classifier-free) in self.head."""
+        [2B,T,D] (rows [0,B) conditional, [B,2B) classifier-free) in self.head.
+        step_b / split: the clips [split, B) are at step index step_b instead (two diffusion loops advancing in the same
+        launches: the sampling of one batch and the inversion of the next batch's exemplars, sampler.cobatched_loop).  Only
+        the timestep-dependent stylization differs between the groups; launch chain, bf16 path."""
         w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
+        if split is not None and not (0 < split < B):
+            step, step_b, split = (step if split >= B else step_b), None, None
         if self.pf is not None:
+            if split is not None:
+                raise capi.RgError("two step groups need the launch-chain engine")
             return self.pf.run(x.contiguous(), step)
         if self.ln_mode == "auto":
+            if split is not None:
+                raise capi.RgError("run one plain forward first (ln_mode='auto' settles on the session's first step)")
             return self._forward_guarded(x, step)
-        return self._forward_chain(x, step)
+        return self._forward_chain(x, step, step_b, split)
 
     LN_GUARD_SIGMAS = 3.0   # |row mean| beyond this many standard deviations: the folded LayerNorm is not used
 
@@ -380,8 +399,11 @@ class DenoiserSession:
         if getattr(self, "_guard", None) is not None:
             self.h.call("ln_guard", stats, self.M, stats.shape[1], self.w.D, self._guard)
 
-    def _forward_chain(self, x, step):
+    def _forward_chain(self, x, step, step_b=None, split=None):
         w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
+        two = split is not None
+        if two and (self.abf is None or self.hcat is None or self.styl_gemm or self.v_sa is not None):
+            raise capi.RgError("two step groups: bf16 launch chain with the stylization pre-pass only")
         xa, xb, xc = self.xa, self.xb, self.xc
         sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c     # sa_: written by the embed GEMM (128-wide tiles)
         sa_w = self._st_a if self.tn else self.st_a           # ... and by every FFN-out GEMM (self.tn-wide tiles)
@@ -395,6 +417,8 @@ class DenoiserSession:
         self._guard_stats(sa_)
         for l, lw in enumerate(w.layers):
             ss = w.ss[step, l]
+            ssb = w.ss[step_b, l] if two else None
+            grp = (lambda bi: ([ssb[bi]], T, B, split)) if two else (lambda bi: None)
             # --- self attention
             qkv_seg = G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])
             if self.xa_bf is not None and self.v_sa is not None:
@@ -438,7 +462,7 @@ class DenoiserSession:
             elif self.abf is not None:
                 # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
                 # pre-pass instead of once per column tile and wave pair inside the GEMM's A prologue
-                G.stylize(h, [sa_seg], D, M, self.abf)
+                G.stylize(h, [sa_seg], D, M, self.abf, groups=grp(0))
                 # out2: bf16 copy of xb = 4th K-segment of the ca_mix GEMM's A operand
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
                        out2=self.hcat[:, 3 * D:], tile_n=tn)
@@ -470,8 +494,12 @@ class DenoiserSession:
                 if self.abf is not None:
                     # cross attention + LN/stylization/SiLU of its three outputs in one launch, straight into
                     # the bf16 A operand of the ca_mix GEMM (classifier-free rows: the (step, layer) table)
-                    h.call("ca_stylize", self.q3, self.a_pre_t[l], self.qmask, lw["ca_sgs"], lw["ca_sbs"], ss[1:4],
-                           lw["unc_tab"][step], self.hcat, 4 * D, B, B, T, D, 3)
+                    if two:
+                        h.call("ca_stylize_groups", self.q3, self.a_pre_t[l], self.qmask, lw["ca_sgs"], lw["ca_sbs"], ss[1:4],
+                               lw["unc_tab"][step], self.hcat, 4 * D, B, B, T, D, 3, ssb[1:4], lw["unc_tab"][step_b], split)
+                    else:
+                        h.call("ca_stylize", self.q3, self.a_pre_t[l], self.qmask, lw["ca_sgs"], lw["ca_sbs"], ss[1:4],
+                               lw["unc_tab"][step], self.hcat, 4 * D, B, B, T, D, 3)
                 else:
                     h.call("ca_attention", self.q3, self.a_pre[l], None, self.qmask_c, self.y3, self.st3c, B, B, T, D, 3,
                            self.perm_cac, self.perm_cac.numel())
@@ -513,7 +541,7 @@ class DenoiserSession:
                 sa_ = sa_w
                 self._guard_stats(sa_)
             elif self.abf is not None:
-                G.stylize(h, [ff_seg], D, M, self.abf)
+                G.stylize(h, [ff_seg], D, M, self.abf, groups=grp(4))
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_w,
                        out2=self.xa_bf, tile_n=tn)
                 sa_ = sa_w   # the next layer's QKV reads the statistics in this tile split
@@ -533,6 +561,14 @@ class DenoiserSession:
         wc, wu = sch.cfg_weights(w.cfg["scale_func_cfg"], step)
         self.h.call("cfg_ddim_update", self.head, x, x_out, x0_out, w.js, self.B, w.T, w.D, wc, wu,
                     float(sch.c_recip[step]), float(sch.c_recipm1[step]), float(c_a), float(c_b))
+
+    def cfg_ddim_rows(self, b0, nb, x, x_out, step, c_a, c_b, x_out2=None):
+        """cfg_ddim for the clips [b0, b0 + nb) of the batch: x / x_out [nb,T,D] (x_out may alias x), x_out2 an optional
+        second copy of the result."""
+        w, sch, T = self.w, self.w.schedule, self.w.T
+        wc, wu = sch.cfg_weights(w.cfg["scale_func_cfg"], step)
+        self.h.call("cfg_ddim_update_rows", self.head[b0 * T:], self.head[(self.B + b0) * T:], x, x_out, x_out2, w.js, nb, T, w.D,
+                    wc, wu, float(sch.c_recip[step]), float(sch.c_recipm1[step]), float(c_a), float(c_b))
 
     def cfg_ddpm(self, x, x_out, step, noise):
         """CFG mix of self.head + one ancestral step (inference_type="ddpm"; gaussian_diffusion.py:795-803)."""

@@ -136,8 +136,10 @@ def gemm(h, stream=None, **kw):
     launch(h, make_desc(**kw), stream)
 
 
-def stylize(h, segs, seg_len, M, out, stream=None, m_cond=None, unc_nseg=0, unc_tab=None, qmask=None):
-    """rg_stylize: materialise the fp32->bf16 A prologue of `segs` once into out [M, nseg*seg_len] bf16."""
+def stylize(h, segs, seg_len, M, out, stream=None, m_cond=None, unc_nseg=0, unc_tab=None, qmask=None, groups=None):
+    """rg_stylize: materialise the fp32->bf16 A prologue of `segs` once into out [M, nseg*seg_len] bf16.
+    groups = (scale_shift_b per segment, T, nseq, split): rows are [2][nseq][T]; sequences >= split take scale_shift_b
+    (two diffusion steps in one batch, rg_stylize_groups)."""
     arr = (ASegment * MAX_SEG)()
     for i, sg in enumerate(segs):
         e = arr[i]
@@ -149,9 +151,15 @@ def stylize(h, segs, seg_len, M, out, stream=None, m_cond=None, unc_nseg=0, unc_
         if sg.mode == A_STYL:
             e.scale_shift = _p(sg.ss, torch.float32)
     s = torch.cuda.current_stream().cuda_stream if stream is None else stream
-    rc = h.lib.rg_stylize(h._h, arr, len(segs), seg_len, M, ctypes.c_void_p(_p(out, torch.bfloat16)), out.stride(-2),
-                          M if m_cond is None else m_cond, unc_nseg,
-                          ctypes.c_void_p(_p(unc_tab, torch.bfloat16) if unc_tab is not None else None),
-                          ctypes.c_void_p(_p(qmask, torch.float32) if qmask is not None else None), ctypes.c_void_p(s))
+    fixed = (h._h, arr, len(segs), seg_len, M, ctypes.c_void_p(_p(out, torch.bfloat16)), out.stride(-2),
+             M if m_cond is None else m_cond, unc_nseg,
+             ctypes.c_void_p(_p(unc_tab, torch.bfloat16) if unc_tab is not None else None),
+             ctypes.c_void_p(_p(qmask, torch.float32) if qmask is not None else None))
+    if groups is None:
+        rc = h.lib.rg_stylize(*fixed, ctypes.c_void_p(s))
+    else:
+        ss_b, T, nseq, split = groups
+        ptrs = (ctypes.c_void_p * len(segs))(*[_p(t, torch.float32) for t in ss_b])
+        rc = h.lib.rg_stylize_groups(*fixed, ptrs, T, nseq, split, ctypes.c_void_p(s))
     if rc != 0:
         raise capi.RgError("rg_stylize failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))

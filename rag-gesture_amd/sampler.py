@@ -72,6 +72,34 @@ def ddim_guided_sample_loop(sess, x, inverted, guidance_iters, guidance_lr, inse
     return x
 
 
+def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None, guidance_lr=0.1, inseq_noise_a=None,
+                   in_seq_a=None):
+    """Two loops advancing in the same launches, one denoiser forward per step for both:
+      clips [0, n_a) of the session: the (insertion-guided) DDIM sampling loop of one batch, exactly
+        ddim_guided_sample_loop / ddim_sample_loop (inverted_a None) on x_all[:n_a], in place;
+      clips [n_a, B): the DDIM inversion of the NEXT batch's exemplars, exactly ddim_reverse_sample_loop on x_all[n_a:]:
+        out_b [S, B - n_a, T, D] receives every level.
+    Step k runs the sampling at respaced index S-1-k and the inversion at index k.  Rows of a batch never mix in any
+    kernel, so each group gets what its own loop would give; the point is the launch count and size: a forward over
+    M = 2 (8 + 24) 43 rows costs ~1.1x the forward over the 24 exemplars alone."""
+    sch, w, h = sess.w.schedule, sess.w, sess.h
+    S, B, T, D = sch.num_timesteps, sess.B, w.T, w.D
+    n_b = B - n_a
+    xa, xb = x_all[:n_a], x_all[n_a:]
+    in_seq = in_seq_a
+    for k in range(S):
+        i = S - 1 - k
+        if inverted_a is not None and i != S - 1:
+            in_seq = inverted_a[i]
+            h.call("guidance_update", xa, in_seq, n_a * T, D, int(guidance_iters[i]), float(guidance_lr))
+        if in_seq is not None:
+            h.call("inseq_replace", xa, in_seq, inseq_noise_a[i], n_a * T, D, float(sch.s_ab[i]), float(sch.s_1mab[i]))
+        sess.forward(x_all, i, step_b=k, split=n_a)
+        sess.cfg_ddim_rows(0, n_a, xa, xa, i, sch.c_prev_a[i], sch.c_prev_b[i])
+        sess.cfg_ddim_rows(n_a, n_b, xb, xb, k, sch.c_next_a[k], sch.c_next_b[k], x_out2=out_b[k])
+    return x_all, out_b
+
+
 class GraphedLoop:
     """Capture fn() (a fixed launch sequence over static buffers) into a HIP graph and replay it.
     torch.cuda.CUDAGraph is used purely as the capture/replay plumbing."""
