@@ -25,6 +25,7 @@ import contextlib
 import copy
 import os
 import time
+import types
 
 import torch
 import yaml
@@ -241,7 +242,9 @@ class MotionDiffusion(torch.nn.Module):
         self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
         # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
-        self._slot, self._inflight, self._graph_owner = 0, collections.deque(), {}
+        self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
+        # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
+        self._pend, self._cob = None, None
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
@@ -522,10 +525,13 @@ class MotionDiffusion(torch.nn.Module):
         # busy with the previous batch's chain
         run_async = self.async_results and self.slots > 1 and not getattr(self, "profile_phases", False)
         self._slot = (self._slot + 1) % self.slots if run_async else 0
+        if run_async and self._slot_done.get(self._slot) is not None:
+            main.wait_event(self._slot_done[self._slot])    # the chain that last used this slot's sessions / graph buffers
         gre.concurrent_parts(not run_async)   # one launch chain per VAE graph when graphs are queued behind a running batch
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
+        cob = self._cob if run_async else None      # submit(): this batch's sampling is deferred to the next call
         with self._phase("conditions"):
-            for lane, stream, b0, b1 in plan_s:
+            for lane, stream, b0, b1 in ([] if cob is not None else plan_s):
                 cstream = main if run_async else stream
                 cstream.wait_stream(main)
                 with torch.cuda.stream(cstream):
@@ -638,32 +644,68 @@ class MotionDiffusion(torch.nn.Module):
         elif not isinstance(tape, _TorchNoise) and not ddpm:
             for _ in range(S):
                 tape.draw((B, T, D))
-        x_out = torch.empty(B, T, D, device=dev)
-        vis_inv, vis_pairs = [], []   # visualize_inversion: per exemplar all levels [S,T,D] and (start, reconstruction)
+        # everything the later phases need, so that the sampling and the tail of this batch can also run in a LATER call
+        # (submit / flush: its sampling then shares launches with the next batch's inversion)
+        st = types.SimpleNamespace(
+            B=B, T=T, D=D, S=S, n_lat=n_lat, plan=plan, plan_s=plan_s, main=main, run_async=run_async, results=results,
+            retrieval_dict=retrieval_dict, x=x, start_noise=start_noise, invl=invl, in_seq=in_seq, inseq_noise=inseq_noise,
+            ddpm=ddpm, ddpm_noise=ddpm_noise, x_out=torch.empty(B, T, D, device=dev), use_inversion=use_inversion,
+            use_insertion_guidance=use_insertion_guidance, guidance_iters=guidance_iters, guidance_lr=guidance_lr,
+            visualize_inversion=visualize_inversion, inversion_start_time=inversion_start_time, vis_inv=[], vis_pairs=[],
+            word=word, audio=audio, spk=spk, motion_mask=motion_mask, qmask=qmask, early_cond=early_cond,
+            use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot)
+        if cob is not None:
+            return self._submit_chain(st)
+        self._inversion_pass(st)
+        self._sampling_pass(st)
+        return self._tail(st)
 
-        # ---- lanes: [exemplar inversion -> splice -> sampling] per clip group, concurrently
-        for lane, stream, b0, b1 in plan:
-            Bl = b1 - b0
-            stream.wait_stream(main)
-            self._used_on(stream, start_noise, invl, qmask)
+    # ------------------------------------------------------------------ phases of forward (after the front end)
+    def _exemplars(self, st, b0, b1):
+        return [(b, q) for b in range(b0, b1) for q in st.retrieval_dict["retr_uncropped_latents"][b].keys()]
+
+    def _exemplar_inputs(self, st, ex, stream):
+        """(Ep, cat): cat(key) = the lane's exemplars' `key` tensors stacked and padded to the Ep bucket."""
+        dev = self.device
+        Ep = bucket(len(ex))
+        lat = lambda b, q: st.retrieval_dict["retr_uncropped_latents"][b][q]
+
+        def cat(key):
+            parts = [lat(b, q)[key].to(dev) for b, q in ex]
+            self._used_on(stream, *parts)
+            return pad_rows(torch.cat(parts, dim=0), Ep)
+        return Ep, cat
+
+    def _splice(self, st, ex, inv, Ep):
+        """The inverted exemplar rows into the start noise (and, level by level, into the guidance target)."""
+        h, rd = self.model.weights.h, st.retrieval_dict
+        for e, (b, q_idx) in enumerate(ex):
+            r0, r1 = rd["retr_startends"][b][q_idx]
+            q0, q1 = rd["query_startends"][b][q_idx]
+            assert r1 - r0 == q1 - q0
+            lvl = st.inversion_start_time % st.S
+            h.call("splice_rows", inv[lvl], st.start_noise, st.T, st.D, st.n_lat, e, b, r0, r1, q0, q1)
+            if st.use_insertion_guidance:
+                h.call("splice_rows_rep", inv, st.invl, st.T, st.D, st.n_lat, e, b, r0, r1, q0, q1, st.S, Ep, st.B)
+
+    def _inversion_pass(self, st):
+        """lanes: exemplar inversion -> splice, per clip group, concurrently."""
+        dev, S, T, D = self.device, st.S, st.T, st.D
+        for lane, stream, b0, b1 in st.plan:
+            stream.wait_stream(st.main)
+            self._used_on(stream, st.start_noise, st.invl, st.qmask)
             with torch.cuda.stream(stream):
-                if use_inversion:
-                    ex = [(b, q_idx) for b in range(b0, b1) for q_idx in retrieval_dict["retr_uncropped_latents"][b].keys()]
+                if st.use_inversion:
+                    ex = self._exemplars(st, b0, b1)
                     if ex:
                         # the lane's E exemplars run as a batch of Ep = E rounded up (padding = copies of exemplar 0,
                         # inverted and dropped): sessions, condition graphs and inversion graphs exist per Ep only
                         E = len(ex)
-                        Ep = bucket(E)
-                        lat = lambda b, q: retrieval_dict["retr_uncropped_latents"][b][q]
-
-                        def cat(key, stream=stream):
-                            parts = [lat(b, q)[key].to(dev) for b, q in ex]
-                            self._used_on(stream, *parts)
-                            return pad_rows(torch.cat(parts, dim=0), Ep)
+                        Ep, cat = self._exemplar_inputs(st, ex, stream)
                         esess = self._session(Ep, "invert", lane)
                         with self._phase("exemplar_conditions"):
-                            if early_cond.get(lane) != E:   # not already projected while the exemplars were encoded
-                                eqm = {c: pad_rows(torch.stack([qmask[b] for b, _ in ex]), Ep) for c in denoiser.CONDS}
+                            if st.early_cond.get(lane) != E:   # not already projected while the exemplars were encoded
+                                eqm = {c: pad_rows(torch.stack([st.qmask[b] for b, _ in ex]), Ep) for c in denoiser.CONDS}
                                 self._set_conditions(Ep, "invert", lane, cat("retr_text"), cat("retr_audio"), cat("retr_spkid"),
                                                      cat("retr_motion_mask"), eqm)
                             x_e = cat("retr_motion_latent").float().contiguous()
@@ -671,46 +713,42 @@ class MotionDiffusion(torch.nn.Module):
                             (inv,) = self._graph_run(("invert", Ep, lane, T, self._slot), dict(x=x_e), lambda s, esess=esess, Ep=Ep: (
                                 sampler.ddim_reverse_sample_loop(esess, s["x"], torch.empty(S, Ep, T, D, device=dev)),),
                                 owner=(Ep, "invert", lane, self._slot))
-                        for e, (b, q_idx) in enumerate(ex):
-                            r0, r1 = retrieval_dict["retr_startends"][b][q_idx]
-                            q0, q1 = retrieval_dict["query_startends"][b][q_idx]
-                            assert r1 - r0 == q1 - q0
-                            lvl = inversion_start_time % S
-                            h.call("splice_rows", inv[lvl], start_noise, T, D, n_lat, e, b, r0, r1, q0, q1)
-                            if use_insertion_guidance:
-                                h.call("splice_rows_rep", inv, invl, T, D, n_lat, e, b, r0, r1, q0, q1, S, Ep, B)
-                        if visualize_inversion:
+                        self._splice(st, ex, inv, Ep)
+                        if st.visualize_inversion:
                             # sanity check of the reference (diffusion_architecture.py:357-382): every inversion level
                             # and the DDIM reconstruction from the last level, decoded after the sampling below
                             (rec,) = self._graph_run(("recon", Ep, lane, T, self._slot), dict(x=inv[S - 1]), lambda s, esess=esess: (
                                 sampler.ddim_sample_loop(esess, s["x"]),), owner=(Ep, "invert", lane, self._slot))
                             for e in range(E):
-                                vis_inv.append(inv[:, e])
-                                vis_pairs.append(torch.stack([x_e[e], rec[e]]))
-                    if use_insertion_guidance and use_prev_latent and prev_latent is not None:
-                        for idx in (up_i, ha_i, fa_i, lt_i):
-                            invl[:, b0:b1, idx[0], :] = 0
-        # second pass: the sampling loops.  Every lane's inversion is queued before the first sampling graph is
-        # launched (a graph launch costs the host ~1.5 ms: lane 1 would otherwise start 3 ms behind lane 0)
-        inverted = [(stream, stream.record_event()) for _, stream, _, _ in plan]
-        for lane, stream, b0, b1 in plan_s:
+                                st.vis_inv.append(inv[:, e])
+                                st.vis_pairs.append(torch.stack([x_e[e], rec[e]]))
+                    if st.use_insertion_guidance and st.use_prev_latent and st.prev_latent is not None:
+                        for idx in st.idx_groups:
+                            st.invl[:, b0:b1, idx[0], :] = 0
+
+    def _sampling_pass(self, st):
+        """The sampling loops.  Every lane's inversion is queued before the first sampling graph is launched (a graph
+        launch costs the host ~1.5 ms: lane 1 would otherwise start 3 ms behind lane 0)."""
+        T, x, in_seq, invl = st.T, st.x, st.in_seq, st.invl
+        inverted = [(stream, stream.record_event()) for _, stream, _, _ in st.plan]
+        for lane, stream, b0, b1 in st.plan_s:
             Bl = b1 - b0
             sess, okey = self._session(Bl, "sample", lane), (Bl, "sample", lane, self._slot)
-            stream.wait_stream(main)
-            self._used_on(stream, x, in_seq, inseq_noise, invl, ddpm_noise, x_out)
-            if plan_s != plan:                   # a sampling lane then reads rows spliced by several inversion lanes
+            stream.wait_stream(st.main)
+            self._used_on(stream, x, in_seq, st.inseq_noise, invl, st.ddpm_noise, st.x_out)
+            if st.plan_s != st.plan:             # a sampling lane then reads rows spliced by several inversion lanes
                 for other, ev in inverted:
                     if other is not stream:
                         stream.wait_event(ev)
             with torch.cuda.stream(stream):
                 sl = lambda t, dim: None if t is None else (t[b0:b1] if dim == 0 else t[:, b0:b1])
-                loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(inseq_noise, 1), invl=sl(invl, 1))
+                loop_in = dict(x=sl(x, 0), in_seq=sl(in_seq, 0), noise=sl(st.inseq_noise, 1), invl=sl(invl, 1))
                 with self._phase("sampling"):
-                    if ddpm:
-                        (xl,) = self._graph_run(("ddpm", Bl, lane, T, self._slot), dict(x=sl(x, 0), noise=sl(ddpm_noise, 1)),
+                    if st.ddpm:
+                        (xl,) = self._graph_run(("ddpm", Bl, lane, T, self._slot), dict(x=sl(x, 0), noise=sl(st.ddpm_noise, 1)),
                                                 lambda s, sess=sess: (sampler.p_sample_loop(sess, s["x"], s["noise"]),), owner=okey)
-                    elif use_insertion_guidance:
-                        gi, lr = tuple(int(v) for v in guidance_iters), float(guidance_lr)
+                    elif st.use_insertion_guidance:
+                        gi, lr = tuple(int(v) for v in st.guidance_iters), float(st.guidance_lr)
                         key = ("guided", Bl, lane, T, self._slot, in_seq is not None, gi, lr)
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess, gi=gi, lr=lr: (
                             sampler.ddim_guided_sample_loop(sess, s["x"], s["invl"], gi, lr, s["noise"], in_seq=s["in_seq"]),),
@@ -719,30 +757,32 @@ class MotionDiffusion(torch.nn.Module):
                         key = ("sample", Bl, lane, T, self._slot, in_seq is not None)
                         (xl,) = self._graph_run(key, loop_in, lambda s, sess=sess: (sampler.ddim_sample_loop(
                             sess, s["x"], in_seq=s["in_seq"], inseq_noise=s["noise"]),), owner=okey)
-                    x_out[b0:b1].copy_(xl)
-        # ---- tail: latent post-processing and VAE decode once every lane is done: on the caller's stream, or, with
-        # asynchronous submission (where that one is already queueing the next batch), on the first sampling lane's stream
-        tail = plan_s[0][1] if run_async else main
-        for _, stream, _, _ in plan + plan_s:
+                    st.x_out[b0:b1].copy_(xl)
+
+    def _tail(self, st):
+        """Latent post-processing and VAE decode once every lane is done: on the caller's stream, or, with asynchronous
+        submission (where that one is already queueing the next batch), on the first sampling lane's stream."""
+        gre, results, main, S, T, D, B = self.model.gesture_rep_encoder, st.results, st.main, st.S, st.T, st.D, st.B
+        tail = st.plan_s[0][1] if st.run_async else main
+        for _, stream, _, _ in st.plan + st.plan_s:
             if stream is not tail:
                 tail.wait_stream(stream)
-        self._used_on(tail, x_out, *vis_inv, *vis_pairs)
+        self._used_on(tail, st.x_out, *st.vis_inv, *st.vis_pairs)
         with torch.cuda.stream(tail):
-            x = x_out
-            output = self.model.post_process(x)
+            output = self.model.post_process(st.x_out)
             results["prev_latentout"] = output
             with self._phase("vae_decode"):
                 up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B, gre.part_streams is None), dict(z=output), lambda s: gre.decode(s["z"]))
             results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
             results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
             results["pred_contact"] = co
-            if use_inversion and visualize_inversion and vis_inv:
+            if st.use_inversion and st.visualize_inversion and st.vis_inv:
                 # diffusion_architecture.py:488-571: decoded inversion levels [n_exemplars, S, frames, *] and decoded
                 # (exemplar, reconstruction) pairs [n_exemplars, 2, frames, *]
-                n_ex = len(vis_inv)
+                n_ex = len(st.vis_inv)
                 keys = ("upper", "lower", "facepose", "hands", "transl", "exps")
-                for name, lat, k in (("inverted_output", torch.stack(vis_inv).reshape(n_ex * S, T, D), S),
-                                     ("reconspair_output", torch.stack(vis_pairs).reshape(n_ex * 2, T, D), 2)):
+                for name, lat, k in (("inverted_output", torch.stack(st.vis_inv).reshape(n_ex * S, T, D), S),
+                                     ("reconspair_output", torch.stack(st.vis_pairs).reshape(n_ex * 2, T, D), 2)):
                     lat = self.model.post_process(lat.contiguous())
                     parts = [[] for _ in keys]
                     for c0 in range(0, lat.shape[0], 128):            # decoded in slabs of 128 like the reference (:496-528)
@@ -755,11 +795,12 @@ class MotionDiffusion(torch.nn.Module):
         done = torch.cuda.Event()
         done.record(tail)
         self._used_on(main, *[v for v in results.values() if torch.is_tensor(v)])   # the caller reads them on its stream
-        if run_async:
+        if st.run_async:
             # done_stream: where the results were produced; work queued there needs no wait (ROCm maps streams onto 4
             # hardware queues: a consumer stream of its own that waits for done_event can block whichever of the
             # caller's / search / lane streams shares its queue, and with it the next batch's front end)
             results["done_event"], results["done_stream"] = done, tail
+            self._slot_done[st.slot] = done
             self._inflight.append(done)
             while len(self._inflight) > self.max_inflight:
                 self._inflight.popleft().synchronize()
