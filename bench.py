@@ -98,7 +98,7 @@ def launch_ranks(n, argv, dry=False):
 class Workload:
     """One benchmark configuration: model + resident synthetic inputs + step()."""
 
-    def __init__(self, rg, kind, B, dev, rank, db_size, precision="bf16", database=None, clips=10, windows=3, pipelined=True):
+    def __init__(self, rg, kind, B, dev, rank, db_size, precision="bf16", database=None, clips=10, windows=3, pipelined=True, cobatch=True):
         self.rg, self.kind, self.B, self.dev, self.precision = rg, kind, B, dev, precision
         self.cfg = rg.synth.default_model_cfg(num_layers=8)
         self.vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
@@ -112,6 +112,8 @@ class Workload:
         self.model.load_state_dict(rg.synth.synth_full_state(0, self.cfg, self.vae_cfgs))
         self.model.eval()
         self.model.async_results = bool(pipelined) and kind != "longform"
+        # guided workload: the sampling loop of batch n shares its denoiser launches with the inversion of batch n + 1
+        self.cobatch = self.model.async_results and kind == "guided" and cobatch
         if kind == "longform":
             self.n_clips, self.windows = clips, windows
             n = 135 * windows   # hop 135: sample lengths in (135 (w - 1), 135 w] give w windows (longform_synthesis.py:262-265)
@@ -143,26 +145,43 @@ class Workload:
         d = dict(self.data)
         d["trans"] = self.trans0.clone()  # forward re-zeroes trans in place like the reference
         ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1) if self.guided else {}
-        out = self.model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
-        # asynchronous submission (model.async_results): the batch is only queued here; its packed result is assembled on
+        call = self.model.submit if self.cobatch else self.model
+        return self.pack(call(**dict(d, retrieval_method="discourse", inference_kwargs=ikw)))
+
+    def pack(self, out):
+        """The packed [B,150,268] result of a finished (or, with asynchronous submission, queued) batch; None while the
+        co-batched pipeline fills (submit() hands out the batch submitted one call earlier)."""
+        if out is None:
+            return None
+        # asynchronous submission (model.async_results): the batch is only queued; its packed result is assembled on
         # the stream the batch ends on, so the caller's stream is free for the next batch's front end
         with torch.cuda.stream(out.get("done_stream") or torch.cuda.current_stream()):
             return torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
                               out["pred_transl"], out["pred_exps"]], dim=-1)
 
-    def timed(self, steps, warmup, fence):
+    def drain(self):
+        """Finish whatever the co-batched pipeline still holds (the last batch's sampling loop)."""
+        return [self.pack(o) for o in self.model.flush()] if self.cobatch else []
+
+    def prime(self):
+        """Graph capture for every slot of the asynchronous pipeline (setup, like building the model): the W warm-up steps
+        and the K timed steps then only replay."""
         if not getattr(self, "primed", False):
-            # graph capture for every slot of the asynchronous pipeline (setup, like building the model): the W warm-up
-            # steps and the K timed steps below then only replay
-            for _ in range(self.model.slots if self.model.async_results else 1):
+            for _ in range((self.model.slots + 1 if self.cobatch else self.model.slots) if self.model.async_results else 1):
                 self.step()
+            self.drain()
             self.primed = True
+
+    def timed(self, steps, warmup, fence):
+        self.prime()
         for _ in range(warmup):
             self.step()
+        self.drain()
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step()
+        self.drain()     # the timed region holds `steps` complete batches: the pipeline fills and drains inside it
         fence()
         return time.perf_counter() - t0
 
@@ -176,14 +195,16 @@ class Workload:
         peak = MFMA_BF16_PEAK if variant == 1 else MFMA_BF16_PEAK / 3
 
         def events():
+            self.drain()
             model.use_graphs = False
             self.step()
             torch.cuda.synchronize()
             h.lib.rg_profile_begin(h._h)
-            self.step()
+            self.step()                 # (co-batched: the previous eager step's sampling + this one's inversion)
             model.use_graphs = True
             n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
             h.lib.rg_profile_end(h._h, variant, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
+            self.drain()
             return n.value, ms.value, fl.value
 
         n, ms, fl = events()
@@ -299,6 +320,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 16 guided, 32 base, 10 longform)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="synchronous forwards (results valid on the caller's stream) instead of asynchronous submission")
+    ap.add_argument("--no-cobatch", action="store_true",
+                    help="asynchronous submission without sharing launches between consecutive batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the additional single-GPU records (base, fp32 mode, longform)")
     ap.add_argument("--db-size", type=int, default=32768, help="retrieval DB entries (guided workload)")
@@ -335,7 +358,7 @@ def main():
     Workload.database_index = lambda self: self.model.model.database.index
     kind = args.workload
     B = args.batch or {"guided": 16, "base": 32, "longform": 10}[kind]
-    wl = Workload(rg, kind, B, dev, rank, args.db_size, clips=B, pipelined=not args.no_pipeline)
+    wl = Workload(rg, kind, B, dev, rank, args.db_size, clips=B, pipelined=not args.no_pipeline, cobatch=not args.no_cobatch)
     guided = kind == "guided"
 
     def fence():
@@ -343,20 +366,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
-        packed = wl.step()
+    def gather(packed):
         if dist is not None and packed is not None:  # the only collective on the path: final result gather (RCCL over xGMI)
             gathered = torch.empty(world * packed.shape[0], packed.shape[1], packed.shape[2], device=dev)
             dist.all_gather_into_tensor(gathered, packed.contiguous())
             return gathered
         return packed
 
+    def one_step():
+        return gather(wl.step())
+
+    def drain():      # co-batched pipeline: the last batch's sampling (every rank drains the same number of batches)
+        return [gather(p) for p in wl.drain()]
+
+    wl.prime()
     for _ in range(args.warmup):
         one_step()
+    drain()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    drain()           # the timed region holds exactly `steps` complete batches
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -442,9 +473,13 @@ def main():
                        "clips_per_gpu": B, "global_batch": world * B, "frames_per_clip": 150, "ddim_steps": 50,
                        "denoiser": "8 layers x 512, CFG x2 rows", "vae": "all_encoder, 8 layers, synthetic hparams",
                        "weights": "random-init at config shapes", "parallelism": "clip-sharded x%d" % world,
-                       "submission": ("asynchronous, %d slots: the front end (conditions, VAE encodes, retrieval) of batch n+1 and "
-                                      "the decode of batch n run beside the inversion -> sampling chain; every batch completes "
-                                      "inside the timed region" % wl.model.slots) if wl.model.async_results
+                       "submission": (("asynchronous, co-batched: the sampling loop of batch n and the exemplar inversion of batch "
+                                       "n+1 advance in the same denoiser launches (sampler.cobatched_loop), the front end of "
+                                       "batch n+1 runs beside them; the pipeline fills and drains inside the timed region, "
+                                       "which holds exactly `steps` complete batches") if wl.cobatch else
+                                      ("asynchronous, %d slots: the front end (conditions, VAE encodes, retrieval) of batch n+1 and "
+                                       "the decode of batch n run beside the inversion -> sampling chain; every batch completes "
+                                       "inside the timed region" % wl.model.slots)) if wl.model.async_results
                        else "synchronous forwards"},
             "roofline": roofline, "roofline_retrieval": roof_retr, "also": also or None, "cpu_baseline": cpu,
         }

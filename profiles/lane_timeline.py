@@ -58,7 +58,8 @@ def one_step(trace=False, sync=True):
         ev_step[0] = torch.cuda.Event(enable_timing=True)
         ev_step[0].record()
         t_step[0] = time.perf_counter()
-    out = model(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
+    call = model.submit if os.environ.get("COBATCH") else model
+    out = call(**dict(d, retrieval_method="discourse", inference_kwargs=ikw))
     t_host = (time.perf_counter() - t_step[0]) * 1e3
     if not sync:
         return t_host, None

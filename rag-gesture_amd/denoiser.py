@@ -369,9 +369,9 @@ class DenoiserSession:
                 raise capi.RgError("two step groups need the launch-chain engine")
             return self.pf.run(x.contiguous(), step)
         if self.ln_mode == "auto":
-            if split is not None:
-                raise capi.RgError("run one plain forward first (ln_mode='auto' settles on the session's first step)")
-            return self._forward_guarded(x, step)
+            out = self._forward_guarded(x, step)     # settles the mode (one read-back; never inside a capture)
+            if split is None:
+                return out
         return self._forward_chain(x, step, step_b, split)
 
     LN_GUARD_SIGMAS = 3.0   # |row mean| beyond this many standard deviations: the folded LayerNorm is not used

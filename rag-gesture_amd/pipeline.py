@@ -244,7 +244,7 @@ class MotionDiffusion(torch.nn.Module):
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
         self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
         # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
-        self._pend, self._cob = None, None
+        self._pend, self._cob, self._ready = None, None, collections.deque()
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
@@ -553,6 +553,8 @@ class MotionDiffusion(torch.nn.Module):
             K/V projections (text / audio / speaker of the retrieved samples) go to the lane streams meanwhile."""
             if not use_inversion or getattr(self, "profile_phases", False):
                 return
+            if cob is not None and self._pend is not None:
+                return      # co-batched with the pending batch's sampling: the conditions go into the shared sessions
             for lane, stream, b0, b1 in plan:
                 sel = [e for e, (b, _, _, placed) in enumerate(ex) if placed is not None and b0 <= b < b1]
                 if not sel:
@@ -659,6 +661,124 @@ class MotionDiffusion(torch.nn.Module):
         self._inversion_pass(st)
         self._sampling_pass(st)
         return self._tail(st)
+
+    # ------------------------------------------------------------------ co-batched pipeline
+    def submit(self, **kwargs):
+        """Queue a batch whose sampling is DEFERRED to the next call: its exemplars are inverted now, in the same denoiser
+        launches that run the sampling loop of the batch submitted before (sampler.cobatched_loop: a forward over the 8 clips
+        + 24 exemplars of a lane costs ~1.1x the forward over the exemplars alone).  Returns the results of the previous
+        batch (asynchronous: `done_event` / `done_stream`, see `wait_results`), or None while the pipeline fills;
+        `flush()` finishes what is pending.  Same arguments as forward(); needs async_results=True.  Batches that cannot
+        be co-batched (no inversion, a lane without exemplars, another batch size) are completed on their own."""
+        if not self.async_results or self.slots < 2:
+            raise capi.RgError("submit() needs MotionDiffusion(async_results=True, slots >= 2)")
+        self._cob = True
+        try:
+            self.forward(**kwargs)
+        finally:
+            self._cob = None
+        return self._ready.popleft() if self._ready else None
+
+    def flush(self):
+        """Finish the pending batch of submit() (its sampling loop alone) and return every result not handed out yet."""
+        st, self._pend = self._pend, None
+        if st is not None:
+            main = st.main = torch.cuda.current_stream()
+            self._slot = (self._slot + 1) % self.slots
+            if self._slot_done.get(self._slot) is not None:
+                main.wait_event(self._slot_done[self._slot])
+            st.slot = self._slot
+            for lane, stream, b0, b1 in st.plan_s:
+                self._set_conditions(b1 - b0, "sample", lane, st.word[b0:b1], st.audio[b0:b1], st.spk[b0:b1],
+                                     st.motion_mask[b0:b1], {c: st.qmask[b0:b1] for c in denoiser.CONDS})
+            self._sampling_pass(st)
+            self._ready.append(self._tail(st))
+        out = list(self._ready)
+        self._ready.clear()
+        return out
+
+    def _set_conditions_pair(self, sess, key, own, a, b, n_a):
+        """Conditions of a session that holds two batches side by side (clips [0, n_a): a, the rest: b), one graph."""
+        dev = self.model.weights.dev
+        ins = {}
+        for tag, (word, audio, spk, mask, qm) in (("a", a), ("b", b)):
+            ins["word_" + tag], ins["audio_" + tag] = word.to(dev).float(), audio.to(dev).float()
+            ins["spk_" + tag], ins["mask_" + tag] = spk.to(dev).long(), mask.to(dev).float()
+            for c in denoiser.CONDS:
+                ins["q_%s_%s" % (c, tag)] = qm[c].to(dev).float()
+
+        def run(st):
+            for tag, off, fin in (("a", 0, False), ("b", n_a, True)):
+                sess.set_conditions(st["word_" + tag], st["audio_" + tag], st["spk_" + tag], st["mask_" + tag],
+                                    {c: st["q_%s_%s" % (c, tag)] for c in denoiser.CONDS}, offset=off, finalize=fin)
+            return ()
+        self._graph_run(key + tuple(tuple(v.shape) for v in ins.values()), ins, run, owner=own)
+
+    def _submit_chain(self, st):
+        """Second half of a submit(): [sampling of the pending batch || inversion of this one] per lane, splice, tail of
+        the pending batch; this batch becomes the pending one."""
+        pend, S, T, D, dev = self._pend, st.S, st.T, st.D, self.device
+        lanes = [(lane, stream, b0, b1, self._exemplars(st, b0, b1)) for lane, stream, b0, b1 in st.plan] if st.use_inversion else []
+        can_defer = (st.use_inversion and not st.visualize_inversion and not st.ddpm and st.plan == st.plan_s
+                     and all(ex for *_, ex in lanes))
+        same = pend is not None and can_defer and (pend.B, pend.T) == (st.B, st.T) and \
+            [(b0, b1) for _, _, b0, b1 in pend.plan] == [(b0, b1) for _, _, b0, b1 in st.plan]
+        if pend is not None and not same:
+            self._ready.extend(self.flush())          # the pending batch finishes alone (in the other slot's sessions)
+            self._slot, pend = st.slot, None
+        if not can_defer:                              # nothing to share launches with later: complete it now
+            for lane, stream, b0, b1 in st.plan_s:
+                self._set_conditions(b1 - b0, "sample", lane, st.word[b0:b1], st.audio[b0:b1], st.spk[b0:b1],
+                                     st.motion_mask[b0:b1], {c: st.qmask[b0:b1] for c in denoiser.CONDS})
+            self._inversion_pass(st)
+            self._sampling_pass(st)
+            self._ready.append(self._tail(st))
+            return None
+        if pend is None:                               # the pipeline fills: inversion alone
+            self._inversion_pass(st)
+            self._pend = st
+            return None
+        main = st.main
+        guided = pend.use_insertion_guidance
+        gi, lr = tuple(int(v) for v in pend.guidance_iters), float(pend.guidance_lr)
+        work = []
+        for lane, stream, b0, b1, ex in lanes:         # front end (caller's stream): conditions of the shared sessions
+            Bl = b1 - b0
+            Ep, cat = self._exemplar_inputs(st, ex, main)
+            okey = (Bl + Ep, "cobatch", lane, self._slot)
+            sess = self._session(Bl + Ep, "cobatch", lane)
+            eqm = {c: pad_rows(torch.stack([st.qmask[b] for b, _ in ex]), Ep) for c in denoiser.CONDS}
+            self._set_conditions_pair(
+                sess, ("cond2", Bl, Ep, lane, self._slot), okey,
+                (pend.word[b0:b1], pend.audio[b0:b1], pend.spk[b0:b1], pend.motion_mask[b0:b1], {c: pend.qmask[b0:b1] for c in denoiser.CONDS}),
+                (cat("retr_text"), cat("retr_audio"), cat("retr_spkid"), cat("retr_motion_mask"), eqm), Bl)
+            work.append((lane, stream, b0, b1, ex, Ep, sess, okey, cat("retr_motion_latent").float().contiguous()))
+        for lane, stream, b0, b1, ex, Ep, sess, okey, x_e in work:
+            Bl = b1 - b0
+            stream.wait_stream(main)
+            self._used_on(stream, pend.x, pend.in_seq, pend.inseq_noise, pend.invl, pend.x_out, x_e, st.start_noise, st.invl, st.qmask)
+            with torch.cuda.stream(stream):
+                sl = lambda t, dim: None if t is None else (t[b0:b1] if dim == 0 else t[:, b0:b1])
+                ins = dict(xa=sl(pend.x, 0), in_seq=sl(pend.in_seq, 0), noise=sl(pend.inseq_noise, 1),
+                           invl=sl(pend.invl, 1) if guided else None, xb=x_e)
+
+                def loop(s, sess=sess, Bl=Bl, Ep=Ep):
+                    x_all = torch.cat([s["xa"], s["xb"]], dim=0).contiguous()
+                    out_b = torch.empty(S, Ep, T, D, device=dev)
+                    sampler.cobatched_loop(sess, x_all, Bl, out_b, inverted_a=s["invl"], guidance_iters=gi, guidance_lr=lr,
+                                           inseq_noise_a=s["noise"], in_seq_a=s["in_seq"])
+                    return x_all[:Bl], out_b
+                key = ("cobatch", Bl, Ep, lane, T, self._slot, guided, pend.in_seq is not None, gi, lr)
+                xl, inv = self._graph_run(key, ins, loop, owner=okey)
+                pend.x_out[b0:b1].copy_(xl)
+                self._splice(st, ex, inv, Ep)
+                if st.use_insertion_guidance and st.use_prev_latent and st.prev_latent is not None:
+                    for idx in st.idx_groups:
+                        st.invl[:, b0:b1, idx[0], :] = 0
+        pend.main, pend.slot = main, self._slot
+        self._ready.append(self._tail(pend))
+        self._pend = st
+        return None
 
     # ------------------------------------------------------------------ phases of forward (after the front end)
     def _exemplars(self, st, b0, b1):

@@ -80,3 +80,54 @@ def test_async_pipeline_equals_synchronous_forwards(rg, guided):
     out = run(0)
     assert "done_event" not in out
     assert torch.equal(out["pred_upper"], ref[0]["pred_upper"])
+
+
+def test_cobatched_pipeline_equals_synchronous_forwards(rg):
+    """submit() / flush(): the sampling loop of batch n advances in the same denoiser launches as the exemplar inversion
+    of batch n + 1 (shared sessions, two step groups per forward); a batch without exemplars in a lane or of another size
+    completes on its own.  Every batch must come out as from its own synchronous forward."""
+    dev = torch.device("cuda", 0)
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    db = rg.synth.SyntheticDataset(512, seed=11, device=dev, feat_device=dev)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=db, device=dev)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+    B, N = 4, 6
+    batches = _batches(rg, B, N, dev) + _batches(rg, 2, 1, dev)      # the last one has another batch size
+    kinds = ["guided", "guided", "guided", "inv", "guided", "base", "guided"]
+
+    def ikw(i):
+        k = dict(guided=dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1),
+                 inv=dict(use_inversion=True), base={})[kinds[i]]
+        return dict(k, noise_tape=rg.synth.NoiseTape(4000 + i))
+
+    def args(i):
+        d = dict(batches[i])
+        d["trans"] = batches[i]["trans"].clone()
+        return dict(d, retrieval_method="discourse", inference_kwargs=ikw(i))
+
+    ref = []
+    for i in range(len(batches)):
+        out = model(**args(i))
+        torch.cuda.synchronize()
+        ref.append({k: out[k].clone() for k in KEYS})
+    model.async_results = True
+    for rep in range(2):
+        got = []
+        for i in range(len(batches)):
+            out = model.submit(**args(i))
+            if out is not None:
+                with torch.cuda.stream(out["done_stream"]):
+                    got.append({k: out[k].clone() for k in KEYS})
+            del out
+        for out in model.flush():
+            with torch.cuda.stream(out["done_stream"]):
+                got.append({k: out[k].clone() for k in KEYS})
+        torch.cuda.synchronize()
+        assert len(got) == len(batches)
+        for i in range(len(batches)):
+            for k in KEYS:
+                assert got[i][k].shape == ref[i][k].shape, (i, k)
+                assert torch.equal(got[i][k], ref[i][k]), (rep, i, kinds[i], k, (got[i][k] - ref[i][k]).abs().max().item())
+    assert model.flush() == []
