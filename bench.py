@@ -113,7 +113,7 @@ class Workload:
         self.model.eval()
         self.model.async_results = bool(pipelined) and kind != "longform"
         # guided workload: the sampling loop of batch n shares its denoiser launches with the inversion of batch n + 1
-        self.cobatch = self.model.async_results and kind == "guided" and cobatch
+        self.cobatch = self.model.async_results and kind == "guided" and cobatch and precision == "bf16"
         if kind == "longform":
             self.n_clips, self.windows = clips, windows
             n = 135 * windows   # hop 135: sample lengths in (135 (w - 1), 135 w] give w windows (longform_synthesis.py:262-265)
@@ -167,9 +167,17 @@ class Workload:
         """Graph capture for every slot of the asynchronous pipeline (setup, like building the model): the W warm-up steps
         and the K timed steps then only replay."""
         if not getattr(self, "primed", False):
-            for _ in range((self.model.slots + 1 if self.cobatch else self.model.slots) if self.model.async_results else 1):
-                self.step()
-            self.drain()
+            # every (phase, slot) pair of the pipeline has a graph of its own (inversion alone while the pipeline fills,
+            # co-batched chain, sampling alone at the drain; slots alternate call by call): fill-and-drain sequences of odd
+            # and even length until no call captures anything new
+            seen, quiet, n = -1, 0, 2
+            while quiet < 2 and self.kind != "longform":
+                for _ in range(n if self.model.async_results else 1):
+                    self.step()
+                self.drain()
+                n = 5 - n
+                quiet = quiet + 1 if len(self.model._graphs) == seen else 0
+                seen = len(self.model._graphs)
             self.primed = True
 
     def timed(self, steps, warmup, fence):
@@ -314,8 +322,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check (no GPU): every rank prints the environment it was started with and exits")
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["guided", "base", "longform"], default="guided")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 16 guided, 32 base, 10 longform)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -433,7 +441,7 @@ def main():
         if guided:
             roof_retr = retrieval_roofline(rg, wl)
         if world == 1 and not args.no_also and guided:
-            def record(w, steps=3, warmup=1):
+            def record(w, steps=6, warmup=1):
                 d = w.timed(steps, warmup, torch.cuda.synchronize)
                 r = {"value": round(w.frames_per_step * steps / d, 1), "unit": "frames/s", "ms_per_step": round(d / steps * 1e3, 2),
                      "steps": steps, "warmup": warmup, "dtype": "bf16" if w.precision == "bf16" else "bf16x3 (fp32-equivalent)"}

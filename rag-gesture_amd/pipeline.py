@@ -719,7 +719,10 @@ class MotionDiffusion(torch.nn.Module):
         the pending batch; this batch becomes the pending one."""
         pend, S, T, D, dev = self._pend, st.S, st.T, st.D, self.device
         lanes = [(lane, stream, b0, b1, self._exemplars(st, b0, b1)) for lane, stream, b0, b1 in st.plan] if st.use_inversion else []
-        can_defer = (st.use_inversion and not st.visualize_inversion and not st.ddpm and st.plan == st.plan_s
+        so = self.session_options
+        groups_ok = (self.precision == "bf16" and so.get("engine") in (None, "chain") and not so.get("persistent")
+                     and so.get("styl_prepass", True) and not so.get("styl_in_gemm") and not so.get("sa_fused"))
+        can_defer = (groups_ok and st.use_inversion and not st.visualize_inversion and not st.ddpm and st.plan == st.plan_s
                      and all(ex for *_, ex in lanes))
         same = pend is not None and can_defer and (pend.B, pend.T) == (st.B, st.T) and \
             [(b0, b1) for _, _, b0, b1 in pend.plan] == [(b0, b1) for _, _, b0, b1 in st.plan]
