@@ -433,10 +433,13 @@ def main():
             # (profiles/r01e_pmc_gemm_traffic.txt explains how they were collected and corrected); null if absent
             roofline["traffic"] = None
             try:
-                with open(os.path.join(ROOT, "profiles", "r01e_pmc_gemm_traffic.json")) as f:
+                # (round 2: the shapes of a co-batched lane, M = 2752 rows; round 1: M = 1376 / 4128)
+                pmc = [p for p in (os.path.join(ROOT, "profiles", n) for n in
+                                   (("r02m_pmc_gemm_traffic.json",) if wl.cobatch else ()) + ("r01e_pmc_gemm_traffic.json",)) if os.path.exists(p)]
+                with open(pmc[0]) as f:
                     rows = json.load(f)
                 roofline["traffic"] = round(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows))
-            except (OSError, ValueError, KeyError, ZeroDivisionError):
+            except (OSError, ValueError, KeyError, ZeroDivisionError, IndexError):
                 pass
         if guided:
             roof_retr = retrieval_roofline(rg, wl)

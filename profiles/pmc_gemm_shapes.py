@@ -27,7 +27,7 @@ LAYER = [("qkv", 1.0, 3 * D, D, True, False), ("sa_out", 1.0, D, D, True, True),
          ("ffn_out", 1.0, D, D, True, True)]
 order = []
 keep = []
-for M0 in (1376, 4128):
+for M0 in [int(v) for v in os.environ.get("PMC_ROWS", "1376,4128").split(",")]:   # round 2 (co-batched lane): PMC_ROWS=2752
     for name, frac, N, K, f32out, copy in LAYER:
         M = int(M0 * frac)
         for r in range(REPS):

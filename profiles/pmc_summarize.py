@@ -13,7 +13,7 @@ def per_dispatch(path, counter):
     return [float(r["Counter_Value"]) for r in rows]
 
 
-def main(fetch_csv, write_csv, order_json):
+def main(fetch_csv, write_csv, order_json, out_json="profiles/r01e_pmc_gemm_traffic.json"):
     order = json.load(open(order_json))
     fetch, write = per_dispatch(fetch_csv, "FETCH_SIZE"), per_dispatch(write_csv, "WRITE_SIZE")
     assert len(fetch) == len(order) == len(write), (len(fetch), len(write), len(order))
@@ -30,8 +30,8 @@ def main(fetch_csv, write_csv, order_json):
         f, w = a["fetch"] / a["n"], a["write"] / a["n"]
         print("%-8s %6d %5d %5d | %12.2f %12.2f %12.2f | %.2f" % (name, M, N, K, f / 1e6, w / 1e6, a["alg"] / 1e6, (f + w) / a["alg"]))
         out.append(dict(name=name, M=M, N=N, K=K, fetch_bytes=f, write_bytes=w, algorithmic_bytes=a["alg"], flops=a["flops"]))
-    json.dump(out, open("profiles/r01e_pmc_gemm_traffic.json", "w"), indent=1)
+    json.dump(out, open(out_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
