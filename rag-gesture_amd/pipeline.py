@@ -244,7 +244,7 @@ class MotionDiffusion(torch.nn.Module):
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
         self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
         # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
-        self._pend, self._cob, self._ready = None, None, collections.deque()
+        self._pend, self._cob, self._ready, self._tail_turn = None, None, collections.deque(), 0
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
@@ -886,7 +886,9 @@ class MotionDiffusion(torch.nn.Module):
         """Latent post-processing and VAE decode once every lane is done: on the caller's stream, or, with asynchronous
         submission (where that one is already queueing the next batch), on the first sampling lane's stream."""
         gre, results, main, S, T, D, B = self.model.gesture_rep_encoder, st.results, st.main, st.S, st.T, st.D, st.B
-        tail = st.plan_s[0][1] if st.run_async else main
+        # (asynchronous: the lanes take turns, so that the decode does not always delay the same lane's next chain)
+        tail = st.plan_s[self._tail_turn % len(st.plan_s)][1] if st.run_async else main
+        self._tail_turn += 1
         for _, stream, _, _ in st.plan + st.plan_s:
             if stream is not tail:
                 tail.wait_stream(stream)
