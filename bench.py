@@ -444,15 +444,19 @@ def main():
         if guided:
             roof_retr = retrieval_roofline(rg, wl)
         if world == 1 and not args.no_also and guided:
-            def record(w, steps=6, warmup=1):
+            def record(w, steps=6, warmup=1, roof=True):
                 d = w.timed(steps, warmup, torch.cuda.synchronize)
                 r = {"value": round(w.frames_per_step * steps / d, 1), "unit": "frames/s", "ms_per_step": round(d / steps * 1e3, 2),
                      "steps": steps, "warmup": warmup, "dtype": "bf16" if w.precision == "bf16" else "bf16x3 (fp32-equivalent)"}
-                if w.kind != "longform":
+                if w.kind != "longform" and roof:
                     r["roofline"] = w.gemm_roofline(local_rank)
                 return r
             also["base_B32"] = dict(record(Workload(rg, "base", 32, dev, rank, args.db_size)),
                                     workload="base diffusion len150 DDIM-50 (no guidance), 32 clips (BASELINE config 2)")
+            if wl.model.async_results:
+                r = record(Workload(rg, "guided", B, dev, rank, args.db_size, database=wl.database, pipelined=False), roof=False)
+                also["guided_B16_synchronous"] = dict(r, workload="the headline workload as one synchronous forward per batch "
+                                                      "(results valid on the caller's stream at return, like the reference's tools)")
             also["guided_B16_fp32mode"] = dict(
                 record(Workload(rg, "guided", B, dev, rank, args.db_size, precision="fp32", database=wl.database)),
                 workload="the headline workload with bf16x3 split operands (~fp32 products): same-precision figure")
