@@ -374,28 +374,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def gather(packed):
-        if dist is not None and packed is not None:  # the only collective on the path: final result gather (RCCL over xGMI)
-            gathered = torch.empty(world * packed.shape[0], packed.shape[1], packed.shape[2], device=dev)
-            dist.all_gather_into_tensor(gathered, packed.contiguous())
-            return gathered
-        return packed
-
-    def one_step():
-        return gather(wl.step())
-
-    def drain():      # co-batched pipeline: the last batch's sampling (every rank drains the same number of batches)
-        return [gather(p) for p in wl.drain()]
+    def run_steps(n):
+        """n batches through the pipeline; then, like the reference's multi-GPU test loop (mogen/apis/test.py:129-160: every
+        rank runs its shard of the clips, `collect_results_gpu` gathers ONCE at the end), one all-gather of this rank's
+        packed results -- the only collective on the path (RCCL over xGMI).  Inside the timed region."""
+        packed = [p for p in (wl.step() for _ in range(n)) if p is not None]
+        packed += [p for p in wl.drain() if p is not None]   # co-batched pipeline: the last batch's sampling
+        if dist is None or not packed:
+            return packed
+        torch.cuda.synchronize()          # the results sit on the lanes' streams; the collective runs beside the caller's
+        mine = torch.cat(packed, dim=0)
+        gathered = torch.empty(world * mine.shape[0], mine.shape[1], mine.shape[2], device=dev)
+        dist.all_gather_into_tensor(gathered, mine)
+        return gathered
 
     wl.prime()
-    for _ in range(args.warmup):
-        one_step()
-    drain()
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    drain()           # the timed region holds exactly `steps` complete batches
+    run_steps(args.steps)     # the timed region holds exactly `steps` complete batches
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
