@@ -657,6 +657,9 @@ class MotionDiffusion(torch.nn.Module):
             word=word, audio=audio, spk=spk, motion_mask=motion_mask, qmask=qmask, early_cond=early_cond,
             use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot)
         if cob is not None:
+            # the conditions of this batch's clips are projected in the NEXT call (into the sessions it shares with that
+            # batch's exemplars): private copies, the caller may reuse its input buffers meanwhile
+            st.word, st.audio, st.spk = (t.to(dev).clone() for t in (word, audio, spk))
             return self._submit_chain(st)
         self._inversion_pass(st)
         self._sampling_pass(st)
