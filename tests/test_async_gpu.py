@@ -131,3 +131,8 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg):
                 assert got[i][k].shape == ref[i][k].shape, (i, k)
                 assert torch.equal(got[i][k], ref[i][k]), (rep, i, kinds[i], k, (got[i][k] - ref[i][k]).abs().max().item())
     assert model.flush() == []
+    # the pipeline is an asynchronous-mode feature
+    model.async_results = False
+    with pytest.raises(rg.capi.RgError):
+        model.submit(**args(0))
+    assert model.flush() == []
