@@ -525,8 +525,9 @@ class MotionDiffusion(torch.nn.Module):
         # busy with the previous batch's chain
         run_async = self.async_results and self.slots > 1 and not getattr(self, "profile_phases", False)
         self._slot = (self._slot + 1) % self.slots if run_async else 0
-        if run_async and self._slot_done.get(self._slot) is not None:
-            main.wait_event(self._slot_done[self._slot])    # the chain that last used this slot's sessions / graph buffers
+        if run_async:
+            for ev in self._slot_done.get(self._slot, ()):   # the chain that last used this slot's sessions / graph buffers
+                main.wait_event(ev)
         gre.concurrent_parts(not run_async)   # one launch chain per VAE graph when graphs are queued behind a running batch
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
         cob = self._cob if run_async else None      # submit(): this batch's sampling is deferred to the next call
@@ -688,8 +689,8 @@ class MotionDiffusion(torch.nn.Module):
         if st is not None:
             main = st.main = torch.cuda.current_stream()
             self._slot = (self._slot + 1) % self.slots
-            if self._slot_done.get(self._slot) is not None:
-                main.wait_event(self._slot_done[self._slot])
+            for ev in self._slot_done.get(self._slot, ()):
+                main.wait_event(ev)
             st.slot = self._slot
             for lane, stream, b0, b1 in st.plan_s:
                 self._set_conditions(b1 - b0, "sample", lane, st.word[b0:b1], st.audio[b0:b1], st.spk[b0:b1],
@@ -742,6 +743,7 @@ class MotionDiffusion(torch.nn.Module):
             return None
         if pend is None:                               # the pipeline fills: inversion alone
             self._inversion_pass(st)
+            self._slot_done[st.slot] = [stream.record_event() for _, stream, _, _ in st.plan]   # (no tail marks this slot's use)
             self._pend = st
             return None
         main = st.main
@@ -928,7 +930,7 @@ class MotionDiffusion(torch.nn.Module):
             # hardware queues: a consumer stream of its own that waits for done_event can block whichever of the
             # caller's / search / lane streams shares its queue, and with it the next batch's front end)
             results["done_event"], results["done_stream"] = done, tail
-            self._slot_done[st.slot] = done
+            self._slot_done[st.slot] = [done]
             self._inflight.append(done)
             while len(self._inflight) > self.max_inflight:
                 self._inflight.popleft().synchronize()
