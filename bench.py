@@ -406,7 +406,9 @@ def main():
         # phase walls need device syncs at phase boundaries, which serialise concurrent lanes: the breakdown is taken
         # on a single lane (one warm-up step captures its graphs), the timed run above used model.lanes lanes
         model = wl.model
+        wl.drain()
         lanes_prod, model.lanes = model.lanes, 1
+        mode_prod, wl.cobatch, model.async_results = (wl.cobatch, model.async_results), False, False   # synchronous forwards
         wl.step()
         model.profile_phases, model.phase_ms = True, {}
         if guided:
@@ -417,6 +419,7 @@ def main():
         if guided:
             model.model.database.phase_ms = None
         model.lanes = lanes_prod
+        wl.cobatch, model.async_results = mode_prod
         print("phase breakdown (ms, one synchronised single-lane step; the timed run used %d lanes): " % lanes_prod +
               ", ".join("%s %.1f" % kv for kv in model.phase_ms.items()), file=sys.stderr)
 
