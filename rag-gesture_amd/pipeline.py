@@ -221,7 +221,7 @@ class MotionDiffusion(torch.nn.Module):
                  diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
-                 vae_options=None, async_results=False, slots=2, max_inflight=2, **kwargs):
+                 vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -245,7 +245,11 @@ class MotionDiffusion(torch.nn.Module):
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
         self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
         # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
-        self._pend, self._cob, self._ready, self._tail_turn = None, None, collections.deque(), 0
+        # (one pipeline per lane when whole batches alternate between the lanes, cobatch_lanes="batch"; else one, key None)
+        self._pend, self._cob, self._ready, self._tail_turn = {}, None, collections.deque(), 0
+        self._slots, self._submitted = {}, 0
+        self.cobatch_lanes = str(cobatch_lanes)
+        assert self.cobatch_lanes in ("batch", "split")
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
@@ -525,13 +529,16 @@ class MotionDiffusion(torch.nn.Module):
         # up to the lanes) stays on the caller's stream and the search stream, because the lane streams may still be
         # busy with the previous batch's chain
         run_async = self.async_results and self.slots > 1 and not getattr(self, "profile_phases", False)
-        self._slot = (self._slot + 1) % self.slots if run_async else 0
-        if run_async:
-            for ev in self._slot_done.get(self._slot, ()):   # the chain that last used this slot's sessions / graph buffers
-                main.wait_event(ev)
+        cob = self._cob if run_async else None      # submit(): this batch's sampling is deferred to a later call
+        pid = None
+        if cob is not None and cob.get("lane") is not None:
+            # whole batches alternate between the lanes: this one runs (inversion now, sampling two calls later) on one
+            # lane's stream, the batch submitted before it is still busy on the other
+            pid = cob["lane"] % len(plan)
+            plan = plan_s = [(pid, plan[pid][1], 0, B)]
+        self._slot = self._take_slot(pid, main) if run_async else 0
         gre.concurrent_parts(not run_async)   # one launch chain per VAE graph when graphs are queued behind a running batch
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
-        cob = self._cob if run_async else None      # submit(): this batch's sampling is deferred to the next call
         with self._phase("conditions"):
             for lane, stream, b0, b1 in ([] if cob is not None else plan_s):
                 cstream = main if run_async else stream
@@ -555,7 +562,7 @@ class MotionDiffusion(torch.nn.Module):
             K/V projections (text / audio / speaker of the retrieved samples) go to the lane streams meanwhile."""
             if not use_inversion or getattr(self, "profile_phases", False):
                 return
-            if cob is not None and self._pend is not None:
+            if cob is not None and self._pend.get(pid) is not None:
                 return      # co-batched with the pending batch's sampling: the conditions go into the shared sessions
             for lane, stream, b0, b1 in plan:
                 sel = [e for e, (b, _, _, placed) in enumerate(ex) if placed is not None and b0 <= b < b1]
@@ -657,7 +664,7 @@ class MotionDiffusion(torch.nn.Module):
             use_insertion_guidance=use_insertion_guidance, guidance_iters=guidance_iters, guidance_lr=guidance_lr,
             visualize_inversion=visualize_inversion, inversion_start_time=inversion_start_time, vis_inv=[], vis_pairs=[],
             word=word, audio=audio, spk=spk, motion_mask=motion_mask, qmask=qmask, early_cond=early_cond,
-            use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot)
+            use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot, pid=pid, seq=self._submitted)
         if cob is not None:
             # the conditions of this batch's clips are projected in the NEXT call (into the sessions it shares with that
             # batch's exemplars): private copies, the caller may reuse its input buffers meanwhile
@@ -666,6 +673,14 @@ class MotionDiffusion(torch.nn.Module):
         self._inversion_pass(st)
         self._sampling_pass(st)
         return self._tail(st)
+
+    def _take_slot(self, pid, main):
+        """Next set of sessions / graph buffers of pipeline `pid`; the caller's stream waits for the chain that used it last."""
+        slot = self._slots[pid] = (self._slots.get(pid, 0) + 1) % self.slots
+        for ev in self._slot_done.get((pid, slot), ()):
+            main.wait_event(ev)
+        self._slot = slot
+        return slot
 
     # ------------------------------------------------------------------ co-batched pipeline
     def submit(self, **kwargs):
@@ -677,7 +692,8 @@ class MotionDiffusion(torch.nn.Module):
         be co-batched (no inversion, a lane without exemplars, another batch size) are completed on their own."""
         if not self.async_results or self.slots < 2:
             raise capi.RgError("submit() needs MotionDiffusion(async_results=True, slots >= 2)")
-        self._cob = True
+        self._cob = dict(lane=self._submitted if (self.cobatch_lanes == "batch" and self.lanes > 1) else None)
+        self._submitted += 1
         try:
             self.forward(**kwargs)
         finally:
@@ -685,22 +701,23 @@ class MotionDiffusion(torch.nn.Module):
         return self._ready.popleft() if self._ready else None
 
     def flush(self):
-        """Finish the pending batch of submit() (its sampling loop alone) and return every result not handed out yet."""
-        st, self._pend = self._pend, None
-        if st is not None:
-            main = st.main = torch.cuda.current_stream()
-            self._slot = (self._slot + 1) % self.slots
-            for ev in self._slot_done.get(self._slot, ()):
-                main.wait_event(ev)
-            st.slot = self._slot
-            for lane, stream, b0, b1 in st.plan_s:
-                self._set_conditions(b1 - b0, "sample", lane, st.word[b0:b1], st.audio[b0:b1], st.spk[b0:b1],
-                                     st.motion_mask[b0:b1], {c: st.qmask[b0:b1] for c in denoiser.CONDS})
-            self._sampling_pass(st)
-            self._ready.append(self._tail(st))
+        """Finish the pending batches of submit() (their sampling loops alone) and return every result not handed out yet,
+        in submission order."""
+        for pid in sorted(self._pend, key=lambda p: self._pend[p].seq):
+            self._ready.append(self._finish_alone(self._pend.pop(pid)))
         out = list(self._ready)
         self._ready.clear()
         return out
+
+    def _finish_alone(self, st):
+        """Sampling loop + tail of a batch whose exemplars are already inverted and spliced."""
+        main = st.main = torch.cuda.current_stream()
+        st.slot = self._take_slot(st.pid, main)
+        for lane, stream, b0, b1 in st.plan_s:
+            self._set_conditions(b1 - b0, "sample", lane, st.word[b0:b1], st.audio[b0:b1], st.spk[b0:b1],
+                                 st.motion_mask[b0:b1], {c: st.qmask[b0:b1] for c in denoiser.CONDS})
+        self._sampling_pass(st)
+        return self._tail(st)
 
     def _set_conditions_pair(self, sess, key, own, a, b, n_a):
         """Conditions of a session that holds two batches side by side (clips [0, n_a): a, the rest: b), one graph."""
@@ -722,7 +739,7 @@ class MotionDiffusion(torch.nn.Module):
     def _submit_chain(self, st):
         """Second half of a submit(): [sampling of the pending batch || inversion of this one] per lane, splice, tail of
         the pending batch; this batch becomes the pending one."""
-        pend, S, T, D, dev = self._pend, st.S, st.T, st.D, self.device
+        pend, S, T, D, dev = self._pend.get(st.pid), st.S, st.T, st.D, self.device
         lanes = [(lane, stream, b0, b1, self._exemplars(st, b0, b1)) for lane, stream, b0, b1 in st.plan] if st.use_inversion else []
         so = self.session_options
         groups_ok = (self.precision == "bf16" and so.get("engine") in (None, "chain") and not so.get("persistent")
@@ -732,9 +749,13 @@ class MotionDiffusion(torch.nn.Module):
         same = pend is not None and can_defer and (pend.B, pend.T) == (st.B, st.T) and \
             [(b0, b1) for _, _, b0, b1 in pend.plan] == [(b0, b1) for _, _, b0, b1 in st.plan]
         if pend is not None and not same:
-            self._ready.extend(self.flush())          # the pending batch finishes alone (in the other slot's sessions)
-            self._slot, pend = st.slot, None
-        if not can_defer:                              # nothing to share launches with later: complete it now
+            self._ready.append(self._finish_alone(self._pend.pop(st.pid)))   # finishes alone (in the other slot's sessions)
+            self._slot = self._slots[st.pid] = st.slot
+            pend = None
+        if not can_defer:                              # nothing to share launches with later: complete it now,
+            for p in sorted(self._pend, key=lambda p: self._pend[p].seq):     # after everything submitted before it
+                self._ready.append(self._finish_alone(self._pend.pop(p)))
+            self._slot = self._slots[st.pid] = st.slot
             for lane, stream, b0, b1 in st.plan_s:
                 self._set_conditions(b1 - b0, "sample", lane, st.word[b0:b1], st.audio[b0:b1], st.spk[b0:b1],
                                      st.motion_mask[b0:b1], {c: st.qmask[b0:b1] for c in denoiser.CONDS})
@@ -744,8 +765,8 @@ class MotionDiffusion(torch.nn.Module):
             return None
         if pend is None:                               # the pipeline fills: inversion alone
             self._inversion_pass(st)
-            self._slot_done[st.slot] = [stream.record_event() for _, stream, _, _ in st.plan]   # (no tail marks this slot's use)
-            self._pend = st
+            self._slot_done[(st.pid, st.slot)] = [stream.record_event() for _, stream, _, _ in st.plan]   # (no tail marks it)
+            self._pend[st.pid] = st
             return None
         main = st.main
         guided = pend.use_insertion_guidance
@@ -786,7 +807,7 @@ class MotionDiffusion(torch.nn.Module):
                         st.invl[:, b0:b1, idx[0], :] = 0
         pend.main, pend.slot = main, self._slot
         self._ready.append(self._tail(pend))
-        self._pend = st
+        self._pend[st.pid] = st
         return None
 
     # ------------------------------------------------------------------ phases of forward (after the front end)
@@ -931,7 +952,7 @@ class MotionDiffusion(torch.nn.Module):
             # hardware queues: a consumer stream of its own that waits for done_event can block whichever of the
             # caller's / search / lane streams shares its queue, and with it the next batch's front end)
             results["done_event"], results["done_stream"] = done, tail
-            self._slot_done[st.slot] = [done]
+            self._slot_done[(st.pid, st.slot)] = [done]
             self._inflight.append(done)
             while len(self._inflight) > self.max_inflight:
                 self._inflight.popleft().synchronize()
