@@ -454,7 +454,12 @@ def main():
             also["base_B32"] = dict(record(Workload(rg, "base", 32, dev, rank, args.db_size)),
                                     workload="base diffusion len150 DDIM-50 (no guidance), 32 clips (BASELINE config 2)")
             if wl.model.async_results:
-                r = record(Workload(rg, "guided", B, dev, rank, args.db_size, database=wl.database, pipelined=False), roof=False)
+                # the same model (same calibrated lane streams) switched to one synchronous forward per batch
+                wl.drain()
+                mode, wl.cobatch, wl.model.async_results, wl.primed = (wl.cobatch, wl.model.async_results), False, False, False
+                r = record(wl, roof=False)
+                wl.drain()
+                (wl.cobatch, wl.model.async_results), wl.primed = mode, False
                 also["guided_B16_synchronous"] = dict(r, workload="the headline workload as one synchronous forward per batch "
                                                       "(results valid on the caller's stream at return, like the reference's tools)")
             also["guided_B16_fp32mode"] = dict(
