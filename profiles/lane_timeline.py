@@ -67,9 +67,12 @@ def one_step(trace=False, sync=True):
     return t_host, (time.perf_counter() - t_step[0]) * 1e3
 
 
-one_step()
-one_step()
-one_step()
+for _ in range(3 if not os.environ.get("COBATCH") else 9):     # (the co-batched pipeline has graphs per phase, lane and slot)
+    one_step()
+if os.environ.get("COBATCH"):
+    model.flush()
+    for _ in range(5):
+        one_step()
 model._graph_run = traced
 model.model.gesture_rep_encoder.graph_runner = traced
 for rep in range(2):
@@ -83,7 +86,7 @@ if os.environ.get("BACK_TO_BACK"):
     # three steps without a synchronisation in between: where does step n + 1 start relative to step n's end?
     one_step(trace=True, sync=False)
     marks = [len(log)]
-    for _ in range(2):
+    for _ in range(int(os.environ.get("BACK_TO_BACK", "3")) - 1):
         one_step(sync=False)
         marks.append(len(log))
     torch.cuda.synchronize()
