@@ -197,7 +197,8 @@ int rg_stylize_groups(rg_handle* h, const rg_a_segment* segs_host, int nseg, int
 
 /* Kernel selection hook for tests / tuning: 0 = auto, 1 = generic register-staged kernel only (any
  * shape), 2 = prefer the LDS-DMA ring kernel, 3 = prefer the depth-4 register-staged kernel, 4 = prefer the
- * 128-row big-tile kernel (bf16 A; 128 x 256 tiles), 5 = never use it, 6 = prefer it with 128 x 128 tiles. */
+ * 128-row big-tile kernel (bf16 A; 128 x 256 tiles), 5 = never use it, 6 = prefer it with 128 x 128 tiles,
+ * 7 = 128 x 128 tiles on a ring of 2 at two workgroups per CU. */
 int rg_set_gemm_path(rg_handle* h, int path);
 /* Tuning knob of this handle: waves per workgroup of the LDS-DMA GEMM kernel (0 = auto by shape, 4 or 8; default 0). */
 int rg_set_gemm_waves(rg_handle* h, int waves);

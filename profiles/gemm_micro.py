@@ -29,7 +29,7 @@ def chain(M, N, K):
 
 for name, M, N, K in SHAPES:
     line = "%-7s M=%5d N=%5d K=%5d:" % (name, M, N, K)
-    for path in (0, 5, 6, 4):
+    for path in [int(v) for v in os.environ.get("PATHS", "0,5,6,4").split(",")]:
         h.lib.rg_set_gemm_path(h._h, path)
         graphs, keep = [], []
         for st in streams:

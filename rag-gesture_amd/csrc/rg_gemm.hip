@@ -461,7 +461,7 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   const int path = h->gemm_path;
   const bool fast_ok = reg_fast_eligible(d), dma_ok = rg_gemm_dma_eligible(d);
   const bool big_ok = rg_gemm_big_eligible(d);
-  const int big_bn = big_ok ? (path == 4 ? (d->N >= 256 ? 256 : 128) : path == 6 ? 128 : (path == 0 ? rg_gemm_big_width(d, h->num_cus) : 0)) : 0;
+  const int big_bn = big_ok ? (path == 4 ? (d->N >= 256 ? 256 : 128) : path == 6 ? 128 : path == 7 ? 129 : (path == 0 ? rg_gemm_big_width(d, h->num_cus) : 0)) : 0;
   if (d->tile_n == 64) {
     RG_REQUIRE(h, d->a_is_bf16 && !d->W_lo && dma_ok && d->N % 64 == 0 && d->split_col == 0,
                "tile_n = 64 needs a bf16 A operand, aligned shapes and N % 64 == 0");
@@ -518,7 +518,7 @@ extern "C" int rg_profile_end(rg_handle* h, int variant, int64_t* launches, doub
 
 // Test / tuning hook, see the dispatch in rg_gemm.
 extern "C" int rg_set_gemm_path(rg_handle* h, int path) {
-  if (!h || path < 0 || path > 6) return RG_ERR_INVALID;
+  if (!h || path < 0 || path > 7) return RG_ERR_INVALID;
   h->gemm_path = path;
   return RG_OK;
 }

@@ -19,8 +19,8 @@ __device__ __forceinline__ void wait_vmcnt_big() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <int BNT, int NS>
-__global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const rg_gemm_desc p) {
+template <int BNT, int NS, int MINW = 1>
+__global__ void __launch_bounds__(512, MINW) gemm_bf16_big_kernel(const rg_gemm_desc p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int A_ST = BBM * ROW_BYTES;            // 16 KiB
   constexpr int W_ST = BNT * ROW_BYTES;            // 16 / 32 KiB
@@ -133,12 +133,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_big_kernel(const rg_gemm_desc p
   }
 }
 
-template <int BNT>
+template <int BNT, int NS = 3, int MINW = 1>
 void big_launch(const rg_gemm_desc* d, hipStream_t s) {
-  constexpr int NS = 3;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<BNT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<BNT, NS, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr = true;
   }
@@ -146,7 +145,7 @@ void big_launch(const rg_gemm_desc* d, hipStream_t s) {
   size_t lds = (size_t)NS * (BBM + BNT) * ROW_BYTES;
   const size_t epi = (size_t)2 * (BNT / 128) * BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
-  hipLaunchKernelGGL((gemm_bf16_big_kernel<BNT, NS>), dim3(mt * nt), dim3(512), lds, s, *d);
+  hipLaunchKernelGGL((gemm_bf16_big_kernel<BNT, NS, MINW>), dim3(mt * nt), dim3(512), lds, s, *d);
 }
 
 }  // namespace
@@ -164,6 +163,9 @@ bool rg_gemm_big_eligible(const rg_gemm_desc* d) {
 // 8 rounds and more.
 int rg_gemm_big_width(const rg_gemm_desc* d, int num_cus) {
   if (d->M < 4096 || d->N < 1024) return 0;
+  // (128x128 tiles on a ring of 2 at two workgroups per CU, rg_set_gemm_path(h, 7): the QKV / FF1 GEMMs of M = 5504 alone
+  // take 33.0 / 24.9 us per concurrent pair instead of 41.1 / 28.3 (profiles/gemm_micro.py), but a whole forward of two
+  // lanes does not get faster (2348 vs 2270 us per step at 64 clips per lane, 70.4 vs 70.6 ms per guided step): not selected)
   if ((long)((d->M + 63) / 64) * ((d->N + 127) / 128) < 8L * num_cus) return 0;
   const int mt = (d->M + BBM - 1) / BBM;
   const int wg256 = mt * ((d->N + 255) / 256);
@@ -172,5 +174,6 @@ int rg_gemm_big_width(const rg_gemm_desc* d, int num_cus) {
 
 void rg_gemm_big_launch(const rg_gemm_desc* d, int bn, void* stream) {
   if (bn == 256) big_launch<256>(d, rg_stream(stream));
+  else if (bn == 129) big_launch<128, 2, 4>(d, rg_stream(stream));   // 128x128 tiles, ring of 2, two workgroups per CU
   else big_launch<128>(d, rg_stream(stream));
 }
