@@ -82,7 +82,7 @@ def test_async_pipeline_equals_synchronous_forwards(rg, guided):
     assert torch.equal(out["pred_upper"], ref[0]["pred_upper"])
 
 
-@pytest.mark.parametrize("mode", ["batch", "split"])
+@pytest.mark.parametrize("mode", ["batch", "split", "one-lane"])
 def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
     """submit() / flush(): the sampling loop of batch n advances in the same denoiser launches as the exemplar inversion
     of batch n + 1 (shared sessions, two step groups per forward); a batch without exemplars in a lane or of another size
@@ -114,7 +114,10 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
         torch.cuda.synchronize()
         ref.append({k: out[k].clone() for k in KEYS})
     model.async_results = True
-    model.cobatch_lanes = mode       # "batch": whole batches alternate between the lanes (results two calls later); "split":
+    if mode == "one-lane":
+        model.lanes = 1              # a single pipeline on a single lane stream
+    else:
+        model.cobatch_lanes = mode   # "batch": whole batches alternate between the lanes (results two calls later); "split":
     for rep in range(2):             # every batch is cut over the lanes (results one call later)
         got = []
         for i in range(len(batches)):
