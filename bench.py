@@ -2,19 +2,23 @@
 """Benchmark of the RAG-Gesture inference hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload guided|base|longform] [--batch B]
+                    [--no-cobatch] [--no-pipeline] [--phases]
 
-One "step" = one pass of the hot path over one batch of synthetic clips through the drop-in
-`model(**data)`: 4x VAE encode -> conditioning precompute -> [batched DDIM inversion of the
-retrieved exemplars] -> 50-step DDIM with CFG [+ insertion guidance] -> 4x VAE decode
-(150 SMPL-X frames per clip at 15 fps).  Inputs are resident in HBM before
-the timed region.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), clips
-sharded across ranks (weak scaling, B clips per rank), results all-gathered once per step.
+One "step" = one pass of the hot path over one batch of synthetic clips through the drop-in model: 4x VAE encode ->
+conditioning precompute -> [retrieval -> batched DDIM inversion of the retrieved exemplars] -> 50-step DDIM with CFG
+[+ insertion guidance] -> 4x VAE decode (150 SMPL-X frames per clip at 15 fps).  Inputs are resident
+in HBM before the timed region.  The K timed steps are K complete batches: the guided workload goes through
+`model.submit()` / `model.flush()` (the sampling loop of a batch shares its denoiser launches with the exemplar
+inversion of a later batch; the pipeline fills and drains INSIDE the timed region), `--no-cobatch` = asynchronous
+`model(**data)` calls, `--no-pipeline` = one synchronous `model(**data)` per step (also reported under `also`).
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), clips sharded across ranks (weak scaling, B clips per
+rank), the ranks' results all-gathered once at the end of the loop.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
   `roofline`            dominant kernel of the headline workload, HIP-event timed in an instrumented step,
   `roofline_retrieval`  the DB sweep against the HBM roofline,
   `also`                the other single-GPU figures in the same run: base B=32 (BASELINE config 2), the headline
-                        workload in the fp32-equivalent mode (bf16x3 operands: same precision class as the reference),
+                        workload as synchronous forwards and in the fp32-equivalent mode (bf16x3 operands: same precision class as the reference),
                         long-form synthesis (config 5: 10 clips x 3 windows, window k of all clips in one forward),
   `cpu_baseline`        the CPU oracle (= a faithful port of the reference) on a bounded sample, rank 0 at N = 1 only:
                         one warm-up, median of 3, in the reference-faithful and the loop-invariant-hoisted form.
