@@ -294,81 +294,49 @@ int rg_ln_guard(rg_handle* h, const float* stats, int rows, int nparts, int K, f
 int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bias, float* out, int M,
                   int N, int K, int silu_in, int silu_out, void* stream);
 
-/* ---------------------------------------------------------------- one denoiser forward in ONE persistent launch
- * `ReGestureTransformer.forward_test` without the CFG mix (raggesture.py:1041-1085: both classifier-free branches of
- * every clip through diffusion_transformer.py:620-668 `forward`, :105-127 `DecoderLayer`, efficient_attention.py:23-45,
- * 62-102, stylization_block.py:29-40) as a dataflow of tiles inside one launch instead of ~90 dependent launches:
- *   per layer  S1 LN + QKV projection + both softmaxes + linear self-attention        (tile = sequence x head pair)
- *              S2 stylization prologue + SA-out GEMM + residual                       (tile = sequence x 64 columns)
- *              S3 LN + query projection + cross-attention, conditional rows only      (tile = sequence x condition x head pair)
- *              S4 stylization prologue x3 + ca_mix(+out_layers) GEMM, K = 2048
- *              S5 FFN linear1 + GELU    S6 FFN linear2    S7 stylization prologue + FFN-out GEMM + residual
- *   plus the joint embedding in front and the output head behind.
- * Tiles of one sequence (43 token rows, 2 per clip: conditional and classifier-free) depend only on earlier tiles of
- * the same sequence, so there is no grid-wide barrier: every workgroup pulls tile descriptors from per-shard queues
- * (topological order: deadlock-free for any number of resident workgroups), prefetches the tile's weight panel by
- * LDS-DMA, waits on the sequence's completion counter, and publishes its outputs with write-through (sc1) stores
- * followed by one agent-scope atomic add; consumers read activations with sc1 loads only (MI355X guide, inter-workgroup
- * visibility).  Weights are bf16 [N][K] (rg_gemm's packed layout), accumulation fp32, LayerNorms are evaluated
- * in fp32 from fp32 rows (no folded statistics), row statistics travel as (sum, M2) partials per 64 columns.
- * D = 512, 16 heads x 32, FF = 1024, T <= 48.
- * sched (DEVICE int32): [0..8] first tile of shard 0..7 and the tile count; from int 16 on one int4 per tile:
- *   (type | layer << 8, sequence, tile index inside the stage, completion count of the sequence to wait for).
- * ctrl (DEVICE, rg_fwd_ctrl_words(B) uint32): queue heads, abort word, per-sequence completion counters.  The caller
- * zeroes it once; every launch leaves it zeroed again (the last workgroup to drain the queues clears it), so
- * consecutive launches need no memset between them.  Returns RG_ERR_INVALID for unsupported shapes; a dependency that
- * never resolves sets the abort word (ctrl[256] != 0 afterwards, block left as is: re-zero it) instead of hanging. */
-enum { RG_FWD_EMBED = 0, RG_FWD_QKV_SA = 1, RG_FWD_SAOUT = 2, RG_FWD_Q3_CA = 3, RG_FWD_MIX = 4, RG_FWD_FF1 = 5,
-       RG_FWD_FF2 = 6, RG_FWD_FFOUT = 7, RG_FWD_HEAD = 8 };
+/* ---------------------------------------------------------------- one denoiser forward, sequence-stationary
+ * ReGestureTransformer.forward at inference (raggesture.py:1041-1085 `forward_test` up to the CFG mix,
+ * diffusion_transformer.py:620-668, :105-127 `DecoderLayer`, :74-87 `FFN`, efficient_attention.py:23-45, 62-102,
+ * stylization_block.py:29-40) in ONE launch of 2B workgroups: workgroup s owns sequence s (T <= 48 token rows; the B
+ * conditional sequences first, then the B classifier-free ones) from the joint embedding to the output head.  The fp32
+ * residual stream stays in registers, the bf16 MFMA operand panels in LDS; the only memory traffic is the weight stream,
+ * which every wave fetches for itself by LDS-DMA in the order it consumes it (csrc/rg_seq.hip).  D = 512, 16 heads x 32,
+ * FF = 1024, L <= 8, bf16 operands / fp32 accumulate, LayerNorm statistics exact in fp32.
+ * Streams (DEVICE, built once per model / per clip batch by the host, rag-gesture_amd/seqfwd.py):
+ *   wstream  bf16  [NU][8 waves][64][1 KiB]   NU = 16 L + 2 unit GEMMs of 512 x 512 (embed; per layer k, v, q, sa_out,
+ *            mix_x, (q3_c, mix_c) x 3, ff1_0, ff2_0, ff1_1, ff2_1, ffn_out; head).  Fragment (wave w, step s, block j) is
+ *            the MFMA operand image of W[64 w + 16 j + (lane & 15)][32 s + 8 (lane >> 4) + e], e = 0..7.  LayerNorm gains
+ *            are folded into the k / v / q / q3 weights (W diag(gamma)), their betas into the biases.
+ *   pstream  fp32  [S][NU][8][4][64]          per step and unit, for the wave's 64 features: vector 0 = bias, 1 / 2 =
+ *            stylization gain gamma (1 + scale) / offset beta (1 + scale) + shift of the block the unit feeds
+ *            (mix_x: vector 1 = row sums of the bf16 weight, for the un-normalised x segment).
+ *   ustream  fp32  [S][L][8][2 KiB]           classifier-free sequences: sum_k W_mix_c[n][k] * unc_tab[flag][c][k] for
+ *            (c, flag) = (0,0) (0,1) (1,0) (1,1) | (2,0) (2,1): their cross-attention output is a constant of (step, layer).
+ *   afrag    bf16  [L][3][B][8][2 heads][2 column blocks][hi, lo][64 lanes][8]   A = softmax_N(K)^T V of every clip,
+ *            condition and head (rg_kv_reduce) as MFMA A-operand fragments: element e of lane (jj, g) is
+ *            A[i][16 jb + jj], i = e < 4 ? 4 g + e : 16 + 4 g + e - 4.
+ * Clips >= split run at step index step_b (two diffusion loops sharing the launch: sampler.cobatched_loop).
+ * dump / dump_stage: diagnostics (stage 1: after the embedding; 2 / 3 / 4: after the self-attention / cross-attention /
+ * FFN block of layer dump_layer; 10: self-attention output y; 11-13: cross-attention y of condition 0-2), the T-layout
+ * registers go to dump [2B][48][512] and the workgroup exits. */
+typedef struct rg_seq_args {
+  const void* wstream;
+  const void* pstream;
+  const void* ustream;
+  const void* afrag;
+  const float* x;          /* fp32 [B][T][512] latent at this step */
+  const float* tbias;      /* fp32 [T][512] positional tables */
+  const float* src_mask;   /* fp32 [2B][T] */
+  const float* qmask;      /* fp32 [3][2B][T] */
+  float* head;             /* fp32 [2B][T][512] result */
+  float* dump;
+  int L, B, T, S;          /* layers, clips, tokens, steps in pstream / ustream */
+  int step, step_b, split; /* clips [0, split) at step, clips [split, B) at step_b */
+  int dump_stage, dump_layer;
+  int pad_;
+} rg_seq_args;
 
-typedef struct rg_fwd_layer {
-  const void* w_qkv;   const float* b_qkv;   /* bf16 [1536][512] (q | k | v rows), fp32 [1536] */
-  const float* sa_g;   const float* sa_b;    /* sa_block.norm */
-  const float* sa_sg;  const float* sa_sb;   /* sa_block.proj_out.norm */
-  const void* w_sao;   const float* b_sao;   /* sa_block.proj_out.out_layers.2 */
-  const void* w_q3;    const float* b_q3;    /* bf16 [1536][512]: query weights of text | audio | speaker */
-  const float* ca_g;   const float* ca_b;    /* [3][512] ca_blocks.*.norm */
-  const float* a_pre;                        /* fp32 [3][B][16][32][32] = softmax_N(K)^T V of this layer (rg_kv_reduce) */
-  const float* ca_sg;  const float* ca_sb;   /* [3][512] ca_blocks.*.proj_out.norm */
-  const void* unc_tab;                       /* bf16 [S][2][1536]: stylized cross-attention rows of the classifier-free branch */
-  const void* w_mix;   const float* b_mix;   /* bf16 [512][2048]: ca_mix fused with the three out_layers */
-  const void* w_ff1;   const float* b_ff1;   /* [1024][512] */
-  const void* w_ff2;   const float* b_ff2;   /* [512][1024] */
-  const float* ff_sg;  const float* ff_sb;   /* ffn.proj_out.norm */
-  const void* w_ffo;   const float* b_ffo;   /* ffn.proj_out.out_layers.2 */
-} rg_fwd_layer;
-
-typedef struct rg_fwd_args {
-  const rg_fwd_layer* layers;   /* DEVICE array [L] */
-  int L, B, T, step;            /* B clips -> 2B sequences: [0,B) conditional, [B,2B) classifier-free; step = respaced index */
-  const void* w_embed; const float* b_embed; const float* tbias;   /* joint_embed; tbias [T][512] positional tables */
-  const void* w_out;   const float* b_out;
-  const float* ss;              /* fp32 [S][L][5][1024]: AdaLN (scale | shift) of every step, layer and block */
-  const float* x;               /* fp32 [B*T][512] latent at this step */
-  const float* src_mask;        /* [2B][T] */
-  const float* qmask;           /* [3][2B][T] */
-  float* xa; float* xb; float* xc; float* head;       /* fp32 [2B*T][512]; head = result */
-  void* xb_bf; void* xc_bf; void* ysa; void* yf;      /* bf16 [2B*T][512] */
-  void* y3;                                           /* bf16 [B*T][1536] */
-  void* g;                                            /* bf16 [2B*T][1024] */
-  float* st_a; float* st_b; float* st_sa; float* st_f;   /* fp32 [2B*T][8][2] (sum, M2) per 64 columns */
-  float* st3;                                         /* fp32 [B*T][24][2] */
-  const int* sched;
-  unsigned* ctrl;
-  unsigned long long* stamps;   /* NULL, or DEVICE [n_tiles][4] wall-clock stamps (100 MHz) per tile: diagnostics */
-} rg_fwd_args;
-
-int rg_fwd_ctrl_words(int B);
-int rg_denoiser_forward(rg_handle* h, const rg_fwd_args* args_host, void* stream);
-/* The same tiles, ONE LAUNCH PER STAGE (58 launches for 8 layers instead of the ~90 of the per-op chain: LayerNorm /
- * stylization ride in the consuming GEMM's A prologue, QKV + self-attention and query projection + cross-attention are
- * one stage each): stage s runs tiles [stage_first_host[s], stage_first_host[s + 1]) of the DEVICE list stage_tiles
- * (int4 per tile as in `sched`; type 255 = padding slot), one workgroup per tile.  The kernel boundary orders producers
- * and consumers, so activations use the default cache policy and stay in the L2 of the XCD that wrote them when the list
- * keeps a sequence on one XCD (workgroups are dealt round-robin over the 8 XCDs: slot p -> XCD p % 8).
- * args.sched / args.ctrl are not used. */
-int rg_denoiser_forward_stages(rg_handle* h, const rg_fwd_args* args_host, const int* stage_tiles,
-                               const int* stage_first_host, int n_stages, void* stream);
+int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);
 
 /* ---------------------------------------------------------------- body-part VAEs + rotations
  * Softmax multi-head attention core of torch.nn.MultiheadAttention for short sequences

@@ -19,7 +19,7 @@ import math
 import numpy as np
 import torch
 
-from . import capi, fwd as F, gemm as G
+from . import capi, gemm as G, seqfwd as SQ
 
 CONDS = ("xf_text", "xf_audio", "xf_spk")
 BLOCKS = ("sa_block", "ca_blocks.xf_text", "ca_blocks.xf_audio", "ca_blocks.xf_spk", "ffn")
@@ -124,7 +124,8 @@ class DenoiserWeights:
                 fused.append(wmc @ g(q + "proj_out.out_layers.2.weight").double())
                 bias = bias + wmc @ g(q + "proj_out.out_layers.2.bias").double()
             fused.append(wm[:, :D] + wm[:, D:2 * D] + wm[:, 2 * D:])
-            lw["w_mix"], lw["b_mix"] = pw(torch.cat(fused, 1).float()), f32(bias.float())
+            lw["w_mix_f32"] = torch.cat(fused, 1).float()
+            lw["w_mix"], lw["b_mix"] = pw(lw["w_mix_f32"]), f32(bias.float())
             lw["w_ff1"], lw["b_ff1"] = pw(g(p + "ffn.linear1.weight")), f32(g(p + "ffn.linear1.bias"))
             lw["w_ff2"], lw["b_ff2"] = pw(g(p + "ffn.linear2.weight")), f32(g(p + "ffn.linear2.bias"))
             lw["ff_sg"], lw["ff_sb"] = f32(g(p + "ffn.proj_out.norm.weight")), f32(g(p + "ffn.proj_out.norm.bias"))
@@ -174,6 +175,13 @@ class DenoiserWeights:
                                   scale_shift=self.ss[si, l, 1 + c], col_offset=c * D) for c in range(3)]
                     G.stylize(self.h, segs, D, 2, tab[si])
                 lw["unc_tab"] = tab
+        # --- streams of the sequence-stationary forward (rg_seq_forward): weights in MFMA-fragment order, per-step parameters
+        self.seq_streams = None
+        if SQ.supported(cfg, self.T, precision):
+            extras = [dict(w_mix=lw.pop("w_mix_f32"), b_mix=lw["b_mix"], unc_tab=lw["unc_tab"]) for lw in self.layers]
+            self.seq_streams = SQ.SeqStreams(g, self.ss, extras, cfg, S, self.dev)
+        for lw in self.layers:
+            lw.pop("w_mix_f32", None)
         torch.cuda.synchronize(self.dev)
         # per-joint CFG scale (raggesture.py:909-922), default all ones
         pjs = cfg.get("per_joint_scale") or dict(upper=1.0, hands=1.0, face=1.0, lowertransl=1.0)
@@ -204,36 +212,51 @@ def xcd_affine_order(n_groups, items_per_group, T, tile_rows=64, n_xcd=8):
 class DenoiserSession:
     """Buffers + conditioning state for B clips (R = 2B rows: conditional rows first, then the
     classifier-free rows).  Not re-entrant; one per (model, batch size, stream)."""
-    DEFAULT_ENGINE = "chain"
+    DEFAULT_ENGINE = "seq"
 
-    def __init__(self, weights, B, persistent=None, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False,
-                 xcd_affine=True, engine=None, styl_in_gemm=False):
-        """persistent: run `forward` as ONE persistent dataflow launch (rg_denoiser_forward) instead of ~90 dependent
-        launches (bf16 production path, D = 512, FF = 1024, T <= 48).  Parity-green, but measured SLOWER than the
-        launch chain on MI355X (1244 vs 881 us per forward at M = 1376, 1864 vs 1437 us at M = 4128: every tile pays
-        ~3 memory round trips of ~2 us for its hand-offs), so it is opt-in: None / False = launch chain.
-        ln_mode (bf16 launch chain): "folded" = LayerNorm folded into the consuming GEMM's epilogue (two passes per
+    def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False, xcd_affine=True, engine=None,
+                 styl_in_gemm=False):
+        """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
+        LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
+        one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
+        supported, else "chain" (precision="fp32" always runs the chain).
+        The remaining options belong to the launch chain:
+        ln_mode: "folded" = LayerNorm folded into the consuming GEMM's epilogue (two passes per
         layer fewer; its bf16 operand is the UN-normalised row, so the error grows with |row mean| / std),
         "prologue" = LayerNorm in a pre-pass (exact for any offset), "auto" = folded unless the session's first
         forward finds rows more than LN_GUARD_SIGMAS standard deviations off centre (one read-back, once per session).
-        styl_in_gemm (bf16 launch chain): the stylization in front of the SA-out and FFN-out GEMMs (LN, scale/shift, SiLU)
+        (The "seq" engine evaluates every LayerNorm in fp32 from the fp32 rows.)
+        styl_in_gemm: the stylization in front of the SA-out and FFN-out GEMMs (LN, scale/shift, SiLU)
         runs inside those GEMMs, on the landed bf16 A tiles in LDS, instead of as two elementwise launches per layer.
-        Parity-green and measured SLOWER (907 vs 887 us per forward at M = 1376, 134.3 vs 131.7 ms per guided step): every
-        one of the 4 column-tile workgroups of a row tile redoes the two transcendentals per element, on a third of the
-        CUs the standalone pass spreads them over -- 16 launches fewer do not pay for it.  Off by default.
+        Parity-green and measured SLOWER (907 vs 887 us per forward at M = 1376): off by default.
         styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain."""
-        assert ln_mode in ("auto", "folded", "prologue")
-        # engine: "chain" = one launch per op (~90 per forward), "stages" = the fused tiles of fwd.py, one launch per
-        # stage (58), "persistent" = the same tiles in one launch; None = persistent if `persistent` else DEFAULT_ENGINE
+        if ln_mode not in ("auto", "folded", "prologue"):
+            raise capi.RgError("ln_mode must be 'auto', 'folded' or 'prologue'")
+        if engine not in (None, "seq", "chain"):
+            raise capi.RgError("engine must be 'seq' or 'chain'")
+        if engine == "seq" and weights.seq_streams is None:
+            raise capi.RgError("engine='seq': unsupported shape / precision (bf16, D = 512, 16 heads, FF = 1024, T <= 48, L <= 8)")
         if engine is None:
-            engine = "persistent" if persistent else ("chain" if persistent is False else self.DEFAULT_ENGINE)
-        assert engine in ("chain", "stages", "persistent")
+            engine = self.DEFAULT_ENGINE if weights.seq_streams is not None else "chain"
+        self.engine = engine
         w = self.w = weights
         self.h = w.h
         self.B, self.R = B, 2 * B
         D, T, dev = w.D, w.T, w.dev
         self.M = M = self.R * T
         f = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+        self.head = f(M, D)
+        self.qmask_c = torch.ones(3, B, T, device=dev)
+        self.a_pre = f(w.L, 3, B, w.H, 32, 32)
+        self.src_mask = torch.ones(self.R, T, device=dev)
+        self.qmask = torch.ones(3, self.R, T, device=dev)
+        self.abf = self.xa_bf = self.v_sa = self.hcat = None
+        self.ln_ratio = None     # max mean^2 / var seen by the guard (chain, ln_mode "auto", after the first forward)
+        self.sq = None
+        if self.engine == "seq":           # activations never leave the CU: no per-op buffers
+            self.ln_mode = "exact"
+            self.sq = SQ.SeqForward(self)
+            return
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
         # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide, or 64 wide
         # where the producer runs 64x64 tiles, self.tn): allocated for the finer split, viewed per producer
@@ -247,11 +270,8 @@ class DenoiserSession:
         self.g = torch.empty(M, w.FF, device=dev, dtype=torch.bfloat16 if w.precision == "bf16" else torch.float32)
         self.yf, self._st_f = f(M, D), f(M, D // 64, 2)
         self.st_f = parts128(self._st_f)
-        self.head = f(M, D)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
-        self.abf = self.xa_bf = self.v_sa = None
         self.ln_mode = ln_mode if (w.precision == "bf16" and styl_prepass) else "prologue"
-        self.ln_ratio = None     # max mean^2 / var seen by the guard (ln_mode "auto", after the first forward)
         if w.precision == "bf16" and styl_prepass:
             self.abf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
             self.abf3 = torch.empty(B * T, 3 * D, device=dev, dtype=torch.bfloat16)
@@ -268,11 +288,7 @@ class DenoiserSession:
             self.y_sa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
             self.yf_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
-        self.qmask_c = torch.ones(3, B, T, device=dev)
-        self.a_pre = f(w.L, 3, B, w.H, 32, 32)
         self.a_pre_t = torch.empty(w.L, 3, B, w.H, 2, 32, 32, device=dev, dtype=torch.bfloat16)  # A^T as bf16 hi/lo
-        self.src_mask = torch.ones(self.R, T, device=dev)
-        self.qmask = torch.ones(3, self.R, T, device=dev)
         # optional 64x64 GEMM tiles for the N = D launches while they still fit one round of workgroups (twice the
         # CUs on the same weight bytes).  Measured: no gain (146.1 vs 143.2 ms guided, 71.6 vs 69.6 ms base): the
         # fixed part of these launches, not the K loop, decides -- off unless tile64=True
@@ -289,11 +305,6 @@ class DenoiserSession:
         self.perm_sa1 = dv(order(self.R, 1, T))
         self.perm_ca = dv(order(self.R, 3 * ng, T))
         self.perm_cac = dv(order(B, 3 * ng, T))
-        ok = F.supported(w, T)
-        if (persistent or engine != self.DEFAULT_ENGINE) and engine != "chain" and not ok:
-            raise capi.RgError("fused forward: unsupported shape / precision")
-        self.engine = engine if ok else "chain"
-        self.pf = F.PersistentForward(self, self.engine) if self.engine != "chain" else None
 
     # ------------------------------------------------------------------ once per clip
     def set_conditions(self, word, audio, speaker_ids, motion_mask, query_masks=None, offset=0, finalize=True):
@@ -350,7 +361,9 @@ class DenoiserSession:
                        segs=[G.Seg(xf, mode=G.A_LN, stats=st, gamma=lw["tn_g"][ci], beta=lw["tn_b"][ci])],
                        seg_len=D, bias=lw["b_kv"][ci], ldo=2 * D)
                 h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci, o0:o1], B, n_tok, D)
-        if self.abf is not None and finalize:
+        if self.sq is not None:
+            self.sq.set_a(self.a_pre[:, :, o0:o1], o0, o1)
+        elif self.abf is not None and finalize:
             h.call("split_transpose_bf16", self.a_pre, self.a_pre_t, w.L * 3 * Bs * w.H)
         self._keep = (getattr(self, "_keep", []) if offset else []) + srcs
 
@@ -364,10 +377,8 @@ class DenoiserSession:
         w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
         if split is not None and not (0 < split < B):
             step, step_b, split = (step if split >= B else step_b), None, None
-        if self.pf is not None:
-            if split is not None:
-                raise capi.RgError("two step groups need the launch-chain engine")
-            return self.pf.run(x.contiguous(), step)
+        if self.sq is not None:
+            return self.sq.run(x.contiguous(), step, step_b, split)
         if self.ln_mode == "auto":
             out = self._forward_guarded(x, step)     # settles the mode (one read-back; never inside a capture)
             if split is None:

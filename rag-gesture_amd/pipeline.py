@@ -214,7 +214,7 @@ class MotionDiffusion(torch.nn.Module):
                         front of / behind it.  Batches alternate between `slots` sets of sessions and graph buffers so that
                         a front end never writes what the chain in flight still reads; at most `max_inflight` batches
                         are queued before forward() blocks on the oldest.
-      session_options   keyword arguments of denoiser.DenoiserSession (ln_mode, persistent, ...)
+      session_options   keyword arguments of denoiser.DenoiserSession (engine, ln_mode, ...)
       vae_options       keyword arguments of vae.GestureRepEncoder (part_streams, chain)"""
 
     def __init__(self, model=None, loss_recon=None, loss_gen=None, loss_contact=None, loss_laplace=None,
@@ -742,8 +742,8 @@ class MotionDiffusion(torch.nn.Module):
         pend, S, T, D, dev = self._pend.get(st.pid), st.S, st.T, st.D, self.device
         lanes = [(lane, stream, b0, b1, self._exemplars(st, b0, b1)) for lane, stream, b0, b1 in st.plan] if st.use_inversion else []
         so = self.session_options
-        groups_ok = (self.precision == "bf16" and so.get("engine") in (None, "chain") and not so.get("persistent")
-                     and so.get("styl_prepass", True) and not so.get("styl_in_gemm") and not so.get("sa_fused"))
+        groups_ok = self.precision == "bf16" and (so.get("engine") != "chain" or (
+            so.get("styl_prepass", True) and not so.get("styl_in_gemm") and not so.get("sa_fused")))
         can_defer = (groups_ok and st.use_inversion and not st.visualize_inversion and not st.ddpm and st.plan == st.plan_s
                      and all(ex for *_, ex in lanes))
         same = pend is not None and can_defer and (pend.B, pend.T) == (st.B, st.T) and \
