@@ -198,21 +198,27 @@ class Workload:
         return time.perf_counter() - t0
 
     def gemm_roofline(self, local_rank):
-        """HIP events around every rg_gemm launch of one eager step (graph replays cannot hold events; the launches are
-        the same).  bf16 mode: the bf16-A GEMMs (variant 1); fp32 mode: the bf16x3 GEMMs (variant 2, 3 MFMAs per
-        product: priced at a third of the bf16 peak)."""
+        """HIP events around every launch of the dominant kernel in eager steps of the SAME submission mode as the timed run
+        (graph replays cannot hold events; the launches are the same), taken in the steady state: the pipeline is primed with
+        4 eager steps before the events start, 2 steps (one per batch lane) are recorded.
+        bf16 mode: rg_seq_kernel (the whole denoiser forward of up to 256 sequences in one launch; variant 3), or the bf16-A
+        rg_gemm kernels when the launch chain is selected (variant 1); fp32 mode: the bf16x3 GEMMs of the launch chain
+        (variant 2, 3 MFMAs per product: priced at a third of the bf16 peak)."""
         rg, model = self.rg, self.model
         h = rg.capi.get_handle(local_rank)
-        variant = 1 if self.precision == "bf16" else 2
-        peak = MFMA_BF16_PEAK if variant == 1 else MFMA_BF16_PEAK / 3
+        seq = self.precision == "bf16" and model.model.weights.seq_streams is not None and model.session_options.get("engine") != "chain"
+        variant = 2 if self.precision != "bf16" else (3 if seq else 1)
+        peak = MFMA_BF16_PEAK if variant != 2 else MFMA_BF16_PEAK / 3
 
-        def events():
+        def events(nprime=4, nprof=2):
             self.drain()
             model.use_graphs = False
-            self.step()
+            for _ in range(nprime):
+                self.step()
             torch.cuda.synchronize()
             h.lib.rg_profile_begin(h._h)
-            self.step()                 # (co-batched: the previous eager step's sampling + this one's inversion)
+            for _ in range(nprof):
+                self.step()
             model.use_graphs = True
             n, ms, fl = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
             h.lib.rg_profile_end(h._h, variant, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl))
@@ -221,20 +227,21 @@ class Workload:
 
         n, ms, fl = events()
         ach = fl / (ms * 1e-3) if ms > 0 else 0.0
-        r = {"bound": "mfma", "kernel": ("rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)"
-                                          if variant == 1 else "rg_gemm bf16x3 kernels (fp32-equivalent products: hi*hi + hi*lo + lo*hi)"),
+        kernel = {3: "rg_seq_kernel (one workgroup per sequence: embedding, 8 decoder layers, head; bf16 MFMA, fp32 accumulate; "
+                     "weights streamed by LDS-DMA)",
+                  1: "rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)",
+                  2: "rg_gemm bf16x3 kernels (fp32-equivalent products: hi*hi + hi*lo + lo*hi)"}[variant]
+        r = {"bound": "mfma", "kernel": kernel,
              "achieved": round(ach / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 5),
              "launches": n, "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "flops_per_launch_avg": round(fl / max(1, n)),
              "lanes": model.lanes}
-        if model.lanes > 1:
-            # The timed run cuts the batch into concurrent lanes: its launches are 1/lanes of the batch each and overlap
-            # in time, so the per-launch figure above understates what the chip does.  The same kernels on one lane:
-            lanes_prod, model.lanes = model.lanes, 1
-            n1, ms1, fl1 = events()
-            model.lanes = lanes_prod
-            a1 = fl1 / (ms1 * 1e-3) if ms1 > 0 else 0.0
-            r["single_lane"] = {"achieved": round(a1 / 1e12, 3), "frac": round(a1 / peak, 5), "launches": n1,
-                                "avg_launch_us": round(ms1 * 1e3 / max(1, n1), 2), "flops_per_launch_avg": round(fl1 / max(1, n1))}
+        if seq:
+            # a launch holds one workgroup per sequence and a workgroup owns a CU (155 KiB of LDS): a lane of 2 x (16 + 48)
+            # sequences runs on 128 of the 256 CUs and the other lane's launch on the rest, at the same time
+            wgs = (fl / max(1, n)) / (2.0 * 43 * 512 * 512 * 106) * 2   # ~ sequences per launch (106 = mean units per sequence)
+            r["workgroups_per_launch"] = round(wgs)
+            r["note"] = ("per launch; a launch occupies one CU per sequence, so %d concurrent lanes share the chip: the chip-level "
+                         "rate is the sum over the lanes' concurrent launches" % model.lanes)
         return r
 
 

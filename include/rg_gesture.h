@@ -205,7 +205,8 @@ int rg_set_gemm_waves(rg_handle* h, int waves);
 
 /* Measurement aid (bench.py roofline): between begin and end every rg_gemm launch is bracketed by
  * HIP events on its stream; end synchronises and returns launch count, summed kernel time and summed
- * algorithmic FLOPs (2*M*N*K) for one kernel variant (0: fp32-source A, 1: bf16 A, 2: bf16x3). */
+ * algorithmic FLOPs (2*M*N*K) for one kernel variant (0: fp32-source A, 1: bf16 A, 2: bf16x3; 3: rg_seq_forward
+ * launches, FLOPs = the unit GEMMs and attention products of the T token rows of every sequence). */
 int rg_profile_begin(rg_handle* h);
 int rg_profile_end(rg_handle* h, int variant, int64_t* launches_host, double* total_ms_host,
                    double* total_flops_host);

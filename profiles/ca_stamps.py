@@ -12,7 +12,7 @@ W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, rg.s
 NAMES = ["entry -> loads issued (q DMA, A frags, params, mask)", "loads landed", "q reads, split, 24 mfma", "y -> lds (mask select)",
          "row statistics of the head tile", "workgroup barrier", "combine statistics + barrier", "LN + stylization + SiLU -> bf16 store"]
 for B in (8, 16, 48):
-    sess = rg.denoiser.DenoiserSession(W, B)
+    sess = rg.denoiser.DenoiserSession(W, B, engine="chain")
     d = rg.synth.synth_batch(B, seed=1)
     mask = torch.ones(B, 43)
     sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, {c: torch.ones(B, 43) for c in rg.denoiser.CONDS})

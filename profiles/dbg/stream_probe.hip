@@ -121,7 +121,7 @@ int main() {
   CK(hipMalloc(&out, 1024 * 512 * sizeof(float)));
   CK(hipMemcpy(stream, h.data(), stream_bytes, hipMemcpyHostToDevice));
   const double mb = 16.0;
-  for (int grid : {256, 128, 512}) {
+  for (int grid : {256, 32, 8}) {
     for (int skew : {1, 2}) {
       run<4, 0>(stream, stream_frags, grid, skew, out, mb);
       run<8, 0>(stream, stream_frags, grid, skew, out, mb);

@@ -12,7 +12,7 @@ BS = (8, 16, 24, 48)
 argv = sys.argv[1:]
 if argv and argv[0].startswith("--B="):          # e.g. --B=16,48
     BS, argv = tuple(int(v) for v in argv[0][4:].split(",")), argv[1:]
-ENGINES = argv or ["chain", "stages", "persistent"]
+ENGINES = argv or ["chain", "seq"]
 for B, engine in [(b, e) for b in BS for e in ENGINES]:
     kw = {}
     if engine.startswith("chain+"):      # chain variants: e.g. chain+tile64 (64x64 GEMM tiles for the N = 512 launches at every M)

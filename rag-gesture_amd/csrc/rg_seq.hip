@@ -117,6 +117,17 @@ __device__ __forceinline__ void bar() {
   __builtin_amdgcn_s_barrier();
 }
 
+#ifdef RG_STAMPS
+// Diagnostic build only (build.py RG_DIAG=1): wall-clock (100 MHz) time per category, summed per wave, written to
+// a.dump[(seq * 8 + wave) * 8 + category] when dump_stage == 99.  Categories: 0 unit GEMMs, 1 row statistics (with their
+// barrier), 2 other barriers, 3 parameter fragments + panel writes, 4 attention math, 5 whole kernel.
+#define TSTART() const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime()
+#define TSTOP(cat) tacc[cat] += __builtin_amdgcn_s_memrealtime() - t0_
+#else
+#define TSTART()
+#define TSTOP(cat)
+#endif
+
 typedef f32x4 Acc[4][3];   // [16-feature block of the wave's 64][16-token block]
 
 __device__ __forceinline__ void zero(Acc& a) {
@@ -148,6 +159,10 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   const bool cond = seq < B;
   const int clip = cond ? seq : seq - B;
   const int st = clip >= a.split ? a.step_b : a.step;
+#ifdef RG_STAMPS
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int NU = UPL * L + 2;
   const int nspl = cond ? NSEG_COND : NSEG_UNC;          // fetch segments per layer
   const int n_seg = nspl * L + 4;                        // embed (P, W), layers, head (P, W)
@@ -273,6 +288,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
     constexpr bool STD = decltype(std_tag)::value;
     LANE_LOCAL();
+    TSTART();
     const unsigned char* slot = consume();
     bf16x8 wc = *reinterpret_cast<const bf16x8*>(slot + lane * 16);
 #pragma unroll 1
@@ -295,10 +311,12 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
         wc = wn;
       }
     }
+    TSTOP(0);
   };
   // half unit, standard layout: the 32 features of ONE head (32 fragments: per step the head's two 16-feature blocks)
   auto gemm_head_std = [&](f32x4 (&acc)[2][3], const unsigned char* panel) {
     LANE_LOCAL();
+    TSTART();
     const unsigned char* slot = consume();
     bf16x8 wc = *reinterpret_cast<const bf16x8*>(slot + lane * 16);
 #pragma unroll 1
@@ -319,6 +337,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
         wc = wn;
       }
     }
+    TSTOP(0);
   };
   std::false_type TL;
 
@@ -347,6 +366,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   // x 8 waves): per-wave (sum, M2 about the wave's own mean) combined exactly (Chan), one barrier
   auto row_stats = [&](const Acc& v, float (&mean)[3], float (&rstd)[3]) {
     LANE_LOCAL();
+    TSTART();
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
       float s = 0.f;
@@ -381,6 +401,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
       mean[tb] = mu;
       rstd[tb] = rsqrtf(m2 * (1.0f / DM) + 1e-5f);
     }
+    TSTOP(1);
   };
   // ---- T-layout values -> bf16 panel fragments (8-byte stores): features 64 wave + 16 j + 4 g4 + [0, 4) of token 16 tb + l15
   auto panel_store = [&](unsigned char* panel, int l15, int g4, int j, int tb, float v0, float v1, float v2, float v3) {
@@ -716,6 +737,12 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
     }
   }
   wait_vmcnt<0>();
+#ifdef RG_STAMPS
+  if (a.dump_stage == 99 && lane0 == 0) {
+    tacc[5] = __builtin_amdgcn_s_memrealtime() - tk0;
+    for (int i = 0; i < 6; ++i) a.dump[(seq * 8 + wave) * 8 + i] = (float)tacc[i];
+  }
+#endif
 }
 
 extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream) {
@@ -733,7 +760,25 @@ extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* 
     }
     attr = true;
   }
+  rg_prof_rec rec;
+  if (h->profiling) {   // bench.py roofline: HIP events around the launch (variant 3), algorithmic FLOPs of the T token rows
+    auto get_ev = [&]() {
+      hipEvent_t e;
+      if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); }
+      return e;
+    };
+    rec.start = get_ev(); rec.stop = get_ev();
+    rec.variant = 3;
+    const double unit = 2.0 * a.T * DM * DM, att = 2.0 * a.T * 32 * 32 * 16;      // one 512 x 512 GEMM; one q A (or K^T V) over 16 heads
+    const double cond = (UPL * a.L + 2) * unit + a.L * (2 + 3) * att, unc = (10 * a.L + 2) * unit + a.L * 2 * att;
+    rec.flops = a.B * (cond + unc);
+    (void)hipEventRecord(rec.start, rg_stream(stream));
+  }
   hipLaunchKernelGGL(rg_seq_kernel, dim3(2 * a.B), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
+  if (h->profiling) {
+    (void)hipEventRecord(rec.stop, rg_stream(stream));
+    h->prof.push_back(rec);
+  }
   return RG_OK;
 }

@@ -39,14 +39,14 @@ def test_cobatched_loop_equals_separate_loops(rg, n_a, n_b):
     noise = rnd(S, n_a, T, D)
     GI = [2] * 25 + [0] * 25
     # --- separate loops (the existing path)
-    sa = rg.denoiser.DenoiserSession(W, n_a, ln_mode="folded")
+    sa = rg.denoiser.DenoiserSession(W, n_a, ln_mode="folded", engine="chain")
     sa.set_conditions(da["word"], da["audio"], da["speaker_ids"], ma, qa)
     ref_a = rg.sampler.ddim_guided_sample_loop(sa, xa0.clone(), inverted, GI, 0.1, noise)
-    sb = rg.denoiser.DenoiserSession(W, n_b, ln_mode="folded")
+    sb = rg.denoiser.DenoiserSession(W, n_b, ln_mode="folded", engine="chain")
     sb.set_conditions(db["word"], db["audio"], db["speaker_ids"], mb, qb)
     ref_b = rg.sampler.ddim_reverse_sample_loop(sb, xb0.clone(), torch.empty(S, n_b, T, D, device="cuda"))
     # --- one session holding both, filled in two calls
-    sc = rg.denoiser.DenoiserSession(W, n_a + n_b, ln_mode="folded")
+    sc = rg.denoiser.DenoiserSession(W, n_a + n_b, ln_mode="folded", engine="chain")
     sc.set_conditions(da["word"], da["audio"], da["speaker_ids"], ma, qa, offset=0, finalize=False)
     sc.set_conditions(db["word"], db["audio"], db["speaker_ids"], mb, qb, offset=n_a)
     x_all = torch.cat([xa0, xb0]).contiguous()

@@ -161,7 +161,7 @@ def test_fused_self_attention_stylization_matches_separate_kernels(rg):
     mask[1, 7:10] = 0
     outs = []
     for fused in (False, True):
-        sess = rg.denoiser.DenoiserSession(W, B, sa_fused=fused, ln_mode="folded")
+        sess = rg.denoiser.DenoiserSession(W, B, sa_fused=fused, ln_mode="folded", engine="chain")
         assert (sess.v_sa is not None) == fused
         sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, None)
         outs.append(sess.forward(x, 17).clone())
@@ -187,7 +187,7 @@ def test_stylization_inside_gemm_matches_separate_pass(rg, B):
     mask[1, 7:10] = 0
     outs = []
     for in_gemm in (False, True):
-        sess = rg.denoiser.DenoiserSession(W, B, styl_in_gemm=in_gemm, ln_mode="folded")
+        sess = rg.denoiser.DenoiserSession(W, B, styl_in_gemm=in_gemm, ln_mode="folded", engine="chain")
         assert sess.styl_gemm == in_gemm
         sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, None)
         outs.append(sess.forward(x, 17).clone())
@@ -197,10 +197,10 @@ def test_stylization_inside_gemm_matches_separate_pass(rg, B):
 
 
 @pytest.mark.parametrize("B", [1, 3, 11])
-def test_persistent_forward_matches_launch_chain(rg, setup, B):
-    """One persistent dataflow launch (rg_denoiser_forward) against the per-op launch chain on the same
-    weights / conditions / masks (both bf16 MFMA operands: they differ by where bf16 roundings fall) and
-    against the fp32 oracle; every sequence of the batch is checked (queues, stealing, ragged shards)."""
+def test_seq_forward_matches_launch_chain_and_oracle(rg, setup, B):
+    """The sequence-stationary forward (rg_seq_forward: one workgroup per sequence, one launch) against the per-op launch
+    chain on the same weights / conditions / masks (both bf16 MFMA operands: they differ by where bf16 roundings fall)
+    and against the fp32 oracle; every sequence of the batch is checked."""
     cfg, P, W = setup[8]
     data = rg.synth.synth_batch(B, seed=77)
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal((B, 43, 512)).astype(np.float32))
@@ -210,31 +210,27 @@ def test_persistent_forward_matches_launch_chain(rg, setup, B):
         mm[1, 5:9] = 0   # a clip with masked motion tokens
     qm = od.make_query_masks(mm)
     outs = {}
-    for persistent in (True, False, "stages"):
-        sess = rg.denoiser.DenoiserSession(W, B, engine={True: "persistent", False: "chain", "stages": "stages"}[persistent])
-        assert (sess.pf is not None) == bool(persistent)
+    for engine in ("seq", "chain"):
+        sess = rg.denoiser.DenoiserSession(W, B, engine=engine)
+        assert (sess.sq is not None) == (engine == "seq")
         sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
         for step in (49, 7):
-            outs[persistent, step] = sess.forward(x.cuda(), step).clone()
+            outs[engine, step] = sess.forward(x.cuda(), step).clone()
             torch.cuda.synchronize()
-        if persistent == "stages":   # same tile code, same arithmetic: the two fused engines agree bit for bit
-            assert torch.equal(outs["stages", 49], outs[True, 49]) and torch.equal(outs["stages", 7], outs[True, 7])
-        if persistent is True:
-            assert not sess.pf.aborted()
-            # replay: same inputs, same bits (the schedule is dynamic, the arithmetic per tile is not)
+        if engine == "seq":   # replay: same inputs, same bits
             again = sess.forward(x.cuda(), 7).clone()
             torch.cuda.synchronize()
-            assert torch.equal(again, outs[True, 7])
+            assert torch.equal(again, outs["seq", 7])
     xf = od.encode_conditions(P, data["word"], data["audio"], data["speaker_ids"])
-    rows = KEEP
     for step, t in ((49, 999), (7, 99)):
-        a, b = outs[True, step].view(2 * B, 43, 512).cpu(), outs[False, step].view(2 * B, 43, 512).cpu()
+        a, b = outs["seq", step].view(2 * B, 43, 512).cpu(), outs["chain", step].view(2 * B, 43, 512).cpu()
+        assert torch.isfinite(a).all()
         for r in range(2 * B):
-            e = relerr(a[r][rows], b[r][rows])
+            e = relerr(a[r], b[r])
             assert e <= 1.5e-2, (B, step, r, e)
-        print("B=%d step=%d persistent vs launch chain: rel err %.3e" % (B, step, relerr(a[:, rows], b[:, rows])))
-    # against the fp32 oracle (CFG-mixed x0, exact LayerNorm on the -1e6 rows like the kernels)
-    sess = rg.denoiser.DenoiserSession(W, B, persistent=True)
+        print("B=%d step=%d seq vs launch chain: rel err %.3e" % (B, step, relerr(a, b)))
+    # against the fp32 oracle (CFG-mixed x0, exact LayerNorm on the -1e6 rows like the kernels), all 43 rows
+    sess = rg.denoiser.DenoiserSession(W, B, engine="seq")
     sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
     x0 = _hip_x0(rg, W, sess, x, 7)
     od.OPTS.update(masked_ln="exact")
@@ -243,5 +239,25 @@ def test_persistent_forward_matches_launch_chain(rg, setup, B):
     finally:
         od.OPTS.update(masked_ln="torch")
     e = relerr(x0, ref)
-    print("B=%d persistent forward, x0 vs fp32 oracle (all rows): %.3e" % (B, e))
-    assert e <= 2e-2
+    emax = ((x0 - ref).norm(dim=-1) / ref.norm(dim=-1)).max().item()
+    print("B=%d seq forward, x0 vs fp32 oracle (all rows): %.3e  worst row %.3e" % (B, e, emax))
+    assert e <= 1e-2 and emax <= 3e-2
+
+
+def test_seq_forward_two_step_groups(rg, setup):
+    """Clips [split, B) at another diffusion step in the same launch (the co-batched pipeline) == two separate forwards,
+    bit for bit: a workgroup's arithmetic does not depend on its neighbours."""
+    cfg, P, W = setup[8]
+    B, split = 5, 2
+    data = rg.synth.synth_batch(B, seed=78)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).standard_normal((B, 43, 512)).astype(np.float32)).cuda()
+    mm = torch.ones(B, 43)
+    mm[:, [10, 21, 32]] = 0
+    sess = rg.denoiser.DenoiserSession(W, B, engine="seq")
+    sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
+    both = sess.forward(x, 40, 9, split).clone().view(2, B, 43, 512)
+    a = sess.forward(x, 40).clone().view(2, B, 43, 512)
+    b = sess.forward(x, 9).clone().view(2, B, 43, 512)
+    torch.cuda.synchronize()
+    assert torch.equal(both[:, :split], a[:, :split]) and torch.equal(both[:, split:], b[:, split:])
+    assert not torch.equal(a, b)
