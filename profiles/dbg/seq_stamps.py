@@ -18,8 +18,9 @@ for _ in range(3):
     sess.sq.run(x, 30, dump=dump, dump_stage=99)
 torch.cuda.synchronize()
 t = dump[:2 * B * 64].view(2 * B, 8, 8).cpu() / 100.0      # us
-names = ["unit GEMMs", "row statistics", "-", "-", "-", "kernel"]
+names = ["unit GEMMs", "row statistics", "barriers", "styl params+panel", "k softmax", "kernel"]
 for tag, sl in (("conditional", slice(0, B)), ("classifier-free", slice(B, 2 * B))):
     m = t[sl].mean(dim=(0, 1))
-    print("%s sequences (mean over workgroups and waves, us): " % tag + "  ".join("%s %.1f" % (names[i], m[i]) for i in (0, 1, 5))
-          + "  rest %.1f" % (m[5] - m[0] - m[1]) + "   kernel min / max over workgroups %.1f / %.1f" % (t[sl, :, 5].min(), t[sl, :, 5].max()))
+    print("%s sequences (mean over workgroups and waves, us): " % tag + "  ".join("%s %.1f" % (names[i], m[i]) for i in (0, 1, 2, 3, 4, 5))
+          + "  rest %.1f" % (m[5] - m[0] - m[1] - m[2] - m[3] - m[4]) + "   kernel min / max over workgroups %.1f / %.1f" % (t[sl, :, 5].min(), t[sl, :, 5].max()))
+print("per wave (conditional workgroups, mean us): " + "  ".join("w%d: gemm %.0f stats %.0f bar %.0f" % (w, t[:B, w, 0].mean(), t[:B, w, 1].mean(), t[:B, w, 2].mean()) for w in range(8)))

@@ -92,26 +92,57 @@ __device__ __forceinline__ float gelu_fast(float v) {
   const float e = 1.0f - pl * t * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
   return 0.5f * v + 0.5f * fabsf(v) * e;
 }
-// 8 fp32 values -> bf16 hi fragment and the bf16 residual fragment (hi * hi + hi * lo + lo * hi ~ fp32 product)
+// Attention products (softmax_N(K)^T V, softmax(q) A): ATT_HL = true feeds the matrix cores bf16 hi + lo operand pairs
+// (hi * hi + hi * lo + lo * hi ~ fp32 products, 3 MFMAs and the residual arithmetic per fragment), false = plain bf16
+// operands with fp32 accumulation (what every GEMM around them does; y is rounded to bf16 right after its stylization).
+#ifndef RG_SEQ_ATT_HL
+#define RG_SEQ_ATT_HL 0
+#endif
+constexpr bool ATT_HL = RG_SEQ_ATT_HL != 0;
+// 8 fp32 values -> bf16 hi fragment and the bf16 residual fragment
 __device__ __forceinline__ void split_hl(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-  u32x4 h, l;
+  u32x4 h, l = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const unsigned short a = f2bf(v[2 * q]), b = f2bf(v[2 * q + 1]);
     h[q] = (unsigned)a | ((unsigned)b << 16);
-    l[q] = pack2(v[2 * q] - bf2f(a), v[2 * q + 1] - bf2f(b));
+    if (ATT_HL) l[q] = pack2(v[2 * q] - bf2f(a), v[2 * q + 1] - bf2f(b));
   }
   hi = __builtin_bit_cast(bf16x8, h);
   lo = __builtin_bit_cast(bf16x8, l);
 }
 __device__ __forceinline__ f32x4 mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4 c) {
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  if (ATT_HL) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  }
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+// sum / max over the four 16-lane groups of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48) on the VALU: v_permlane16_swap exchanges
+// the odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the
+// lower half of the second; with both operands the same value the two results are the value and its partner's
+// (ds_bpermute-based shuffles cost an LDS round trip each: 12 dependent ones per LayerNorm call)
+__device__ __forceinline__ float xsum4(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+__device__ __forceinline__ float xmax4(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// lgkmcnt(0) as the BUILTIN: the compiler's wait-count bookkeeping sees it, so it does not add a wait of its own in front of
+// the first use of a register that this wait already covers (after an inline-asm wait it does: a full lgkmcnt(0) right behind
+// the next fragment's LDS read, which exposes that read's latency).  The empty asm keeps memory operations from crossing.
+__device__ __forceinline__ void wait_lds() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void bar() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -163,6 +194,11 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
   const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  auto barx = [&]() {      // workgroup barrier (stamped as category 2 in the diagnostic build)
+    TSTART();
+    bar();
+    TSTOP(2);
+  };
   const int NU = UPL * L + 2;
   const int nspl = cond ? NSEG_COND : NSEG_UNC;          // fetch segments per layer
   const int n_seg = nspl * L + 4;                        // embed (P, W), layers, head (P, W)
@@ -248,19 +284,22 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   }
   __syncthreads();     // descriptors + P0 written; every register-destination load above has been waited for
 
-  // ---- the wave's fetch cursor: segment, fragment inside it.  All state is wave-uniform (scalar registers).
+  // ---- the wave's fetch cursor: segment, fragment inside it.  All state is wave-uniform (scalar registers): the source of
+  // a fragment is a buffer descriptor of the segment (for this wave) + a scalar offset, the lane only adds its 16 bytes.
   int ie = 0, ir = 0;
-  const unsigned char* cur = nullptr;
   int cur_cnt = 0;
+  __amdgpu_buffer_rsrc_t cur_rsrc;
+  const int lane16 = lane0 * 16;
   auto load_seg = [&]() {
     const u32x4 d = *reinterpret_cast<const u32x4*>(smem + OFF_DESC + ie * 16);
     const unsigned lo = __builtin_amdgcn_readfirstlane(d[0]), hi = __builtin_amdgcn_readfirstlane(d[1]);
     cur_cnt = __builtin_amdgcn_readfirstlane(d[2]);
     const unsigned stride = __builtin_amdgcn_readfirstlane(d[3]);
-    cur = reinterpret_cast<const unsigned char*>(((unsigned long long)hi << 32) | lo) + ((size_t)(wave * stride) << 10);
+    unsigned char* base = reinterpret_cast<unsigned char*>(((unsigned long long)hi << 32) | lo) + ((size_t)(wave * stride) << 10);
+    cur_rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
   };
   auto issue = [&](int slot) {
-    __builtin_amdgcn_global_load_lds((const void*)(cur + ((size_t)ir << 10) + lane0 * 16), (lds_void*)(ring + slot * 1024), 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_rsrc, (lds_void*)(ring + slot * 1024), 16, lane16, ir << 10, 0, 0);
     if (++ir == cur_cnt) {
       ir = 0;
       ++ie;
@@ -282,62 +321,62 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
 #pragma unroll
   for (int s = 0; s < RD; ++s) issue(s);
 
-  // ---- unit GEMM: acc += W_unit x panel over K = 512 (16 steps of 32), 64 weight fragments from the ring.
-  // STD = false: T layout (A = weights); true: standard layout (A = panel).  The LDS read of fragment i + 1 is issued
-  // before the MFMAs of fragment i.
-  auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
+
+  // ---- unit GEMM: acc += W_unit x panel over K = 512 (16 steps of 32); NJ weight fragments per step from the ring
+  // (NJ = 4: the wave's 64 features, NJ = 2: the 32 features of one head).  STD = false: T layout (A = weights); true:
+  // standard layout (A = panel).  Per fragment f: [its LDS read has landed -> refill its ring slot] [fragment f + 1 has
+  // landed in LDS -> issue its LDS read] [MFMAs of f]: the LDS latency of the next fragment hides behind these MFMAs and
+  // every ring slot is in flight again as soon as its bytes are in registers.  Two steps per loop iteration with static
+  // register names (no rotation copies: a copy of a register with a pending LDS read makes the compiler wait for it at
+  // once); the panel fragments of step s + 1 are read during the last fragment of step s.
+  auto gemm_frags = [&](auto& acc, const unsigned char* panel, auto nj_tag, auto std_tag) {
+    constexpr int NJ = decltype(nj_tag)::value;
     constexpr bool STD = decltype(std_tag)::value;
+    static_assert(NJ % 2 == 0, "fragments per step alternate between two registers");
     LANE_LOCAL();
     TSTART();
-    const unsigned char* slot = consume();
-    bf16x8 wc = *reinterpret_cast<const bf16x8*>(slot + lane * 16);
+    const unsigned char* pl = panel + lane * 16;
+    const unsigned char* rl = ring + lane * 16;
+    bf16x8 w[2], pf[2][3];
+    wait_vmcnt<RD - 1>();
+    w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) pf[0][tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16) << 10));
 #pragma unroll 1
-    for (int s = 0; s < 16; ++s) {
-      bf16x8 pf[3];
+    for (int s2 = 0; s2 < 16; s2 += 2) {
 #pragma unroll
-      for (int tb = 0; tb < 3; ++tb) pf[tb] = *reinterpret_cast<const bf16x8*>(panel + ((tb * 16 + s) << 10) + lane * 16);
+      for (int ss = 0; ss < 2; ++ss) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        release();                               // (waits for wc and pf)
-        bf16x8 wn = wc;
-        if (!(j == 3 && s == 15)) {
-          slot = consume();
-          wn = *reinterpret_cast<const bf16x8*>(slot + lane * 16);
+        for (int j = 0; j < NJ; ++j) {
+          const bool last = ss == 1 && j == NJ - 1 && s2 == 14;   // the unit's last fragment
+          wait_lds();                                             // w[j & 1] (and pf[ss]) are in registers
+          issue(head);                                            // refill the slot they came from
+          head = head + 1 == RD ? 0 : head + 1;
+          if (!last) {
+            wait_vmcnt<RD - 1>();
+            w[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
+          }
+          if (j == NJ - 1 && !last) {
+#pragma unroll
+            for (int tb = 0; tb < 3; ++tb) pf[ss ^ 1][tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16 + s2 + ss + 1) << 10));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int tb = 0; tb < 3; ++tb)
+            acc[j][tb] = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ss][tb], w[j & 1], acc[j][tb], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[ss][tb], acc[j][tb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int tb = 0; tb < 3; ++tb)
-          acc[j][tb] = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[tb], wc, acc[j][tb], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc, pf[tb], acc[j][tb], 0, 0, 0);
-        wc = wn;
       }
     }
     TSTOP(0);
   };
+  auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
+    gemm_frags(acc, panel, std::integral_constant<int, 4>(), std_tag);
+  };
   // half unit, standard layout: the 32 features of ONE head (32 fragments: per step the head's two 16-feature blocks)
   auto gemm_head_std = [&](f32x4 (&acc)[2][3], const unsigned char* panel) {
-    LANE_LOCAL();
-    TSTART();
-    const unsigned char* slot = consume();
-    bf16x8 wc = *reinterpret_cast<const bf16x8*>(slot + lane * 16);
-#pragma unroll 1
-    for (int s = 0; s < 16; ++s) {
-      bf16x8 pf[3];
-#pragma unroll
-      for (int tb = 0; tb < 3; ++tb) pf[tb] = *reinterpret_cast<const bf16x8*>(panel + ((tb * 16 + s) << 10) + lane * 16);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        release();
-        bf16x8 wn = wc;
-        if (!(j == 1 && s == 15)) {
-          slot = consume();
-          wn = *reinterpret_cast<const bf16x8*>(slot + lane * 16);
-        }
-#pragma unroll
-        for (int tb = 0; tb < 3; ++tb) acc[j][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[tb], wc, acc[j][tb], 0, 0, 0);
-        wc = wn;
-      }
-    }
-    TSTOP(0);
+    gemm_frags(acc, panel, std::integral_constant<int, 2>(), std::true_type());
   };
   std::false_type TL;
 
@@ -372,19 +411,17 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = xsum4(s);
       const float mw = s * (1.0f / 64);
       float m2 = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) m2 = fmaf(v[j][tb][r] - mw, v[j][tb][r] - mw, m2);
-      m2 += __shfl_xor(m2, 16);
-      m2 += __shfl_xor(m2, 32);
+      m2 = xsum4(m2);
       if (g4 == 0) *reinterpret_cast<float2*>(sStat + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, m2);
     }
-    bar();
+    bar();   // (inside the row-statistics stamp)
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
       float tot = 0.f;
@@ -444,11 +481,15 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   auto styl_unit = [&](Acc& acc, unsigned char* panel, const Acc& y) {
     float m3[3], r3[3];
     row_stats(y, m3, r3);
-    const unsigned char* ps = consume();
-    write_styl(panel, y, m3, r3, ps);
-    add_bias_t(acc, ps);
-    release();
-    bar();
+    {
+      TSTART();
+      const unsigned char* ps = consume();
+      write_styl(panel, y, m3, r3, ps);
+      add_bias_t(acc, ps);
+      release();
+      TSTOP(3);
+    }
+    barx();
     gemm_unit(acc, panel, TL);
   };
   // softmax over the 32 features of each of the wave's two heads, T layout (features: 8 in the lane x 4 lane groups)
@@ -460,8 +501,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
         f32x4& q0 = q[2 * h][tb];
         f32x4& q1 = q[2 * h + 1][tb];
         float mx = fmaxf(fmaxf(fmaxf(q0[0], q0[1]), fmaxf(q0[2], q0[3])), fmaxf(fmaxf(q1[0], q1[1]), fmaxf(q1[2], q1[3])));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = xmax4(mx);
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -469,20 +509,24 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
           q1[r] = __expf(q1[r] - mx);
           sum += q0[r] + q1[r];
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = xsum4(sum);
         const float inv = 1.0f / sum;
         q0 *= inv;
         q1 *= inv;
       }
   };
-  // y = softmax(q) A for one head: T-layout out block jb <- A fragments (hi, lo) of that block, q blocks 2 h, 2 h + 1
-  auto qa_block = [&](const Acc& q, int h, int tb, bf16x8 ah, bf16x8 al) -> f32x4 {
-    const float b8[8] = {q[2 * h][tb][0], q[2 * h][tb][1], q[2 * h][tb][2], q[2 * h][tb][3],
-                         q[2 * h + 1][tb][0], q[2 * h + 1][tb][1], q[2 * h + 1][tb][2], q[2 * h + 1][tb][3]};
-    bf16x8 bh, bl;
-    split_hl(b8, bh, bl);
-    return mfma3(ah, al, bh, bl, f32x4{0.f, 0.f, 0.f, 0.f});
+  // y = softmax(q) A for one head: T-layout out blocks 2 h, 2 h + 1 <- A fragments (hi, lo) of the head's two column
+  // blocks, q blocks 2 h, 2 h + 1 (the contraction runs over the head's 32 features)
+  auto qa_head = [&](Acc& y, const Acc& q, int h, const bf16x8 (&ah)[2], const bf16x8 (&al)[2]) {
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) {
+      const float b8[8] = {q[2 * h][tb][0], q[2 * h][tb][1], q[2 * h][tb][2], q[2 * h][tb][3],
+                           q[2 * h + 1][tb][0], q[2 * h + 1][tb][1], q[2 * h + 1][tb][2], q[2 * h + 1][tb][3]};
+      bf16x8 bh, bl;
+      split_hl(b8, bh, bl);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) y[2 * h + jb][tb] = mfma3(ah[jb], al[jb], bh, bl, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
   };
   auto dump = [&](const Acc& v) {       // diagnostics: T-layout registers -> a.dump [R][TP][512]
     LANE_LOCAL();
@@ -505,7 +549,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
     // ======================================================= self attention (efficient_attention.py:23-45)
     row_stats(xr, mean, rstd);
     write_norm(P0, xr, mean, rstd);            // P0 = xhat; gamma is folded into the weights, beta into the bias
-    bar();
+    barx();
     {
       f32x4 Ab[2][2][2];                       // [head][16-row block i][16-column block j] of A_h = softmax_N(K_h)^T V_h
       {
@@ -534,6 +578,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
               vv[j][tb] = f32x4{bv[2 * h + j], bv[2 * h + j], bv[2 * h + j], bv[2 * h + j]};
             }
           gemm_head_std(kk, P0);
+          TSTART();
           // softmax over the tokens, per feature column (lane): tokens 16 tb + 4 g4 + r; masked / padded tokens weigh 0
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
@@ -543,8 +588,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 if ((tokbits >> (4 * tb + r)) & 1u) mx = fmaxf(mx, kk[j][tb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xmax4(mx);
             float sum = 0.f;
 #pragma unroll
             for (int tb = 0; tb < 3; ++tb)
@@ -554,14 +598,23 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
                 kk[j][tb][r] = e;
                 sum += e;
               }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = xsum4(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int tb = 0; tb < 3; ++tb) kk[j][tb] *= inv;
           }
+          TSTOP(4);
           gemm_head_std(vv, P0);
           // A_h[i][jc] = sum_t P[t][i] V[t][jc] (contraction over tokens: step 0 = token blocks 0 | 1, step 1 = block 2 | zeros)
+          bf16x8 vh0[2], vl0[2], vh1[2], vl1[2];
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) {
+            const f32x4* vb = vv[jb];
+            const float v0[8] = {vb[0][0], vb[0][1], vb[0][2], vb[0][3], vb[1][0], vb[1][1], vb[1][2], vb[1][3]};
+            const float v1[8] = {vb[2][0], vb[2][1], vb[2][2], vb[2][3], 0.f, 0.f, 0.f, 0.f};
+            split_hl(v0, vh0[jb], vl0[jb]);
+            split_hl(v1, vh1[jb], vl1[jb]);
+          }
 #pragma unroll
           for (int ib = 0; ib < 2; ++ib) {
             const f32x4* kb = kk[ib];
@@ -572,14 +625,8 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
             split_hl(k1, kh1, kl1);
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb) {
-              const f32x4* vb = vv[jb];
-              const float v0[8] = {vb[0][0], vb[0][1], vb[0][2], vb[0][3], vb[1][0], vb[1][1], vb[1][2], vb[1][3]};
-              const float v1[8] = {vb[2][0], vb[2][1], vb[2][2], vb[2][3], 0.f, 0.f, 0.f, 0.f};
-              bf16x8 vh0, vl0, vh1, vl1;
-              split_hl(v0, vh0, vl0);
-              split_hl(v1, vh1, vl1);
-              f32x4 d = mfma3(kh0, kl0, vh0, vl0, f32x4{0.f, 0.f, 0.f, 0.f});
-              Ab[h][ib][jb] = mfma3(kh1, kl1, vh1, vl1, d);
+              f32x4 d = mfma3(kh0, kl0, vh0[jb], vl0[jb], f32x4{0.f, 0.f, 0.f, 0.f});
+              Ab[h][ib][jb] = mfma3(kh1, kl1, vh1[jb], vl1[jb], d);
             }
           }
         }
@@ -589,16 +636,16 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
       unit(qq, P0, TL);
       softmax_q(qq);
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 ah[2], al[2];
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
           const float a8[8] = {Ab[h][0][jb][0], Ab[h][0][jb][1], Ab[h][0][jb][2], Ab[h][0][jb][3],
                                Ab[h][1][jb][0], Ab[h][1][jb][1], Ab[h][1][jb][2], Ab[h][1][jb][3]};
-          bf16x8 ah, al;
-          split_hl(a8, ah, al);
-#pragma unroll
-          for (int tb = 0; tb < 3; ++tb) yy[2 * h + jb][tb] = qa_block(qq, h, tb, ah, al);
+          split_hl(a8, ah[jb], al[jb]);
         }
+        qa_head(yy, qq, h, ah, al);
+      }
       if (dl && a.dump_stage == 10) dump(yy);
       styl_unit(xr, P1, yy);                   // x += proj_out(...)  (stylization_block.py:40, efficient_attention.py:44)
     }
@@ -608,7 +655,7 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
     // diffusion_transformer.py:110-122), as [h_text | h_audio | h_spk | x] @ W_fused^T (rg_gesture.h: ca_mix fusion)
     row_stats(xr, mean, rstd);
     write_norm(P0, xr, mean, rstd);            // xhat: query projections (per-condition gamma / beta folded) and the x segment
-    bar();
+    barx();
     {
       // x W_x^T + b = sd * (xhat W_x^T + rstd * (mean * rowsum(W_x) + b)),  sd = 1 / rstd
       LANE_LOCAL();
@@ -660,18 +707,19 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
         unsigned qbits = qbits0;
         asm volatile("" : "+v"(qbits));
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 ah[2], al[2];
 #pragma unroll
           for (int jb = 0; jb < 2; ++jb) {
             const unsigned char* s0 = consume();
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(s0 + lane * 16);
+            ah[jb] = *reinterpret_cast<const bf16x8*>(s0 + lane * 16);
             release();
             const unsigned char* s1 = consume();
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(s1 + lane * 16);
+            al[jb] = *reinterpret_cast<const bf16x8*>(s1 + lane * 16);
             release();
-#pragma unroll
-            for (int tb = 0; tb < 3; ++tb) yy[2 * h + jb][tb] = qa_block(qq, h, tb, ah, al);
           }
+          qa_head(yy, qq, h, ah, al);
+        }
         // masked queries: the reference adds -1e6 before the LayerNorm; keep its fp32 rounding (DESIGN: masked query rows)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb)
@@ -692,9 +740,9 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
     if (dl && a.dump_stage == 3) dump(xr);
 
     // ======================================================= FFN (diffusion_transformer.py:74-87): 1024 hidden units in two halves
-    bar();                                     // every wave is done reading P0
+    barx();                                     // every wave is done reading P0
     write_raw(P0, xr);
-    bar();
+    barx();
     {
       Acc yf;
       zero(yf);
@@ -709,9 +757,9 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
           for (int tb = 0; tb < 3; ++tb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gg[j][tb][r] = gelu_fast(gg[j][tb][r]);
-        bar();                                 // P1 is free
+        barx();                                 // P1 is free
         write_raw(P1, gg);
-        bar();
+        barx();
         unit(yf, P1, TL);                      // (the bias of linear2 rides with the first half)
       }
       styl_unit(xr, P1, yf);
@@ -720,9 +768,9 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   }
 
   // =========================================================== output head (diffusion_transformer.py:662-666)
-  bar();
+  barx();
   write_raw(P0, xr);
-  bar();
+  barx();
   Acc out;
   zero(out);
   unit(out, P0, TL);
