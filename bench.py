@@ -103,11 +103,13 @@ class Workload:
     """One benchmark configuration: model + resident synthetic inputs + step()."""
 
     def __init__(self, rg, kind, B, dev, rank, db_size, precision="bf16", database=None, clips=10, windows=3, pipelined=True, cobatch=True):
+        import collections
         self.rg, self.kind, self.B, self.dev, self.precision = rg, kind, B, dev, precision
+        self._submitted, self._latency = collections.deque(), []
         self.cfg = rg.synth.default_model_cfg(num_layers=8)
         self.vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
-        self.guided = kind == "guided"
-        # guided: the retrieval DB (discourse metadata + token features) is replicated on every GPU
+        self.guided = kind in ("guided", "longform")
+        # guided / longform: the retrieval DB (discourse metadata, gesture labels, token features) is replicated on every GPU
         self.database = database
         if self.guided and database is None:
             self.database = rg.synth.SyntheticDataset(db_size, seed=2025, device=dev, feat_device=dev)
@@ -119,16 +121,20 @@ class Workload:
         # guided workload: the sampling loop of batch n shares its denoiser launches with the inversion of batch n + 1
         self.cobatch = self.model.async_results and kind == "guided" and cobatch and precision == "bf16"
         if kind == "longform":
+            # BASELINE config 5: tools/longform_synthesis.py's loop -- overlapping 150-frame windows, every window a guided
+            # forward with `use_inversion + insertion_guidance + use_prev_latent` (longform_synthesis.py:389-403) and
+            # retrieval_method = "llm" (rag/llm_retrieval.py:166-466) on CACHED LLM answers: the response cache is filled
+            # by a deterministic stand-in for the API call during warm-up, the timed steps only hit it
+            import tempfile
             self.n_clips, self.windows = clips, windows
-            n = 135 * windows   # hop 135: sample lengths in (135 (w - 1), 135 w] give w windows (longform_synthesis.py:262-265)
-            self.clips = []
-            for c in range(clips):
-                parts = [rg.synth.synth_batch(1, seed=5000 + 100 * rank + 10 * c + w, device=dev) for w in range(windows)]
-                self.clips.append({k: torch.cat([p[k] for p in parts], dim=1)[:, :n] for k in rg.longform.MOTION_KEYS + rg.longform.REPEAT_KEYS
-                                   if k in parts[0] and torch.is_tensor(parts[0][k]) and parts[0][k].dim() >= 2 and parts[0][k].shape[1] == 150})
+            self.clips = [rg.synth.synth_longform_clip(5000 + 100 * rank + 10 * c, windows, device=dev) for c in range(clips)]
             self.audio = [rg.synth.synth_batch(1, seed=7000 + w, device=dev)["audio"] for w in range(windows)]
+            self.feats = [[rg.synth.synth_query(300 + 10 * c + w)["text_features"].to(dev) for w in range(windows)] for c in range(clips)]
+            self.llm_cache = rg.retrieval.LLMResponseCache(os.path.join(tempfile.mkdtemp(prefix="rg_llm_"), "llm_cache.json"),
+                                                           call=rg.synth.synth_llm_answer)
+            self.model.model.database.llm_output = self.llm_cache.get
             self.synth = rg.longform.LongformSynthesizer(self.model, overlap=15)
-            self.frames_per_step = clips * n
+            self.frames_per_step = clips * 135 * windows
             return
         self.data = rg.synth.synth_batch(B, seed=1234 + rank, device=dev)
         if self.guided:  # per-clip discourse relations / prominence / BERT token features (3 relations per query)
@@ -143,12 +149,19 @@ class Workload:
     def step(self):
         """One pass of the hot path; returns the packed [B,150,268] result (None for longform)."""
         if self.kind == "longform":
-            self.synth.run_many([dict(c, trans=c["trans"].clone()) for c in self.clips],
-                                lambda ci, cidx, t0, t1, ann: dict(audio=self.audio[cidx], text_features=None), shard=False)
+            def features(ci, cidx, t0, t1, ann):     # the per-window callback of longform_synthesis.py:320-343
+                text = " ".join(seg[1] for seg in ann["text_segments"][0])
+                return dict(audio=self.audio[cidx], raw_word=[text], text_features=[self.feats[ci][cidx]])
+            self.last = self.synth.run_many([dict(c, trans=c["trans"].clone()) for c in self.clips], features, use_inversion=True,
+                                            insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1, retrieval_method="llm",
+                                            shard=False)
             return None
         d = dict(self.data)
         d["trans"] = self.trans0.clone()  # forward re-zeroes trans in place like the reference
-        ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1) if self.guided else {}
+        ev = torch.cuda.Event(enable_timing=True)      # submission time of this batch (per-batch latency, see pack())
+        ev.record()
+        self._submitted.append(ev)
+        ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1) if self.kind == "guided" else {}
         call = self.model.submit if self.cobatch else self.model
         return self.pack(call(**dict(d, retrieval_method="discourse", inference_kwargs=ikw)))
 
@@ -160,8 +173,20 @@ class Workload:
         # asynchronous submission (model.async_results): the batch is only queued; its packed result is assembled on
         # the stream the batch ends on, so the caller's stream is free for the next batch's front end
         with torch.cuda.stream(out.get("done_stream") or torch.cuda.current_stream()):
-            return torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
-                              out["pred_transl"], out["pred_exps"]], dim=-1)
+            packed = torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
+                                out["pred_transl"], out["pred_exps"]], dim=-1)
+            done = torch.cuda.Event(enable_timing=True)
+            done.record()
+        if self._submitted:     # results come back in submission order: device time from a batch's submission to its packed result
+            self._latency.append((self._submitted.popleft(), done))
+        return packed
+
+    def latency_ms(self):
+        """Median / max device time from the submission of a batch to its packed result over the batches seen since the
+        last call (call after a device synchronisation)."""
+        ms = sorted(a.elapsed_time(b) for a, b in self._latency)
+        self._latency = []
+        return (round(ms[len(ms) // 2], 2), round(ms[-1], 2)) if ms else (None, None)
 
     def drain(self):
         """Finish whatever the co-batched pipeline still holds (the last batch's sampling loop)."""
@@ -238,11 +263,31 @@ class Workload:
         if seq:
             # a launch holds one workgroup per sequence and a workgroup owns a CU (155 KiB of LDS): a lane of 2 x (16 + 48)
             # sequences runs on 128 of the 256 CUs and the other lane's launch on the rest, at the same time
-            wgs = (fl / max(1, n)) / (2.0 * 43 * 512 * 512 * 106) * 2   # ~ sequences per launch (106 = mean units per sequence)
-            r["workgroups_per_launch"] = round(wgs)
+            per_clip = 2.0 * 43 * 512 * 512 * (130 + 82) + 8 * 7 * 2.0 * 43 * 32 * 32 * 16   # one conditional + one classifier-free sequence
+            r["workgroups_per_launch"] = 2 * round(fl / max(1, n) / per_clip)
             r["note"] = ("per launch; a launch occupies one CU per sequence, so %d concurrent lanes share the chip: the chip-level "
                          "rate is the sum over the lanes' concurrent launches" % model.lanes)
         return r
+
+
+def run_steps(wl, n, dist=None, world=1, sync=None):
+    """n batches through the pipeline; then, like the reference's multi-GPU test loop (mogen/apis/test.py:129-160: every
+    rank runs its shard of the clips, `collect_results_gpu` gathers ONCE at the end), one all-gather of this rank's
+    packed results -- the only collective on the path (RCCL over xGMI).  Inside the timed region.
+    wl: anything with step() -> packed [B, 150, 268] result or None and drain() -> list of the same (the co-batched
+    pipeline hands results out late); sync(): device synchronisation before the collective (the results sit on the lanes'
+    streams); dist: torch.distributed or None."""
+    import torch
+    packed = [p for p in (wl.step() for _ in range(n)) if p is not None]
+    packed += [p for p in wl.drain() if p is not None]   # co-batched pipeline: the last batches' sampling
+    if dist is None or not packed:
+        return packed
+    if sync is not None:
+        sync()
+    mine = torch.cat(packed, dim=0)
+    gathered = torch.empty(world * mine.shape[0], mine.shape[1], mine.shape[2], device=mine.device, dtype=mine.dtype)
+    dist.all_gather_into_tensor(gathered, mine)
+    return gathered
 
 
 def retrieval_roofline(rg, wl):
@@ -385,25 +430,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n):
-        """n batches through the pipeline; then, like the reference's multi-GPU test loop (mogen/apis/test.py:129-160: every
-        rank runs its shard of the clips, `collect_results_gpu` gathers ONCE at the end), one all-gather of this rank's
-        packed results -- the only collective on the path (RCCL over xGMI).  Inside the timed region."""
-        packed = [p for p in (wl.step() for _ in range(n)) if p is not None]
-        packed += [p for p in wl.drain() if p is not None]   # co-batched pipeline: the last batch's sampling
-        if dist is None or not packed:
-            return packed
-        torch.cuda.synchronize()          # the results sit on the lanes' streams; the collective runs beside the caller's
-        mine = torch.cat(packed, dim=0)
-        gathered = torch.empty(world * mine.shape[0], mine.shape[1], mine.shape[2], device=dev)
-        dist.all_gather_into_tensor(gathered, mine)
-        return gathered
-
     wl.prime()
-    run_steps(args.warmup)
+    run_steps(wl, args.warmup, dist, world, torch.cuda.synchronize)
     fence()
+    wl.latency_ms()          # (forget the warm-up batches)
     t0 = time.perf_counter()
-    run_steps(args.steps)     # the timed region holds exactly `steps` complete batches
+    run_steps(wl, args.steps, dist, world, torch.cuda.synchronize)     # the timed region holds exactly `steps` complete batches
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -412,6 +444,7 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * wl.frames_per_step * args.steps / dt
+    lat_med, lat_max = wl.latency_ms()
 
     if args.phases and rank == 0 and kind != "longform":
         # phase walls need device syncs at phase boundaries, which serialise concurrent lanes: the breakdown is taken
@@ -476,11 +509,14 @@ def main():
             also["guided_B16_fp32mode"] = dict(
                 record(Workload(rg, "guided", B, dev, rank, args.db_size, precision="fp32", database=wl.database)),
                 workload="the headline workload with bf16x3 split operands (~fp32 products): same-precision figure")
-            lw = Workload(rg, "longform", 10, dev, rank, args.db_size)
+            lw = Workload(rg, "longform", 10, dev, rank, args.db_size, database=wl.database, clips=10)
             also["longform_10clips"] = dict(
-                record(lw), workload="long-form synthesis (BASELINE config 5 on one GPU): 10 clips x %d overlapping 150-frame "
-                                     "windows, window k of all clips in one forward, prev-latent chaining, 6D blend, 30 fps; "
-                                     "frames = model frames at 15 fps" % lw.windows)
+                record(lw, steps=4, roof=False),
+                workload="long-form synthesis as tools/longform_synthesis.py runs it (BASELINE config 5 on one GPU): 10 clips x %d "
+                         "overlapping 150-frame windows, every window with retrieval_method='llm' over the replicated DB on "
+                         "cached LLM answers (LLMResponseCache), use_inversion + insertion_guidance + use_prev_latent, window k of "
+                         "all clips in one forward, 6D overlap blend, 30 fps; frames = model frames at 15 fps" % lw.windows,
+                llm_cache={"hits": lw.llm_cache.hits, "misses": lw.llm_cache.misses})
     if dist is not None:
         dist.barrier()
 
@@ -493,12 +529,17 @@ def main():
         names = {"guided": ("guided discourse config: discourse retrieval over a replicated %d-entry DB, use_inversion + "
                             "insertion_guidance decreasing_till_25, <=3 exemplars/clip, len150 DDIM-50" % args.db_size),
                  "base": "base diffusion len150 DDIM-50 (no guidance)",
-                 "longform": "long-form synthesis: %d clips x 3 overlapping 150-frame windows per GPU" % B}
+                 "longform": "long-form synthesis (tools/longform_synthesis.py loop): %d clips x 3 overlapping 150-frame windows per GPU, llm retrieval on cached answers + inversion + insertion guidance + prev-latent per window" % B}
         line = {
             "metric": "SMPL-X frames/sec, len150 DDIM-50 + insertion guidance; 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if dist is not None else None, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
+            "batch_latency_ms": {"median": lat_med, "max": lat_max,
+                                 "note": "device time from a batch's submission to its packed result; the co-batched pipeline "
+                                         "hands a batch out two submissions later (its sampling shares launches with a later "
+                                         "batch's inversion), so latency > 2 x ms_per_step while throughput = 1 / ms_per_step"},
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": names[kind],
                        "clips_per_gpu": B, "global_batch": world * B, "frames_per_clip": 150, "ddim_steps": 50,

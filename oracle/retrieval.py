@@ -219,17 +219,22 @@ def place_exemplars(retr_indexes, retr_bounds, query_bounds, retrieval_method="d
     return out
 
 
-def database_forward(P, vae_cfgs, db, dataset, conditions, own_names, tape, retrieval_method="discourse"):
+def database_forward(P, vae_cfgs, db, dataset, conditions, own_names, tape, retrieval_method="discourse", retrieve=None):
     """reference: RetrievalDatabase.forward (raggesture.py:479-884), the parts the sampler consumes:
     per clip retrieve -> select -> fetch + VAE-encode each visited exemplar (4 rsample draws each, in
-    visiting order, even when the exemplar is skipped afterwards) -> placement -> re_dict."""
+    visiting order, even when the exemplar is skipped afterwards) -> placement -> re_dict.
+    retrieve(b) -> (sample_indexes, db_bounds, query_bounds): the retrieval method of clip b when it is not the discourse
+    one (raggesture.py:313-477 dispatches on retrieval_method; llm / gesture_type take other annotations)."""
     from . import vae as ovae
     B = len(conditions["text_features"])
     retr_se, query_se, lats = [], [], []
     for b in range(B):
         spk = int(conditions["speaker_ids"][b, 0].item())
-        si, dbb, qb = discourse_retrieval(conditions["discourse"][b], conditions["prominence"][b], spk, db,
-                                          conditions["text_features"][b])
+        if retrieve is not None:
+            si, dbb, qb = retrieve(b)
+        else:
+            si, dbb, qb = discourse_retrieval(conditions["discourse"][b], conditions["prominence"][b], spk, db,
+                                              conditions["text_features"][b])
         sel = select_retrieved(si, own_names[b], 1)
         rs, qs, ls = {}, {}, {}
         # visiting order and skip rules as in place_exemplars, but the encode happens before the skips

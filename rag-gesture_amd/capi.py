@@ -20,6 +20,17 @@ class RgError(RuntimeError):
     pass
 
 
+class RgConfigError(RgError, AssertionError):
+    """An argument / configuration check that the reference states as an `assert` (e.g. the inference_kwargs compatibility
+    rules, diffusion_architecture.py:227-241): still an AssertionError for callers that catch one, but raised explicitly,
+    so it does not disappear under `python -O`."""
+
+
+def require(cond, msg="unsupported configuration"):
+    if not cond:
+        raise RgConfigError(msg)
+
+
 def header_symbols():
     """Every entry point include/rg_gesture.h declares."""
     with open(HEADER_PATH) as f:

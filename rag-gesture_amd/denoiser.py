@@ -51,7 +51,7 @@ class DenoiserWeights:
     def __init__(self, state, cfg, schedule, device="cuda", prefix="", precision="bf16"):
         """precision: "bf16" (MFMA operands rounded to bf16, the production path) or "fp32"
         (bf16x3 split operands: ~fp32 products at 3 MFMAs per tile, used for parity checks)."""
-        assert precision in ("bf16", "fp32")
+        capi.require(precision in ("bf16", "fp32"), "unsupported argument: requires precision in (\"bf16\", \"fp32\")")
         self.precision = precision
         self.cfg = cfg
         self.schedule = schedule
@@ -60,7 +60,7 @@ class DenoiserWeights:
         D, L = cfg["latent_dim"], cfg["num_layers"]
         self.D, self.L, self.H = D, L, cfg["num_heads"]
         self.TE, self.FF = cfg["time_embed_dim"], cfg["ff_size"]
-        assert D % 128 == 0 and D // self.H == 32, "kernels are specialised for head_dim 32"
+        capi.require(D % 128 == 0 and D // self.H == 32, "kernels are specialised for head_dim 32")
         n_lat = cfg["max_seq_len"] // cfg["frame_chunk_size"]
         self.n_lat, self.T = n_lat, 4 * n_lat + 3
         sd = {k[len(prefix):]: v for k, v in state.items() if k.startswith(prefix)} if prefix else state
@@ -317,7 +317,7 @@ class DenoiserSession:
         dev = w.dev
         Bs, B = self.B, word.shape[0]          # session clips, clips of this call
         o0, o1 = offset, offset + B
-        assert 0 <= o0 and o1 <= Bs
+        capi.require(0 <= o0 and o1 <= Bs, "unsupported argument: requires 0 <= o0 and o1 <= Bs")
         mm = motion_mask.to(dev).float()
         self.src_mask[o0:o1].copy_(mm)
         self.src_mask[Bs + o0:Bs + o1].copy_(mm)

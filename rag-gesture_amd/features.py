@@ -167,7 +167,7 @@ class Wav2Vec2Features:
             w = v * (g / v.norm(p=2, dim=(0, 1), keepdim=True))
         C, Cg, K = w.shape                                                                       # [768, 48, 128]
         self.pos_groups, self.pos_k = pos_groups, K
-        assert C // pos_groups == Cg
+        capi.require(C // pos_groups == Cg, "unsupported argument: requires C // pos_groups == Cg")
         pb = sd[pk + "bias"]
         self.pos = [_Linear(w[g * Cg:(g + 1) * Cg].permute(0, 2, 1).reshape(Cg, K * Cg), pb[g * Cg:(g + 1) * Cg], dev, split)
                     for g in range(pos_groups)]

@@ -100,7 +100,8 @@ class LongformSynthesizer:
         for cidx, (c0, c1) in enumerate(zip(starts, ends)):
             t0, t1 = c0 / self.fps, c1 / self.fps
             chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
-            assert chunk["motion"].shape[1] == self.seqlen
+            capi.require(chunk["motion"].shape[1] == self.seqlen,
+                    "unsupported argument: requires chunk[\"motion\"].shape[1] == self.seqlen")
             chunk["motion_length"] = [self.seqlen] * chunk["motion"].shape[0]
             ann = window_annotations(data, t0, t1)
             chunk.update(ann)
@@ -171,7 +172,8 @@ class LongformSynthesizer:
                 t0, t1 = c0 / self.fps, c1 / self.fps
                 data = st["data"]
                 chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
-                assert chunk["motion"].shape[0] == 1 and chunk["motion"].shape[1] == self.seqlen
+                capi.require(chunk["motion"].shape[0] == 1 and chunk["motion"].shape[1] == self.seqlen,
+                        "unsupported argument: requires chunk[\"motion\"].shape[0] == 1 and chunk[\"motion\"].shape[1] == self.seqlen")
                 ann = window_annotations(data, t0, t1)
                 chunk.update(ann)
                 chunk.update(features(ci, cidx, t0, t1, ann))

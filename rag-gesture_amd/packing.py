@@ -60,8 +60,8 @@ def scatter_parts(pred_upper, pred_lower, pred_hands, pred_face):
     """[B,n,39], [B,n,27], [B,n,90], [B,n,3] -> pred_motion [B,n,165] (joints of no part stay zero)."""
     up, lo, ha, fa = _dev(pred_upper), _dev(pred_lower), _dev(pred_hands), _dev(pred_face)
     B, n = up.shape[:2]
-    assert up.shape[-1] == 3 * len(UPPER) and lo.shape[-1] == 3 * len(LOWER) and ha.shape[-1] == 3 * len(HANDS) \
-        and fa.shape[-1] == 3 * len(FACE)
+    capi.require(up.shape[-1] == 3 * len(UPPER) and lo.shape[-1] == 3 * len(LOWER) and ha.shape[-1] == 3 * len(HANDS)
+                 and fa.shape[-1] == 3 * len(FACE), "body-part widths must be 39 / 27 / 90 / 3 (axis-angle, 3 per joint)")
     h = capi.get_handle(up.device.index)
     part, idx = _joint_maps(up.device)
     out = torch.empty(B, n, N_JOINTS * 3, device=up.device)
@@ -91,7 +91,7 @@ def upsample_features(x, scale=2):
 def pack_outputs(output, motion_fps=15, target_fps=30):
     """The dict returned by MotionDiffusion.forward -> (poses [B,N,165], expressions [B,N,100], trans [B,N,3])
     at target_fps, device tensors (visualize.py:204-291, prediction branch)."""
-    assert target_fps % motion_fps == 0
+    capi.require(target_fps % motion_fps == 0, "unsupported argument: requires target_fps % motion_fps == 0")
     scale = target_fps // motion_fps
     poses = scatter_parts(output["pred_upper"], output["pred_lower"], output["pred_hands"], output["pred_facepose"])
     expr, trans = _dev(output["pred_exps"]), _dev(output["pred_transl"])

@@ -141,12 +141,14 @@ class ReGestureTransformer:
                  vae_cfg=None, ffn_cfg=None, text_encoder=None, audio_encoder=None, speaker_embedding=None,
                  use_cache_for_text=False, init_cfg=None, body_part_cat_axis="time", database=None, device="cuda",
                  **_unused):
-        assert not retrieval_train
-        assert body_part_cat_axis == "time", "Only time axis is supported for body part categorization"
+        if _unused:
+            raise capi.RgError("ReGestureTransformer: unknown configuration key(s) %s" % ", ".join(sorted(_unused)))
+        capi.require(not retrieval_train, "retrieval_train is a training-time switch (raggesture.py:900 asserts it off)")
+        capi.require(body_part_cat_axis == "time", "Only time axis is supported for body part categorization")
         for enc in (text_encoder, audio_encoder):
-            assert enc is None or (enc.get("pretrained_model") is None and enc.get("num_layers", 0) == 0
-                                   and not enc.get("use_text_proj", False)), \
-                "only the shipped configuration (pre-extracted features, pre_proj only) is on the hot path"
+            capi.require(enc is None or (enc.get("pretrained_model") is None and enc.get("num_layers", 0) == 0
+                                   and not enc.get("use_text_proj", False)),
+                    "only the shipped configuration (pre-extracted features, pre_proj only) is on the hot path")
         self.cfg = dict(
             latent_dim=latent_dim, time_embed_dim=time_embed_dim, num_layers=num_layers,
             num_heads=(sa_block_cfg or {}).get("num_heads", 16), ff_size=(ffn_cfg or {}).get("ffn_dim", 1024),
@@ -155,7 +157,7 @@ class ReGestureTransformer:
             num_speakers=(speaker_embedding or {}).get("num_speakers", 25),
             scale_func_cfg=scale_func_cfg, per_joint_scale=per_joint_scale,
         )
-        assert scale_func_cfg is not None, "the shipped config always runs the CFG mix (scale_func_cfg)"
+        capi.require(scale_func_cfg is not None, "the shipped config always runs the CFG mix (scale_func_cfg)")
         self.vae_cfgs, self.vae_states = self._read_vae_cfgs(vae_cfg)
         self.retrieval_cfg, self.use_retrieval_for_test = retrieval_cfg, use_retrieval_for_test
         self.database = None
@@ -194,6 +196,49 @@ class ReGestureTransformer:
 IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 
+class AsyncResults(dict):
+    """Result dict of an asynchronously submitted batch (MotionDiffusion(async_results=True), submit() / flush()): the
+    tensors are produced on the batch's own stream, and the FIRST READ of any entry makes the reader's current stream wait for
+    the batch (`done_event`) -- once per reading stream, a device-side wait, the host is not blocked.  Code written against the
+    reference's synchronous results (tools/visualize.py:201-260 indexes `output[...]` right after the call) therefore reads
+    finished tensors without knowing about the pipeline; `done_event` / `done_stream` themselves are read without waiting."""
+    _PLAIN = ("done_event", "done_stream")
+
+    def _ready(self):
+        ev = dict.get(self, "done_event")
+        if ev is None:
+            return
+        st = torch.cuda.current_stream()
+        seen = self.__dict__.setdefault("_waited", set())
+        if st.cuda_stream not in seen:
+            seen.add(st.cuda_stream)
+            st.wait_event(ev)
+            MotionDiffusion._used_on(st, *[v for v in dict.values(self) if torch.is_tensor(v)])
+
+    def __getitem__(self, k):
+        if k not in self._PLAIN:
+            self._ready()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if k not in self._PLAIN:
+            self._ready()
+        return dict.get(self, k, default)
+
+    def values(self):
+        self._ready()
+        return dict.values(self)
+
+    def items(self):
+        self._ready()
+        return dict.items(self)
+
+    def pop(self, k, *default):
+        if k not in self._PLAIN:
+            self._ready()
+        return dict.pop(self, k, *default)
+
+
 @register_module
 class MotionDiffusion(torch.nn.Module):
     """nn.Module like the reference's class (diffusion_architecture.py:64), so the tools' plumbing works on it as
@@ -228,9 +273,10 @@ class MotionDiffusion(torch.nn.Module):
         dt = dict(diffusion_test)
         self.schedule = sched_mod.Schedule(beta_scheduler=dt["beta_scheduler"], diffusion_steps=dt["diffusion_steps"],
                                            respace=dt.get("respace"))
-        assert dt.get("model_mean_type", "start_x") == "start_x" and dt.get("classifier_free_guidance_scale", 0) == 0
+        capi.require(dt.get("model_mean_type", "start_x") == "start_x" and dt.get("classifier_free_guidance_scale", 0) == 0,
+                "unsupported argument: requires dt.get(\"model_mean_type\", \"start_x\") == \"start_x\" and dt.get(\"classifier_free_guidance_scale\", 0) == 0")
         self.inference_type = inference_type
-        assert inference_type in ("ddim", "ddpm"), "inference_type is 'ddim' (shipped config) or 'ddpm'"
+        capi.require(inference_type in ("ddim", "ddpm"), "inference_type is 'ddim' (shipped config) or 'ddpm'")
         self.device, self.precision = torch.device(device), precision
         self.training = False
         self.session_options, self.vae_options = dict(session_options or {}), dict(vae_options or {})
@@ -249,7 +295,8 @@ class MotionDiffusion(torch.nn.Module):
         self._pend, self._cob, self._ready, self._tail_turn = {}, None, collections.deque(), 0
         self._slots, self._submitted = {}, 0
         self.cobatch_lanes = str(cobatch_lanes)
-        assert self.cobatch_lanes in ("batch", "split")
+        capi.require(self.cobatch_lanes in ("batch", "split"),
+                "unsupported argument: requires self.cobatch_lanes in (\"batch\", \"split\")")
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
@@ -492,13 +539,13 @@ class MotionDiffusion(torch.nn.Module):
         prev_latent = inference_kwargs.pop("prev_latent", None)
         tape = inference_kwargs.pop("noise_tape", None) or _TorchNoise(dev)
         if use_prev_latent:
-            assert not use_outpaint
+            capi.require(not use_outpaint, "use_prev_latent excludes use_outpaint (diffusion_architecture.py:227-241)")
         if use_outpaint:
-            assert not use_inversion
-            assert not use_insertion_guidance
+            capi.require(not use_inversion, "use_outpaint excludes use_inversion")
+            capi.require(not use_insertion_guidance, "use_outpaint excludes insertion_guidance")
         if use_insertion_guidance:
-            assert not use_outpaint
-            assert use_inversion
+            capi.require(not use_outpaint, "insertion_guidance excludes use_outpaint")
+            capi.require(use_inversion, "insertion_guidance needs use_inversion")
 
         gre = self.model.gesture_rep_encoder
         ev_inputs = torch.cuda.Event()
@@ -551,7 +598,7 @@ class MotionDiffusion(torch.nn.Module):
                 f(kwargs["motion_upper"]), f(kwargs["motion_lower"]), f(kwargs["motion_face"]), f(kwargs["motion_hands"]),
                 f(kwargs["trans"]), f(kwargs["facial"]), f(kwargs["contact"]), [f(e) for e in eps_list])
         kwargs["trans"].copy_(tr_rel.to(kwargs["trans"].device))  # the reference's in-place re-zeroing
-        assert motion.shape[1] == T
+        capi.require(motion.shape[1] == T, "unsupported argument: requires motion.shape[1] == T")
         kwargs.update({"motion_mask": motion_mask, "text": kwargs["word"], "raw_text": kwargs.get("raw_word"),
                        "text_times": kwargs.get("text_segments")})
         retrieval_dict = kwargs.get("re_dict")
@@ -591,7 +638,7 @@ class MotionDiffusion(torch.nn.Module):
 
         if use_outpaint:
             rml = retrieval_dict["raw_motion_latents"]
-            assert rml.shape[1] == 1
+            capi.require(rml.shape[1] == 1, "unsupported argument: requires rml.shape[1] == 1")
             retrieval_motion_latents = rml.squeeze(1).to(dev).float().contiguous()
         if use_prev_latent and prev_latent is not None:
             prev_latent = prev_latent.to(dev).float()
@@ -832,7 +879,7 @@ class MotionDiffusion(torch.nn.Module):
         for e, (b, q_idx) in enumerate(ex):
             r0, r1 = rd["retr_startends"][b][q_idx]
             q0, q1 = rd["query_startends"][b][q_idx]
-            assert r1 - r0 == q1 - q0
+            capi.require(r1 - r0 == q1 - q0, "unsupported argument: requires r1 - r0 == q1 - q0")
             lvl = st.inversion_start_time % st.S
             h.call("splice_rows", inv[lvl], st.start_noise, st.T, st.D, st.n_lat, e, b, r0, r1, q0, q1)
             if st.use_insertion_guidance:
@@ -952,6 +999,7 @@ class MotionDiffusion(torch.nn.Module):
             # hardware queues: a consumer stream of its own that waits for done_event can block whichever of the
             # caller's / search / lane streams shares its queue, and with it the next batch's front end)
             results["done_event"], results["done_stream"] = done, tail
+            results = AsyncResults(results)      # the first read of an entry waits for the batch on the reader's stream
             self._slot_done[(st.pid, st.slot)] = [done]
             self._inflight.append(done)
             while len(self._inflight) > self.max_inflight:

@@ -628,6 +628,10 @@ class RetrievalDatabase:
     from `metadata` (dict of idx_2_text / idx_2_sense / idx_2_discbounds / idx_2_prominence) or from
     `dataset.retrieval_samples` (raw records, see build_db_dicts)."""
     CACHE_CAP = 4096   # clips kept in the write-only test_indexes / test_dbounds / test_qbounds dicts
+    # keys of the reference's constructor (raggesture.py:159-184) that only size its TRAINING-time retrieval encoders
+    # (never built or used at inference): accepted and ignored, anything else is an error
+    REFERENCE_TRAINING_KEYS = frozenset(("motion_feat_dim", "output_dim", "num_layers", "num_motion_layers", "kinematic_coef",
+                                         "num_heads", "ff_size", "stride", "sa_block_cfg", "ffn_cfg", "dropout"))
 
     def __init__(self, num_retrieval=None, topk=None, latent_dim=512, text_latent_dim=768, max_seq_len=150,
                  motion_fps=15, motion_framechunksize=15, dataset=None, metadata=None, device="cuda", word_similarity=None,
@@ -636,6 +640,9 @@ class RetrievalDatabase:
         """DB metadata, in this order: `metadata=` (the six dicts), the reference's LMDB caches under `lmdb_paths`
         (when readable here and new_lmdb_cache is off, raggesture.py:219-243), `dataset.retrieval_samples` (raw
         records -> build_db_dicts, what the reference does when its caches are empty)."""
+        unknown = sorted(set(_cfg) - self.REFERENCE_TRAINING_KEYS)
+        if unknown:
+            raise capi.RgError("RetrievalDatabase: unknown configuration key(s) %s" % ", ".join(unknown))
         if metadata is None and not new_lmdb_cache:
             metadata = read_lmdb_dicts(lmdb_paths)
         if metadata is None:

@@ -63,7 +63,8 @@ def ddim_guided_sample_loop(sess, x, inverted, guidance_iters, guidance_lr, inse
     mse(x*mask, in_seq) and then ddim_sample re-inserts q_sample(in_seq) on the masked rows."""
     sch, w, h = sess.w.schedule, sess.w, sess.h
     S = sch.num_timesteps
-    assert len(guidance_iters) == S == inverted.shape[0]
+    capi.require(len(guidance_iters) == S == inverted.shape[0],
+            "unsupported argument: requires len(guidance_iters) == S == inverted.shape[0]")
     for i in range(S - 1, -1, -1):
         if i != S - 1:
             in_seq = inverted[i]

@@ -40,7 +40,7 @@ def supported(cfg, T, precision):
 def pack_unit(W):
     """fp32 [512 n, 512 k] -> bf16 [8 waves][64 fragments][64 lanes][8]: fragment (s, j) of wave w, lane (g, nl), element e =
     W[64 w + 16 j + nl][32 s + 8 g + e] (fragment index 4 s + j, lane 16 g + nl)."""
-    assert W.shape == (512, 512)
+    capi.require(W.shape == (512, 512), "unsupported argument: requires W.shape == (512, 512)")
     v = W.to(torch.bfloat16).view(8, 4, 16, 16, 4, 8)          # w, j, nl, s, g, e
     return v.permute(0, 3, 1, 4, 2, 5).contiguous().view(8, 64, 64, 8)
 

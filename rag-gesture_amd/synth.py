@@ -389,6 +389,35 @@ def synth_llm_query(seed):
                 speaker_id=q["speaker_id"], text_features=q["text_features"])
 
 
+def synth_llm_answer(text):
+    """Stand-in for the GPT call of the llm retrieval method (rag/llm_retrieval.py:69-96): names the gesture words it
+    finds in the window's transcript, in the list-of-tuples answer format.  Deterministic, so an LLMResponseCache filled
+    with it during warm-up serves the timed / checked run from cache (BASELINE config 5: cached LLM calls)."""
+    words = [w for w in GESTURE_WORDS if (" " + w + " ") in (" " + text.lower().replace(",", "") + " ")][:2]
+    return "[" + ", ".join('("%s", "%s")' % (w, GESTURE_TYPES[1 + len(w) % 3]) for w in words) + "]"
+
+
+def synth_longform_clip(seed, windows=3, hop_s=9.0, device=None):
+    """One long-form sample of `windows` overlapping 150-frame windows (hop 135 frames = 9 s at 15 fps): the motion-side
+    tensors of synth_batch chained along time plus the transcript annotations the llm method reads (text_segments with
+    word timings, prominence), one synth_llm_query per window shifted to its start."""
+    import torch
+    parts = [synth_batch(1, seed=seed + w, device=device) for w in range(windows)]
+    n = 135 * windows       # sample lengths in (135 (w - 1), 135 w] give w windows (longform_synthesis.py:262-265)
+    clip = {k: torch.cat([p[k] for p in parts], dim=1)[:, :n] for k in parts[0]
+            if torch.is_tensor(parts[0][k]) and parts[0][k].dim() >= 2 and parts[0][k].shape[1] == 150}
+    segs, prom = [], []
+    for w in range(windows):
+        q = synth_llm_query(seed + 10 * w + 1)
+        sh = hop_s * w + 0.3
+        segs += [[[t[0][0] + sh, t[0][1] + sh], t[1]] for t in q["text_times"] if t[0][1] + sh < hop_s * (w + 1)]
+        prom += [(p[0], p[1] + sh, p[2] + sh, p[3]) for p in q["prominence"] if p[2] + sh < hop_s * (w + 1)]
+    clip["text_segments"], clip["prominence"] = [segs], [prom]
+    clip["discourse"], clip["gesture_labels"] = [[]], [[]]
+    clip["sample_name"] = ["9_longform_%d_0/0" % seed]
+    return clip
+
+
 def synth_retrieval_samples(n_entries, seed=2025, n_speakers=25, feat_dim=768, tie_groups=True, feat_device=None):
     """Raw per-sample records with the fields the reference's DB builder reads
     (raggesture.py:244-293): sample_name, speaker_id, discourse (8-tuples

@@ -71,7 +71,7 @@ class TransformerVAE:
     def __init__(self, state, vcfg, device="cuda", precision="bf16", chain=True):
         """chain: bf16 path only -- producers hand bf16 copies to the GEMMs that consume them (False: every GEMM converts
         its fp32 operand tiles itself; a measurement knob)."""
-        assert vcfg.get("vae_dist", "normal") == "normal", "only the Normal posterior is supported"
+        capi.require(vcfg.get("vae_dist", "normal") == "normal", "only the Normal posterior is supported")
         self.cfg = vcfg
         self.dev = torch.device(device)
         self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
@@ -163,7 +163,7 @@ class TransformerVAE:
                                         vp(o.data_ptr()), self.D, 1 if o.dtype == torch.bfloat16 else 0, B, heads, Sq, Sk, hd,
                                         vp(s))
         else:
-            assert o.dtype == torch.float32
+            capi.require(o.dtype == torch.float32, "unsupported argument: requires o.dtype == torch.float32")
             rc = self.h.lib.rg_mha(self.h._h, vp(q.data_ptr()), ldq, vp(k.data_ptr()), ldk, vp(v.data_ptr()), ldv,
                                    vp(o.data_ptr()), self.D, B, heads, Sq, Sk, hd, vp(s))
         if rc != 0:

@@ -141,3 +141,62 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
     with pytest.raises(rg.capi.RgError):
         model.submit(**args(0))
     assert model.flush() == []
+
+
+def _tool_body(rg, output):
+    """tools/visualize.py:201-291 restated: index the result dict right after the call (no explicit wait: the first read of
+    an asynchronous result makes the reader's stream wait, pipeline.AsyncResults), scatter the body parts into the 55-joint
+    pose, interpolate 15 -> 30 fps through 6D, move to the host."""
+    pred_motion = rg.packing.scatter_parts(output["pred_upper"], output["pred_lower"], output["pred_hands"], output["pred_facepose"])
+    pred_motion = rg.packing.upsample_motion(pred_motion, 2)
+    pred_facial = rg.packing.upsample_features(output["pred_exps"].float(), 2)
+    pred_trans = rg.packing.upsample_features(output["pred_transl"].float(), 2)
+    return [t.cpu().numpy() for t in (pred_motion, pred_facial, pred_trans)]
+
+
+def test_unchanged_tool_loop_and_three_line_pipelined_loop(rg):
+    """(i) the reference tool's loop as written -- `output = model(**data)` then its body -- on a model with
+    async_results=True: correct without any change (lazy results), throughput of the synchronous path;
+    (ii) the three-line change of INTEGRATION.md -- `output = model.submit(**data)`, skip while None, `model.flush()` behind
+    the loop -- gives every batch the same bits from the co-batched pipeline."""
+    import numpy as np
+    dev = torch.device("cuda", 0)
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    db = rg.synth.SyntheticDataset(512, seed=11, device=dev, feat_device=dev)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=db, device=dev)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+    batches = _batches(rg, 4, 5, dev)
+
+    def args(i):
+        d = dict(batches[i])
+        d["trans"] = batches[i]["trans"].clone()
+        return dict(d, retrieval_method="discourse",
+                    inference_kwargs=dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1,
+                                          noise_tape=rg.synth.NoiseTape(4100 + i)))
+
+    want = []
+    for i in range(len(batches)):           # synchronous model: the reference's semantics
+        with torch.no_grad():
+            want.append(_tool_body(rg, model(**args(i))))
+    model.async_results = True
+    got = []
+    for i in range(len(batches)):           # (i) the same loop, unchanged
+        with torch.no_grad():
+            output = model(**args(i))
+        assert isinstance(output, rg.pipeline.AsyncResults)
+        got.append(_tool_body(rg, output))
+    for a, b in zip(got, want):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    got = []
+    for i in range(len(batches)):           # (ii) three changed lines
+        with torch.no_grad():
+            output = model.submit(**args(i))
+        if output is None:
+            continue
+        got.append(_tool_body(rg, output))
+    got += [_tool_body(rg, output) for output in model.flush()]
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))

@@ -153,3 +153,62 @@ def test_longform_run_many_shards_clips_over_ranks():
     (r0, g0, m0), (r1, g1, m1) = out[2]
     assert m0 == [0, 1, 2] and m1 == [3, 4], "contiguous balanced shards (dist.shard_range)"
     assert g0 == g1 == single, "every rank ends with every clip's result, equal to the single-process run"
+
+
+# ---- the loop the driver launches with `--gpus N`: bench.run_steps (pipeline with late results + ONE all-gather at the end)
+class _StubWorkload:
+    """Hands results out two calls late, like the co-batched pipeline with whole batches alternating between two lanes."""
+
+    def __init__(self, rank, B=4):
+        self.rank, self.B, self.n, self.pending = rank, B, 0, []
+
+    def _result(self, k):
+        return torch.full((self.B, 150, 268), float(100 * self.rank + k))
+
+    def step(self):
+        self.pending.append(self._result(self.n))
+        self.n += 1
+        return self.pending.pop(0) if len(self.pending) > 2 else None
+
+    def drain(self):
+        out, self.pending = self.pending, []
+        return out
+
+
+def _bench_worker(rank, world, port, steps, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bench = importlib.import_module("bench")
+    wl = _StubWorkload(rank)
+    synced = []
+    got = bench.run_steps(wl, steps, dist, world, lambda: synced.append(True))
+    ok = tuple(got.shape) == (world * steps * wl.B, 150, 268) and synced == [True] and wl.pending == []
+    for r in range(world):          # rank r's batches, in submission order, in rank r's block of the gathered tensor
+        for k in range(steps):
+            blk = got[(r * steps + k) * wl.B:(r * steps + k + 1) * wl.B]
+            ok = ok and bool((blk == float(100 * r + k)).all())
+    # a second call on the same workload object (bench.py runs warm-up steps, then the timed steps)
+    got2 = bench.run_steps(wl, 1, dist, world, None)
+    ok = ok and tuple(got2.shape) == (world * wl.B, 150, 268) and bool((got2[:wl.B] == float(steps)).all())
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_bench_run_steps_gathers_once_at_the_end_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, 29613, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_run_steps_single_process_returns_the_list():
+    bench = importlib.import_module("bench")
+    wl = _StubWorkload(0)
+    out = bench.run_steps(wl, 4)
+    assert len(out) == 4 and all(float(o[0, 0, 0]) == k for k, o in enumerate(out))

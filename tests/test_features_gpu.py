@@ -16,7 +16,7 @@ def relerr(a, b):
     return ((a - b).norm() / b.norm()).item()
 
 
-def test_bert_last_four_hidden_states(rg):
+def test_bert_last_four_hidden_states(rg, parity):
     torch.manual_seed(0)
     cfg = transformers.BertConfig(vocab_size=28996)          # bert-base-cased: 12 layers, 768 wide, 12 heads, gelu, eps 1e-12
     model = transformers.BertModel(cfg, add_pooling_layer=False).eval()
@@ -34,11 +34,11 @@ def test_bert_last_four_hidden_states(rg):
             assert len(st) == 13 and got.shape == (L, 768)
             e0 = relerr(st[0].cpu(), hs[0][0])
             e = relerr(got.cpu(), ref)
-            print("BERT L=%d %s: embeddings %.2e, sum of last four layers %.3e" % (L, precision, e0, e))
-            assert e0 <= 1e-5 and e <= tol
+            parity.check("BERT-base L=%d %s: embeddings vs transformers" % (L, precision), e0, 1e-5)
+            parity.check("BERT-base L=%d %s: sum of the last four layers vs transformers" % (L, precision), e, tol)
 
 
-def test_wav2vec2_last_hidden_state(rg):
+def test_wav2vec2_last_hidden_state(rg, parity):
     torch.manual_seed(1)
     cfg = transformers.Wav2Vec2Config()                       # wav2vec2-base: conv (512 x 7, group norm), 12 post-norm layers
     assert cfg.feat_extract_norm == "group" and not cfg.do_stable_layer_norm and cfg.num_conv_pos_embeddings == 128
@@ -56,8 +56,8 @@ def test_wav2vec2_last_hidden_state(rg):
         torch.cuda.synchronize()
         assert conv.shape == (499, 512) and got.shape == (499, 768)
         ec, e = relerr(conv.cpu(), ref_conv), relerr(got.cpu(), ref)
-        print("wav2vec2 %s: conv features %.3e, last hidden state %.3e" % (precision, ec, e))
-        assert ec <= tol_conv and e <= tol
+        parity.check("wav2vec2-base %s: conv features vs transformers" % precision, ec, tol_conv)
+        parity.check("wav2vec2-base %s: last hidden state vs transformers" % precision, e, tol)
 
 
 def test_window_features_callback(rg):

@@ -8,21 +8,23 @@ Clips are independent, so clip i of the batched HIP run must equal a batch-of-on
 inputs and clip i's share of the noise.  The batched run's explicit noise tape is recorded; ClipTape replays, in the
 oracle's draw order, the rows that belong to one clip (VAE noise rows [10 i, 10 i + 10), the exemplar-encode draws of
 the clip's own exemplars, row i of every [B, 43, 512] draw).
-Bars: retrieved samples, bounds and placement exact; final latent <= 3e-2 relative (bf16 operands vs fp32, rows 10/20/30
-excluded as everywhere); decoded translation <= 5e-2.
+Bars: retrieved samples, bounds and placement exact; final latent <= 1e-2 relative over all kept rows and <= 3e-2 on the
+worst token row (bf16 operands vs fp32, rows 10/20/30 excluded as everywhere); decoded translation
+<= 3e-2.  Every measured value goes through the `parity` recorder (tests/conftest.py) and is printed with the run.
+
+  config 3 as BENCHMARKED: three different B = 16 batches through model.submit() / flush() (asynchronous results, the
+            sampling loop of batch n sharing its denoiser launches with the exemplar inversion of batch n + 1 / n + 2, whole
+            batches alternating between two lanes): clips {0, 7, 15} of the MIDDLE batch against the per-clip oracle.
 """
 import pytest
 import torch
 
+from conftest import relerr, rowerr
 from oracle import diffusion as odf, pipeline as opipe, retrieval as oret
 
 pytestmark = pytest.mark.gpu
 KEEP = [r for r in range(43) if r not in (10, 20, 30)]
 GI = [0] * 25 + list(range(25))
-
-
-def relerr(a, b):
-    return ((a - b).norm() / b.norm()).item()
 
 
 class RecordingTape:
@@ -69,37 +71,35 @@ def _clip(data, i):
     return out
 
 
-def test_config3_guided_b16_full_db_vs_oracle(rg):
-    dev = torch.device("cuda", 0)
-    B, N_DB = 16, 32768
+def _guided_setup(rg, dev, B, n_db):
     cfg = rg.synth.default_model_cfg(num_layers=8)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
-    database = rg.synth.SyntheticDataset(N_DB, seed=2025, device=dev, feat_device=dev)
+    database = rg.synth.SyntheticDataset(n_db, seed=2025, device=dev, feat_device=dev)
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=database,
                                   device=dev)
     P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
     model.load_state_dict(P)
     model.eval()
     assert model.precision == "bf16" and model.lanes >= 2
-    data = rg.synth.synth_batch(B, seed=1234, device=dev)
-    qs = [rg.synth.synth_query(i) for i in range(B)]
+    cpu_db = oret.build_db_dicts([dict(r, text_feature=r["text_feature"].cpu()) for r in database.retrieval_samples])
+    return cfg, vae_cfgs, database, model, P, cpu_db
+
+
+def _guided_batch(rg, dev, B, seed, q0):
+    data = rg.synth.synth_batch(B, seed=seed, device=dev)
+    qs = [rg.synth.synth_query(q0 + i) for i in range(B)]
     data["discourse"] = [q["discourse"] for q in qs]
     data["prominence"] = [q["prominence"] for q in qs]
     data["text_features"] = [q["text_features"].to(dev) for q in qs]
     data["speaker_ids"] = torch.tensor([[q["speaker_id"]] * 150 for q in qs], device=dev)
-    ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
-    tape = RecordingTape(rg.synth.NoiseTape(9))
-    keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}   # forward re-zeroes trans in place
-    out = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=tape)))
-    torch.cuda.synchronize()
-    ex = model.model.database.last_exemplars
-    assert len(ex) >= B, "the synthetic queries should retrieve exemplars"
-    rd = out["retrieval_dict"]
+    return data
 
-    cpu_db = oret.build_db_dicts([dict(r, text_feature=r["text_feature"].cpu()) for r in database.retrieval_samples])
+
+def _check_clips(rg, parity, tag, clips, B, P, cfg, vae_cfgs, cpu_db, keep, tape, ex, out, ikw):
+    rd = out["retrieval_dict"]
     cpu_ds = rg.synth.SyntheticDataset(0)
     torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
-    for i in (0, 7, 15):
+    for i in clips:
         cdata = _clip(keep, i)
         ccond = dict(text_features=cdata["text_features"], discourse=cdata["discourse"], prominence=cdata["prominence"],
                      speaker_ids=cdata["speaker_ids"])
@@ -116,13 +116,58 @@ def test_config3_guided_b16_full_db_vs_oracle(rg):
         assert rd["query_startends"][i] == got["re"]["query_startends"][0]
         assert list(rd["retr_uncropped_latents"][i].keys()) == list(got["re"]["retr_uncropped_latents"][0].keys())
         assert len(rd["retr_startends"][i]) >= 1
-        e = relerr(out["prev_latentout"][i:i + 1].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP])
-        et = relerr(out["pred_transl"][i:i + 1].cpu(), ref["pred_transl"])
-        print("config 3, clip %d: %d exemplars, final latent rel err %.3e, transl %.3e" % (i, len(rd["retr_startends"][i]), e, et))
-        assert e <= 3e-2 and et <= 5e-2
+        lat, rlat = out["prev_latentout"][i:i + 1].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP]
+        parity.check("%s clip %d (%d exemplars): final latent, norm ratio" % (tag, i, len(rd["retr_startends"][i])), relerr(lat, rlat), 1e-2)
+        parity.check("%s clip %d: final latent, worst token row" % (tag, i), rowerr(lat, rlat), 3e-2)
+        parity.check("%s clip %d: decoded translation, norm ratio" % (tag, i), relerr(out["pred_transl"][i:i + 1].cpu(), ref["pred_transl"]), 3e-2)
 
 
-def test_config2_base_b32_vs_oracle(rg):
+def test_config3_guided_b16_full_db_vs_oracle(rg, parity):
+    dev = torch.device("cuda", 0)
+    B, N_DB = 16, 32768
+    cfg, vae_cfgs, database, model, P, cpu_db = _guided_setup(rg, dev, B, N_DB)
+    data = _guided_batch(rg, dev, B, 1234, 0)
+    ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    tape = RecordingTape(rg.synth.NoiseTape(9))
+    keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}   # forward re-zeroes trans in place
+    out = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=tape)))
+    torch.cuda.synchronize()
+    ex = model.model.database.last_exemplars
+    assert len(ex) >= B, "the synthetic queries should retrieve exemplars"
+    _check_clips(rg, parity, "config 3 (synchronous forward)", (0, 7, 15), B, P, cfg, vae_cfgs, cpu_db, keep, tape, ex, out, ikw)
+
+
+def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity):
+    """What bench.py times: asynchronous submission, co-batched pipeline, whole batches alternating between the lanes.  The
+    middle one of three different batches has its sampling loop co-batched with a later batch's exemplar inversion and its
+    own inversion with an earlier batch's sampling: every step-group code path and the real exemplar counts meet the
+    independent reference here."""
+    dev = torch.device("cuda", 0)
+    B, N_DB = 16, 32768
+    cfg, vae_cfgs, database, model, P, cpu_db = _guided_setup(rg, dev, B, N_DB)
+    model.async_results = True
+    ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    outs, keeps, tapes, exs = [], [], [], []
+    for n in range(3):
+        data = _guided_batch(rg, dev, B, 1234 + 17 * n, 100 * n)
+        keeps.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()})
+        tapes.append(RecordingTape(rg.synth.NoiseTape(90 + n)))
+        r = model.submit(**dict(data, retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=tapes[-1])))
+        exs.append(list(model.model.database.last_exemplars))
+        if r is not None:
+            outs.append(r)
+    outs += model.flush()
+    assert len(outs) == 3
+    for r in outs:
+        model.wait_results(r)
+    torch.cuda.synchronize()
+    assert len(exs[1]) >= B
+    assert not torch.equal(outs[0]["prev_latentout"], outs[1]["prev_latentout"])
+    _check_clips(rg, parity, "config 3 as benchmarked (submit / flush, middle batch)", (0, 7, 15), B, P, cfg, vae_cfgs, cpu_db,
+                 keeps[1], tapes[1], exs[1], outs[1], ikw)
+
+
+def test_config2_base_b32_vs_oracle(rg, parity):
     dev = torch.device("cuda", 0)
     B = 32
     cfg = rg.synth.default_model_cfg(num_layers=8)
@@ -141,7 +186,7 @@ def test_config2_base_b32_vs_oracle(rg):
         ct = ClipTape(tape.record, i, B, [])
         with torch.no_grad():
             ref = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), _clip(keep, i), ct)
-        e = relerr(out["prev_latentout"][i:i + 1].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP])
-        et = relerr(out["pred_transl"][i:i + 1].cpu(), ref["pred_transl"])
-        print("config 2, clip %d: final latent rel err %.3e, transl %.3e" % (i, e, et))
-        assert e <= 3e-2 and et <= 5e-2
+        lat, rlat = out["prev_latentout"][i:i + 1].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP]
+        parity.check("config 2 clip %d: final latent, norm ratio" % i, relerr(lat, rlat), 1e-2)
+        parity.check("config 2 clip %d: final latent, worst token row" % i, rowerr(lat, rlat), 3e-2)
+        parity.check("config 2 clip %d: decoded translation, norm ratio" % i, relerr(out["pred_transl"][i:i + 1].cpu(), ref["pred_transl"]), 3e-2)

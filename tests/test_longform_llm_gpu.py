@@ -10,6 +10,7 @@ import torch
 from oracle import retrieval as oret
 
 pytestmark = pytest.mark.gpu
+KEEP = [r for r in range(43) if r not in (10, 20, 30)]
 
 
 def _answer(rg):
@@ -73,3 +74,79 @@ def test_longform_llm_guidance_windows(rg, tmp_path):
         assert rdb.test_dbounds[name]["llm"] == want[1] and rdb.test_qbounds[name]["llm"] == want[2]
         n_exemplars += len(want[0])
     assert n_exemplars >= 2
+
+
+def test_config5_one_clip_three_windows_l8_vs_oracle(rg, tmp_path, parity):
+    """BASELINE config 5 at full depth (8 denoiser layers, bf16), one clip x 3 windows, exactly the flags of
+    tools/longform_synthesis.py:389-403 -- retrieval_method="llm" on cached LLM answers (default word similarity = the
+    reference's effective fuzz.partial_ratio / 100), use_inversion + insertion_guidance + use_prev_latent per window,
+    prev-latent chaining, overlap blend, 30 fps -- against the oracle pipeline driven by the same loop: retrieval results
+    exact per window, latents / poses within the bf16 bars."""
+    from oracle import diffusion as odf, fuzzy as ofz, packing as opk, pipeline as opipe, rotation as orot
+    GI = [0] * 25 + list(range(25))
+    cfg = rg.synth.default_model_cfg(num_layers=8)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    ds = rg.synth.SyntheticDataset(300, seed=31)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds, precision="bf16")
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    model.load_state_dict(P)
+    model.eval()
+    rdb = model.model.database
+    cache = rg.retrieval.LLMResponseCache(str(tmp_path / "llm_cache.json"), call=rg.synth.synth_llm_answer)
+    rdb.llm_output = cache.get
+    clip = rg.synth.synth_longform_clip(40, windows=3)
+    feats = [rg.synth.synth_query(200 + i) for i in range(3)]
+    audio = [rg.synth.synth_batch(1, seed=100 + i)["audio"] for i in range(3)]
+    seen = {}
+
+    def features(cidx, t0, t1, ann):
+        text = " ".join(s[1] for s in ann["text_segments"][0])
+        seen[cidx] = dict(text=text, ann=ann)
+        return dict(audio=audio[cidx], raw_word=[text], text_features=[feats[cidx]["text_features"]])
+
+    synth = rg.longform.LongformSynthesizer(model, overlap=15)
+    flags = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    got = synth.run({k: (v.clone() if torch.is_tensor(v) else v) for k, v in clip.items()}, features, retrieval_method="llm",
+                    noise_tape=rg.synth.NoiseTape(5), **flags)
+    assert got["windows"] == [(0, 150), (135, 285), (270, 420)] and got["poses"].shape == (810, 165)
+    assert sum(bool(seen[c]["text"]) for c in range(3)) == 3 and cache.misses == 3
+
+    # ---- oracle loop (same noise tape order, same cached answers)
+    odb = oret.build_db_dicts(ds.retrieval_samples)
+    sim = lambda a, b: ofz.partial_ratio(a, b) / 100
+    otape, sch = rg.synth.NoiseTape(5), odf.SpacedSchedule()
+    starts, ends, rem = opk.window_bounds(405)
+    od = rg.longform.pad_tail({k: (v.clone() if torch.is_tensor(v) else v) for k, v in clip.items()}, rem)
+    spk = int(clip["speaker_ids"][0, 0])
+    prev, so_far, n_ex = None, None, 0
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    for cidx, (c0, c1) in enumerate(zip(starts, ends)):
+        chunk = {k: od[k][:, c0:c1] for k in od if torch.is_tensor(od[k])}
+        chunk["audio"] = audio[cidx]
+        ann, name = seen[cidx]["ann"], "9_longform_40_0/%d" % cidx
+        want = oret.llm_retrieval(seen[cidx]["text"], ann["text_segments"][0], spk, ann["prominence"][0], odb["idx_2_gesture_labels"],
+                                  odb["idx_2_gestprom"], feats[cidx]["text_features"], odb["idx_2_text"], sim, cache.get)
+        assert rdb.test_indexes[name]["llm"] == want[0], "window %d: llm retrieval differs from the oracle" % cidx
+        assert rdb.test_dbounds[name]["llm"] == want[1] and rdb.test_qbounds[name]["llm"] == want[2]
+        n_ex += len(want[0])
+        cond = dict(text_features=[feats[cidx]["text_features"]], speaker_ids=chunk["speaker_ids"])
+        with torch.no_grad():
+            o = opipe.motion_diffusion_forward(
+                P, cfg, vae_cfgs, sch, chunk, otape, use_prev_latent=True, prev_latent=prev,
+                re_dict=lambda tp: oret.database_forward(P, vae_cfgs, odb, ds, cond, [name], tp, retrieval_method="llm",
+                                                         retrieve=lambda b: want), **flags)
+        lat = got["latents"][cidx].cpu()
+        parity.check("config 5 (llm, L8, bf16) window %d: final latent vs oracle" % cidx,
+                     ((lat - o["prev_latentout"])[:, KEEP].norm() / o["prev_latentout"][:, KEEP].norm()).item(), 1.5e-2)
+        prev = o["prev_latentout"]
+        cur = (opk.scatter_parts(o["pred_upper"], o["pred_lower"], o["pred_hands"], o["pred_facepose"]), o["pred_exps"], o["pred_transl"])
+        so_far = cur if cidx == 0 else opk.blend_window(*so_far, *cur, 15)
+    assert cache.misses == 3 and cache.hits >= 3, "the oracle loop was served from the response cache"
+    assert n_ex >= 2, "the windows should retrieve exemplars"
+    want_m = opk.interp_motion(so_far[0], 2)[0, :810]
+    want_f, want_t = opk.interp_features(so_far[1], 2)[0, :810], opk.interp_features(so_far[2], 2)[0, :810]
+    rel = lambda x, y: ((x - y).norm() / y.norm()).item()
+    ma = orot.axis_angle_to_matrix(torch.from_numpy(got["poses"]).reshape(-1, 3))
+    parity.check("config 5 (llm, L8, bf16): 30-fps poses vs oracle loop (rotation matrices)", rel(ma, orot.axis_angle_to_matrix(want_m.reshape(-1, 3))), 3e-2)
+    parity.check("config 5 (llm, L8, bf16): expressions", rel(torch.from_numpy(got["expressions"]), want_f), 3e-2)
+    parity.check("config 5 (llm, L8, bf16): trans", rel(torch.from_numpy(got["trans"]), want_t), 3e-2)

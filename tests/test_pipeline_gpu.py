@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import rowerr
+
 from oracle import pipeline as opipe
 
 pytestmark = pytest.mark.gpu
@@ -47,7 +49,7 @@ def models(rg):
 @pytest.mark.parametrize("tag,arch,vkw", [("L2_allenc", "all_encoder", None),
                                           ("L8_encdec", "encoder_decoder", dict(num_layers=4, ff_size=512))])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_vae_encode_decode(rg, golden_dir, tag, arch, vkw, precision):
+def test_vae_encode_decode(rg, parity, golden_dir, tag, arch, vkw, precision):
     g = np.load(os.path.join(golden_dir, "vae_%s.npz" % tag))
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch=arch, **(vkw or {}))
     P = {}
@@ -63,8 +65,7 @@ def test_vae_encode_decode(rg, golden_dir, tag, arch, vkw, precision):
                            [tape.draw((B * 10, 1, 512)) for _ in range(4)])
     ref = torch.from_numpy(g["enc_latent"])
     e = relerr(lat.cpu(), ref)
-    print(tag, precision, "encode rel err %.3e" % e)
-    assert e <= (2e-4 if precision == "fp32" else 2e-2)
+    parity.check("VAE encode %s %s: latent vs reference golden" % (tag, precision), e, 5e-5 if precision == "fp32" else 1e-2)
     assert mask.shape == (B, 43) and mask[:, [10, 21, 32]].sum() == 0
     # the reference re-zeroes trans x/z in place
     assert torch.equal(data["trans"][:, :, 1], trans_in[:, :, 1]) and data["trans"][:, 0, 0].abs().max() == 0
@@ -75,8 +76,8 @@ def test_vae_encode_decode(rg, golden_dir, tag, arch, vkw, precision):
     for nm, a in zip(("upper", "lower", "face", "hands", "transl", "exps", "contact"), dec):
         r = torch.from_numpy(g["dec_" + nm])
         e = rot_relerr(a.cpu(), r) if nm in ROT else relerr(a.cpu(), r)
-        print(tag, precision, "decode", nm, "rel err %.3e  max abs %.3e" % (e, (a.cpu() - r).abs().max().item()))
-        assert e <= (2e-3 if precision == "fp32" else 5e-2), nm
+        parity.check("VAE decode %s %s: %s vs reference golden%s" % (tag, precision, nm, " (rotation matrices)" if nm in ROT else ""), e,
+                     2e-4 if precision == "fp32" else 3e-2)
 
 
 RUNS = [("base", dict(), False),
@@ -89,7 +90,7 @@ RUNS = [("base", dict(), False),
 
 @pytest.mark.parametrize("rtag,ikw,need_re", RUNS)
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_end_to_end_vs_reference_golden(rg, models, golden_dir, rtag, ikw, need_re, precision):
+def test_end_to_end_vs_reference_golden(rg, parity, models, golden_dir, rtag, ikw, need_re, precision):
     model = models[("L2", precision)]
     g = np.load(os.path.join(golden_dir, "e2e_L2_allenc.npz"))
     B = 2
@@ -104,21 +105,23 @@ def test_end_to_end_vs_reference_golden(rg, models, golden_dir, rtag, ikw, need_
     torch.cuda.synchronize()
     lat, ref = out["prev_latentout"].cpu(), torch.from_numpy(g["%s_prev_latentout" % rtag])
     e = relerr(lat[:, KEEP], ref[:, KEEP])
-    print(rtag, precision, "final latent rel err (rows != 10,20,30) %.3e" % e)
     # fp32 mode: what remains is the reference's platform-dependent LayerNorm rounding on the three
-    # -1e6 rows leaking through self-attention; bf16 mode: operand rounding
-    # (measured 9e-4 in fp32 mode)
-    assert e <= (2e-3 if precision == "fp32" else 3e-2)
+    # -1e6 rows leaking through self-attention (against the exact-LN oracle the same run is at 1e-4, see
+    # test_end_to_end_all_token_rows_vs_exact_ln_oracle); bf16 mode: operand rounding
+    parity.check("e2e L2 %s %s: final latent vs reference golden, norm ratio" % (rtag, precision), e, 2e-3 if precision == "fp32" else 1e-2)
+    parity.check("e2e L2 %s %s: final latent vs reference golden, worst token row" % (rtag, precision), rowerr(lat[:, KEEP], ref[:, KEEP]),
+                 1e-2 if precision == "fp32" else 3e-2)
     for k in ("pred_upper", "pred_lower", "pred_facepose", "pred_hands", "pred_transl", "pred_exps"):
         r = torch.from_numpy(g["%s_%s" % (rtag, k)])
         ek = rot_relerr(out[k].cpu(), r) if k in ROT else relerr(out[k].cpu(), r)
-        print("   ", k, "rel err %.3e" % ek)
         assert out[k].shape == r.shape
-        assert ek <= (3e-2 if precision == "fp32" else 8e-2), k
+        # (pred_hands: 30 joints x 3, the longest decoder chain behind the LayerNorm-quirk rows of the fp32 comparison)
+        parity.check("e2e L2 %s %s: %s vs reference golden" % (rtag, precision, k), ek,
+                     (6e-3 if k == "pred_hands" else 3e-3) if precision == "fp32" else 3e-2)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_end_to_end_with_retrieval_database_vs_oracle(rg, precision):
+def test_end_to_end_with_retrieval_database_vs_oracle(rg, parity, precision):
     """build_architecture(cfg.model, database=train_dataset) with use_retrieval_for_test: discourse
     retrieval over the replicated DB (HIP sweep), exemplar encode, batched inversion, guided sampling --
     against the oracle run of the same chain (retrieval indices/placement exact, latents close), in the
@@ -158,12 +161,11 @@ def test_end_to_end_with_retrieval_database_vs_oracle(rg, precision):
     assert sum(len(x) for x in rd["retr_startends"]) >= 2, "the synthetic queries should retrieve exemplars"
     lat, r = out["prev_latentout"].cpu(), ref["prev_latentout"]
     e = relerr(lat[:, KEEP], r[:, KEEP])
-    print("e2e with retrieval DB (%s): final latent rel err %.3e" % (precision, e))
-    assert e <= (2e-3 if precision == "fp32" else 3e-2)
+    parity.check("e2e with retrieval DB %s: final latent vs oracle" % precision, e, 2e-3 if precision == "fp32" else 1e-2)
 
 
 @pytest.mark.parametrize("rtag,ikw,need_re", RUNS[:2])
-def test_end_to_end_all_token_rows_vs_exact_ln_oracle(rg, models, rtag, ikw, need_re):
+def test_end_to_end_all_token_rows_vs_exact_ln_oracle(rg, parity, models, rtag, ikw, need_re):
     """Rows 20 and 30 are real hands / face tokens whose cross-attention queries the reference masks
     (diffusion_architecture.py:155); the goldens of the real reference cannot pin them tightly because torch's
     LayerNorm of (y - 1e6) rounds platform-dependently.  Against the oracle in masked_ln="exact"
@@ -192,8 +194,9 @@ def test_end_to_end_all_token_rows_vs_exact_ln_oracle(rg, models, rtag, ikw, nee
     lat, r = out["prev_latentout"].cpu(), ref["prev_latentout"]
     e_all = relerr(lat[:, tokens], r[:, tokens])
     e_2030 = relerr(lat[:, [20, 30]], r[:, [20, 30]])
-    print(rtag, "fp32 mode vs exact-LN oracle: all token rows %.3e, rows 20/30 %.3e" % (e_all, e_2030))
-    assert e_all <= 2e-3 and e_2030 <= 2e-3
+    parity.check("e2e L2 %s fp32 mode vs exact-LN oracle: all token rows" % rtag, e_all, 1e-4)
+    parity.check("e2e L2 %s fp32 mode vs exact-LN oracle: rows 20 / 30" % rtag, e_2030, 1e-4)
+    parity.check("e2e L2 %s fp32 mode vs exact-LN oracle: worst token row" % rtag, rowerr(lat[:, tokens], r[:, tokens]), 5e-4)
 
 
 def test_concurrent_lanes_equal_single_lane(rg, models):
@@ -217,7 +220,7 @@ def test_concurrent_lanes_equal_single_lane(rg, models):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_outpaint_vs_oracle(rg, models, precision):
+def test_outpaint_vs_oracle(rg, parity, models, precision):
     """inference_kwargs["outpaint"]: the retrieved latents (re_dict["raw_motion_latents"]) are re-inserted as
     q_sample(in_seq) on every step (diffusion_architecture.py:283-292, 566-573).  No reference golden for this
     mode; the oracle's in_seq path is the one pinned bit-exact by the prev-latent goldens."""
@@ -240,13 +243,12 @@ def test_outpaint_vs_oracle(rg, models, precision):
         ref = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), rg.synth.synth_batch(B, seed=4321),
                                              rg.synth.NoiseTape(606), re_dict=re, outpaint=True)
     e = relerr(out["prev_latentout"].cpu()[:, KEEP], ref["prev_latentout"][:, KEEP])
-    print("outpaint", precision, "final latent rel err %.3e" % e)
-    assert e <= (1e-2 if precision == "fp32" else 3e-2)
+    parity.check("outpaint %s: final latent vs oracle" % precision, e, 2e-3 if precision == "fp32" else 1e-2)
 
 
 @pytest.mark.parametrize("rtag,ikw,need_re", RUNS[:2])
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_full_depth_end_to_end_vs_reference_golden(rg, golden_dir, rtag, ikw, need_re, precision):
+def test_full_depth_end_to_end_vs_reference_golden(rg, parity, golden_dir, rtag, ikw, need_re, precision):
     """The configuration of the released model: 8 denoiser layers, encoder_decoder VAE stacks (29 blocks),
     base and guided runs against the real reference's outputs (tests/golden/e2e_L8_encdec.npz, batch of one)."""
     cfg = rg.synth.default_model_cfg(num_layers=8)
@@ -263,13 +265,15 @@ def test_full_depth_end_to_end_vs_reference_golden(rg, golden_dir, rtag, ikw, ne
     e = relerr(lat[:, KEEP], ref[:, KEEP])
     et = relerr(out["pred_transl"].cpu(), torch.from_numpy(g["%s_pred_transl" % rtag]))
     eu = rot_relerr(out["pred_upper"].cpu(), torch.from_numpy(g["%s_pred_upper" % rtag]))
-    print("L8 encdec", rtag, precision, "latent %.3e transl %.3e upper(rot) %.3e" % (e, et, eu))
-    assert e <= (1e-2 if precision == "fp32" else 3e-2)
-    assert et <= 5e-2 and eu <= 5e-2
+    parity.check("e2e L8 encdec %s %s: final latent vs reference golden" % (rtag, precision), e, 5e-3 if precision == "fp32" else 1e-2)
+    parity.check("e2e L8 encdec %s %s: final latent, worst token row" % (rtag, precision), rowerr(lat[:, KEEP], ref[:, KEEP]),
+                 1e-2 if precision == "fp32" else 3e-2)
+    parity.check("e2e L8 encdec %s %s: pred_transl" % (rtag, precision), et, 3e-3 if precision == "fp32" else 3e-2)
+    parity.check("e2e L8 encdec %s %s: pred_upper (rotation matrices)" % (rtag, precision), eu, 3e-3 if precision == "fp32" else 3e-2)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_ddpm_inference_type_vs_reference_golden(rg, golden_dir, precision):
+def test_ddpm_inference_type_vs_reference_golden(rg, parity, golden_dir, precision):
     """inference_type="ddpm": ancestral sampling (rg_cfg_ddpm_update) against the real reference
     (diffusion_architecture.py:424-432, gaussian_diffusion.py:741-905)."""
     g = np.load(os.path.join(golden_dir, "e2e_ddpm_L2.npz"))
@@ -283,11 +287,11 @@ def test_ddpm_inference_type_vs_reference_golden(rg, golden_dir, precision):
     torch.cuda.synchronize()
     e = relerr(out["prev_latentout"].cpu()[:, KEEP], torch.from_numpy(g["ddpm_prev_latentout"])[:, KEEP])
     et = relerr(out["pred_transl"].cpu(), torch.from_numpy(g["ddpm_pred_transl"]))
-    print("ddpm", precision, "final latent rel err %.3e, transl %.3e" % (e, et))
-    assert e <= (2e-3 if precision == "fp32" else 3e-2) and et <= 5e-2
+    parity.check("ddpm %s: final latent vs reference golden" % precision, e, 2e-3 if precision == "fp32" else 1e-2)
+    parity.check("ddpm %s: pred_transl" % precision, et, 3e-3 if precision == "fp32" else 3e-2)
 
 
-def test_visualize_inversion_vs_reference_golden(rg, models, golden_dir):
+def test_visualize_inversion_vs_reference_golden(rg, parity, models, golden_dir):
     """inference_kwargs["visualize_inversion"]: decoded inversion levels [n_exemplars, 50, 150, *] and decoded
     (exemplar, DDIM reconstruction) pairs (diffusion_architecture.py:357-382, 488-571), noise tape kept aligned."""
     g = np.load(os.path.join(golden_dir, "e2e_ddpm_L2.npz"))
@@ -298,10 +302,11 @@ def test_visualize_inversion_vs_reference_golden(rg, models, golden_dir):
                        inference_kwargs=dict(use_inversion=True, visualize_inversion=True, noise_tape=rg.synth.NoiseTape(2024))))
     torch.cuda.synchronize()
     e = relerr(out["prev_latentout"].cpu()[:, KEEP], torch.from_numpy(g["visinv_prev_latentout"])[:, KEEP])
-    assert e <= 2e-3
+    parity.check("visualize_inversion fp32: final latent vs reference golden", e, 2e-3)
     assert out["inverted_output_upper"].shape == (4, 50, 150, 39) and out["reconspair_output_hands"].shape == (4, 2, 150, 90)
     et = relerr(out["inverted_output_transl"][:, [0, 24, 49]].cpu(), torch.from_numpy(g["visinv_inverted_output_transl_lv"]))
     er = relerr(out["reconspair_output_transl"].cpu(), torch.from_numpy(g["visinv_reconspair_output_transl"]))
     eu = rot_relerr(out["reconspair_output_upper"].cpu().reshape(-1, 150, 39), torch.from_numpy(g["visinv_reconspair_output_upper"]).reshape(-1, 150, 39))
-    print("visualize_inversion fp32: latent %.3e, inverted transl %.3e, recon transl %.3e, recon upper(rot) %.3e" % (e, et, er, eu))
-    assert et <= 3e-2 and er <= 3e-2 and eu <= 3e-2
+    parity.check("visualize_inversion fp32: decoded inversion levels, transl", et, 3e-3)
+    parity.check("visualize_inversion fp32: reconstruction pairs, transl", er, 3e-3)
+    parity.check("visualize_inversion fp32: reconstruction pairs, upper (rotation matrices)", eu, 3e-3)
