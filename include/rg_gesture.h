@@ -331,9 +331,13 @@ typedef struct rg_seq_args {
   const float* qmask;      /* fp32 [3][2B][T] */
   float* head;             /* fp32 [2B][T][512] result */
   float* dump;
+  float* xbuf;             /* fp32 [2B][8][12][64][4] hand-over of the residual stream between the launches of one forward, or NULL */
   int L, B, T, S;          /* layers, clips, tokens, steps in pstream / ustream */
   int step, step_b, split; /* clips [0, split) at step, clips [split, B) at step_b */
   int dump_stage, dump_layer;
+  int l0, l1;              /* this launch runs layers [l0, l1): + the embedding when l0 == 0, + the head when l1 == L.  A forward
+                              cut into several launches frees every compute unit between them (a workgroup holds its CU for the
+                              whole launch), which is what lets OTHER streams' kernels in promptly */
   int pad_;
 } rg_seq_args;
 

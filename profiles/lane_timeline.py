@@ -19,6 +19,12 @@ database = rg.synth.SyntheticDataset(int(os.environ.get("DB", "32768")), seed=20
 model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=database, device=dev)
 model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
 model.eval()
+if "SEQ_LAUNCHES" in os.environ:
+    model.session_options["seq_launches"] = int(os.environ["SEQ_LAUNCHES"])
+if "MAX_INFLIGHT" in os.environ:
+    model.max_inflight = int(os.environ["MAX_INFLIGHT"])
+if "SLOTS" in os.environ:
+    model.slots = int(os.environ["SLOTS"])
 if "LANES" in os.environ:
     model.lanes = int(os.environ["LANES"])
 model.async_results = bool(int(os.environ.get("PIPELINED", "0")))

@@ -215,11 +215,15 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False, xcd_affine=True, engine=None,
-                 styl_in_gemm=False):
+                 styl_in_gemm=False, seq_launches=1):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
         supported, else "chain" (precision="fp32" always runs the chain).
+        seq_launches (engine "seq"): kernel launches per forward (the layers cut into ranges, the residual stream handed over
+        through a 96 KiB-per-sequence buffer).  A workgroup holds its compute unit for a whole launch; cutting the forward
+        frees every CU a few times per millisecond, which lets the kernels of other streams (the next batch's front end) in
+        promptly.  Same bits for every value.
         The remaining options belong to the launch chain:
         ln_mode: "folded" = LayerNorm folded into the consuming GEMM's epilogue (two passes per
         layer fewer; its bf16 operand is the UN-normalised row, so the error grows with |row mean| / std),
@@ -255,7 +259,7 @@ class DenoiserSession:
         self.sq = None
         if self.engine == "seq":           # activations never leave the CU: no per-op buffers
             self.ln_mode = "exact"
-            self.sq = SQ.SeqForward(self)
+            self.sq = SQ.SeqForward(self, launches=seq_launches)
             return
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
         # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide, or 64 wide

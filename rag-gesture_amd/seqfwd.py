@@ -25,10 +25,11 @@ _vp = ctypes.c_void_p
 
 class SeqArgs(ctypes.Structure):
     _fields_ = [("wstream", _vp), ("pstream", _vp), ("ustream", _vp), ("afrag", _vp), ("x", _vp), ("tbias", _vp),
-                ("src_mask", _vp), ("qmask", _vp), ("head", _vp), ("dump", _vp),
+                ("src_mask", _vp), ("qmask", _vp), ("head", _vp), ("dump", _vp), ("xbuf", _vp),
                 ("L", ctypes.c_int), ("B", ctypes.c_int), ("T", ctypes.c_int), ("S", ctypes.c_int),
                 ("step", ctypes.c_int), ("step_b", ctypes.c_int), ("split", ctypes.c_int),
-                ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("pad_", ctypes.c_int)]
+                ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("l0", ctypes.c_int), ("l1", ctypes.c_int),
+                ("pad_", ctypes.c_int)]
 
 
 def supported(cfg, T, precision):
@@ -152,10 +153,15 @@ class SeqStreams:
 class SeqForward:
     """Buffers of one DenoiserSession for rg_seq_forward."""
 
-    def __init__(self, sess):
+    def __init__(self, sess, launches=1):
+        """launches: kernel launches per forward (the L layers cut into near-equal ranges; 1 = the whole forward in one)."""
         w = sess.w
         self.sess, self.h, self.st = sess, sess.h, w.seq_streams
         B, dev = sess.B, w.dev
+        n = max(1, min(int(launches), w.L))
+        cuts = [round(i * w.L / n) for i in range(n + 1)]
+        self.ranges = [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
+        self.xbuf = torch.empty(2 * B * 8 * 12 * 64 * 4, device=dev, dtype=torch.float32) if len(self.ranges) > 1 else None
         self.afrag = torch.zeros(w.L, 3, B, 8, 2, 2, 2, 64, 8, device=dev, dtype=torch.bfloat16)
         a = self.args = SeqArgs()
         p = lambda t: t.data_ptr()
@@ -163,6 +169,7 @@ class SeqForward:
         a.tbias, a.src_mask, a.qmask, a.head = p(w.tbias), p(sess.src_mask), p(sess.qmask), p(sess.head)
         a.L, a.B, a.T, a.S = w.L, B, w.T, self.st.S
         a.dump, a.dump_stage, a.dump_layer = None, 0, 0
+        a.xbuf = p(self.xbuf) if self.xbuf is not None else None
 
     def set_a(self, a_pre, o0, o1):
         """a_pre fp32 [L, 3, n, H, 32, 32] of the clips [o0, o1) of the session."""
@@ -178,7 +185,8 @@ class SeqForward:
         a.dump = dump.data_ptr() if dump is not None else None
         a.dump_stage, a.dump_layer = int(dump_stage), int(dump_layer)
         s = torch.cuda.current_stream().cuda_stream
-        rc = self.h.lib.rg_seq_forward(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
-        if rc != 0:
-            raise capi.RgError("rg_seq_forward failed (%d): %s" % (rc, self.h.lib.rg_last_error(self.h._h).decode()))
+        for a.l0, a.l1 in self.ranges:
+            rc = self.h.lib.rg_seq_forward(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
+            if rc != 0:
+                raise capi.RgError("rg_seq_forward failed (%d): %s" % (rc, self.h.lib.rg_last_error(self.h._h).decode()))
         return self.sess.head

@@ -258,3 +258,21 @@ def test_seq_forward_two_step_groups(rg, setup):
     torch.cuda.synchronize()
     assert torch.equal(both[:, :split], a[:, :split]) and torch.equal(both[:, split:], b[:, split:])
     assert not torch.equal(a, b)
+
+
+def test_seq_forward_cut_into_several_launches_is_bit_identical(rg, setup):
+    """DenoiserSession(seq_launches=n): the layers cut into n launches, the residual stream handed over through a buffer."""
+    cfg, P, W = setup[8]
+    B = 3
+    data = rg.synth.synth_batch(B, seed=79)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal((B, 43, 512)).astype(np.float32)).cuda()
+    mm = torch.ones(B, 43)
+    mm[:, [10, 21, 32]] = 0
+    outs = []
+    for n in (1, 2, 3, 8):
+        sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_launches=n)
+        assert len(sess.sq.ranges) == n and sess.sq.ranges[0][0] == 0 and sess.sq.ranges[-1][1] == 8
+        sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
+        outs.append(sess.forward(x, 23, 40, 1).clone())
+        torch.cuda.synchronize()
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
