@@ -330,7 +330,9 @@ def cpu_baseline(rg, wl, guided):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 32))  # the port is bandwidth/latency bound well below that
+    avail = cores
+    cores = max(1, min(cores, 32))  # torch's CPU matmuls on [43, 512] operands stop scaling well below that (one run with
+    # every core of a 200+ core host did not finish one clip in 40 minutes: oversubscribed OpenMP teams on tiny GEMMs)
     torch.set_num_threads(cores)
     cfg, vae_cfgs = wl.cfg, wl.vae_cfgs
     P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
@@ -359,6 +361,7 @@ def cpu_baseline(rg, wl, guided):
 
     out = {}
     one(full=False)   # warm-up: one base clip (thread pool, allocator, first-touch of the weights)
+
     for mode in ("faithful", "hoisted"):
         od.OPTS["hoist"] = mode == "hoisted"
         ts = sorted(one() for _ in range(3))
@@ -366,6 +369,7 @@ def cpu_baseline(rg, wl, guided):
     od.OPTS["hoist"] = False
     od.hoist_clear()
     return {"value": round(150.0 / out["faithful"], 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "host_cores_available": avail,
             "hoisted": {"value": round(150.0 / out["hoisted"], 2), "seconds_per_clip": round(out["hoisted"], 2)},
             "seconds_per_clip": round(out["faithful"], 2),
             "sample": "1 clip (150 frames) of the headline workload (%s), torch fp32 on %d host threads; 1 warm-up, median of 3 "
@@ -477,12 +481,18 @@ def main():
             # (profiles/r01e_pmc_gemm_traffic.txt explains how they were collected and corrected); null if absent
             roofline["traffic"] = None
             try:
-                # (round 2: the shapes of a co-batched lane, M = 2752 rows; round 1: M = 1376 / 4128)
-                pmc = [p for p in (os.path.join(ROOT, "profiles", n) for n in
-                                   (("r02m_pmc_gemm_traffic.json",) if wl.cobatch else ()) + ("r01e_pmc_gemm_traffic.json",)) if os.path.exists(p)]
-                with open(pmc[0]) as f:
-                    rows = json.load(f)
-                roofline["traffic"] = round(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows))
+                # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 gfx950
+                # correction + WRITE_SIZE; profiles/pmc_seq.py, pmc_seq_summarize.py; round 1-2: the rg_gemm shapes)
+                if roofline.get("workgroups_per_launch") is not None:
+                    with open(os.path.join(ROOT, "profiles", "r03_pmc_seq.json")) as f:
+                        pm = json.load(f)
+                    roofline["traffic"] = round(pm["fetch_bytes"] + pm["write_bytes"])
+                    roofline["traffic_algorithmic"] = round(pm["algorithmic_hbm_bytes"])
+                    roofline["mfma_utilisation_pmc"] = round(pm["mfma_utilisation"], 4)
+                else:
+                    with open(os.path.join(ROOT, "profiles", "r02m_pmc_gemm_traffic.json")) as f:
+                        rows = json.load(f)
+                    roofline["traffic"] = round(sum(r["fetch_bytes"] + r["write_bytes"] for r in rows) / len(rows))
             except (OSError, ValueError, KeyError, ZeroDivisionError, IndexError):
                 pass
         if guided:

@@ -40,6 +40,9 @@ def main(root, info_json):
         res["mfma_utilisation"] = res["mfma_busy_cycles"] / (1024.0 * res["us_under_pmc"] * 1e3 * 2.4)
         res["expected_busy_cycles"] = info["flops_per_launch"] / 2 / 512 * (48.0 / 43.0)
     print(json.dumps(res, indent=1))
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as f:
+            json.dump(res, f, indent=1)
     if "fetch_bytes" in res and "write_bytes" in res:
         print("HBM-side traffic per launch %.1f MB (fetch %.1f + write %.1f) against %.1f MB algorithmic: x%.2f; LDS-ring intake %.1f GB per launch"
               % ((res["fetch_bytes"] + res["write_bytes"]) / 1e6, res["fetch_bytes"] / 1e6, res["write_bytes"] / 1e6,

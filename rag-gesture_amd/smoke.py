@@ -15,7 +15,8 @@ def run():
     P = synth.synth_full_state(0, cfg, vae_cfgs)
     gi = [0] * 25 + list(range(25))
     keep = [r for r in range(43) if r not in (10, 20, 30)]
-    for precision, tol in (("fp32", 1e-2), ("bf16", 3e-2)):
+    rows = []
+    for precision, tol in (("fp32", 2e-3), ("bf16", 1e-2)):
         model = pipeline.build_architecture(synth.reference_style_model_cfg(cfg, vae_cfgs), database=None,
                                             device="cuda:0", precision=precision)
         model.load_state_dict(P)
@@ -36,7 +37,11 @@ def run():
             a, b = out["prev_latentout"].cpu()[:, keep], ref["prev_latentout"][:, keep]
             err = ((a - b).norm() / b.norm()).item()
             et = ((out["pred_transl"].cpu() - ref["pred_transl"]).norm() / ref["pred_transl"].norm()).item()
-            print("smoke %s %s: latent rel err %.3e, pred_transl rel err %.3e" % (precision, tag, err, et))
-            if not (err <= tol and et <= 5 * tol):
-                raise AssertionError("smoke: HIP path disagrees with the oracle (%s %s: %g, %g)" % (precision, tag, err, et))
-    print("smoke ok")
+            worst = ((a - b).norm(dim=-1) / b.norm(dim=-1)).max().item()
+            engine = ",".join(sorted({s.engine for s in model._sessions.values()})) or "-"
+            rows.append((precision, tag, engine, err, worst, et))
+            print("smoke %s %s (denoiser engine %s): final latent rel err %.3e (bound %.0e), worst token row %.3e, pred_transl %.3e"
+                  % (precision, tag, engine, err, tol, worst, et))
+            if not (err <= tol and worst <= 5 * tol and et <= 3 * tol):
+                raise AssertionError("smoke: HIP path disagrees with the oracle (%s %s: %g, %g, %g)" % (precision, tag, err, worst, et))
+    print("smoke ok: " + "; ".join("%s/%s %.1e" % (p, t, e) for p, t, _, e, _, _ in rows))
