@@ -474,6 +474,22 @@ def main():
     # ---- rank-0-only records (instrumented / additional steps never enter a collective)
     roofline = roof_retr = None
     also = {}
+    steady = None
+    if rank == 0 and world == 1 and wl.cobatch:
+        # Informational, never `value`: the same K submissions with the pipeline already full when the clock starts and
+        # still full when it stops (K results come out, the two pending batches are drained after the clock) -- `value`
+        # above pays the pipeline's fill and drain inside its K steps.
+        for _ in range(4):
+            wl.step()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        torch.cuda.synchronize()
+        steady = round((time.perf_counter() - ts) / args.steps * 1e3, 2)
+        wl.drain()
+        torch.cuda.synchronize()
+        wl.latency_ms()
     if rank == 0:
         if kind != "longform":
             roofline = wl.gemm_roofline(local_rank)
@@ -549,6 +565,7 @@ def main():
                                  "note": "device time from a batch's submission to its packed result; the co-batched pipeline "
                                          "hands a batch out two submissions later (its sampling shares launches with a later "
                                          "batch's inversion), so latency > 2 x ms_per_step while throughput = 1 / ms_per_step"},
+            "steady_state_ms_per_step": steady,   # informational (pipeline full at both ends of the clock); never `value`
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": names[kind],

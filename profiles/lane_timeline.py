@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 rg = importlib.import_module("rag-gesture_amd")
 dev = torch.device("cuda", 0)
-B = 16
+B = int(os.environ.get("B", "16"))
 GI = [2] * 25 + [0] * 25
 cfg = rg.synth.default_model_cfg(num_layers=8)
 vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
@@ -88,6 +88,30 @@ for rep in range(2):
         print("   %-44s host call %6.1f -> %6.1f ms | device %6.1f -> %6.1f ms (%.1f)" % (
             str(key)[:44], h0, h1, ev_step[0].elapsed_time(e0), ev_step[0].elapsed_time(e1), e0.elapsed_time(e1)))
 
+blocks = []
+if os.environ.get("HOSTBLOCK"):
+    # every host call that can wait for the device, with its duration and the frames that made it
+    import traceback
+
+    def wrap(owner, name):
+        fn = getattr(owner, name)
+
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            dt = (time.perf_counter() - t0) * 1e3
+            if dt > 0.5:
+                fr = [f for f in traceback.extract_stack()[:-1] if "rag-gesture_amd" in f.filename][-3:]
+                blocks.append(((t0 - t_step[0]) * 1e3, dt, "%s.%s" % (getattr(owner, "__name__", owner), name),
+                               " < ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in reversed(fr))))
+            return r
+        setattr(owner, name, w)
+    for owner, names in ((torch.Tensor, ("cpu", "item", "tolist", "numpy", "to", "nonzero", "__bool__", "__int__", "__float__", "copy_", "__setitem__", "__getitem__", "pin_memory", "index_copy_", "index_select", "clone", "record_stream")),
+                         (torch.cuda.Event, ("synchronize",)), (torch.cuda.Stream, ("synchronize",)), (torch.cuda, ("synchronize",)),
+                         (torch, ("tensor", "as_tensor", "stack", "cat", "zeros", "empty", "randn"))):
+        for nm in names:
+            wrap(owner, nm)
+
 if os.environ.get("BACK_TO_BACK"):
     # three steps without a synchronisation in between: where does step n + 1 start relative to step n's end?
     one_step(trace=True, sync=False)
@@ -102,3 +126,5 @@ if os.environ.get("BACK_TO_BACK"):
             print("   ---- next step")
         print("   %-44s host call %6.1f -> %6.1f ms | device %6.1f -> %6.1f ms (%.1f)" % (
             str(key)[:44], h0, h1, ev_step[0].elapsed_time(e0), ev_step[0].elapsed_time(e1), e0.elapsed_time(e1)))
+    for t0, dt, what, where in blocks:
+        print("   host blocked %6.1f -> %6.1f ms (%5.1f) in %s  %s" % (t0, t0 + dt, dt, what, where))

@@ -83,6 +83,16 @@ def build_db_dicts(samples, stratified_db_creation=False, stratification_interva
     return out
 
 
+def to_device_async(host, dev):
+    """Host tensor / array -> device without stalling the host: staged in page-locked memory (torch's caching host
+    allocator keeps the block until the copy has run), copied asynchronously on the current stream.  A copy from pageable
+    memory instead returns only after everything queued on that stream before it has run -- on a stream that holds a
+    just-launched VAE graph that is milliseconds of host time, per copy."""
+    t = torch.from_numpy(np.ascontiguousarray(host)) if isinstance(host, np.ndarray) else host
+    if t.device.type != "cpu" or torch.device(dev).type == "cpu":
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)
+
 class DiscourseIndex:
     """Integer-coded, device-resident copy of the discourse DB (replicated per GPU)."""
 
@@ -147,9 +157,9 @@ class DiscourseIndex:
         o_score = torch.empty(Q, cap, dtype=torch.float64, device=self.dev)
         s = torch.cuda.current_stream().cuda_stream
         nan = float("nan")
-        params = torch.tensor([[float(self.sense_code.get(sense, -2)), float(self.conn_code.get(conn, -1)), float(int(spk)),
-                                nan if q_prom is None else float(q_prom)] for sense, conn, spk, q_prom in queries],
-                              dtype=torch.float64).to(self.dev, non_blocking=True)
+        params = to_device_async(torch.tensor([[float(self.sense_code.get(sense, -2)), float(self.conn_code.get(conn, -1)),
+                                                float(int(spk)), nan if q_prom is None else float(q_prom)]
+                                               for sense, conn, spk, q_prom in queries], dtype=torch.float64), self.dev)
         # one sweep launch and one three-launch selection for the whole batch of queries
         rc = lib.rg_discourse_scores_batched(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
                                              vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
@@ -184,7 +194,7 @@ class DiscourseIndex:
     def sims_async(self, q_feat_dev, cand):
         """Launch only: float64 device tensor [len(cand)]."""
         lib, vp = self.h.lib, ctypes.c_void_p
-        c = torch.tensor(cand, dtype=torch.int32, device=self.dev)
+        c = to_device_async(torch.tensor(cand, dtype=torch.int32), self.dev)
         out = torch.empty(len(cand), dtype=torch.float64, device=self.dev)
         s = torch.cuda.current_stream().cuda_stream
         rc = lib.rg_text_diag_sim(self.h._h, vp(q_feat_dev.data_ptr()), q_feat_dev.shape[0], vp(self.feats.data_ptr()),
@@ -847,7 +857,7 @@ class RetrievalDatabase:
                 dst, src = np.concatenate(dst), np.concatenate(src)
                 _, last = np.unique(dst[::-1], return_index=True)
                 keep = len(dst) - 1 - last
-                return torch.from_numpy(dst[keep]).to(dev), torch.from_numpy(src[keep]).to(dev)
+                return to_device_async(dst[keep], dev), to_device_async(src[keep], dev)
             dst, src = idx(lat_dst, lat_src)
             zero_motion.view(B * T, D).index_copy_(0, dst, lat.reshape(E * T, D).index_select(0, src))
             dst, src = idx(frame_dst, frame_src)
@@ -857,9 +867,11 @@ class RetrievalDatabase:
         src_mask = (zero_motion != 0).any(dim=-1).to(torch.int)
         raw_latent_mask = src_mask.clone()
         raw_motion_latents = zero_motion.clone()
-        fl = list(range(2 * L + 2, 3 * L + 2)) + list(range(3 * L + 3, T))
-        src_mask[:, fl] = 0
-        raw_motion_latents[:, fl, :] = 0
+        # (face and lower-body rows; as two slices: a LIST index is uploaded from pageable memory, and that copy returns
+        # only after everything queued on this stream -- the exemplar encode -- has run)
+        for r0, r1 in ((2 * L + 2, 3 * L + 2), (3 * L + 3, T)):
+            src_mask[:, r0:r1] = 0
+            raw_motion_latents[:, r0:r1, :] = 0
         tick("retrieval.assemble")
         return dict(re_text=None, re_motion=None, re_mask=src_mask,
                     raw_motion_latents=raw_motion_latents.view(B, self.num_retrieval, T, D),
