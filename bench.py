@@ -8,7 +8,7 @@ One "step" = one pass of the hot path over one batch of synthetic clips through 
 conditioning precompute -> [retrieval -> batched DDIM inversion of the retrieved exemplars] -> 50-step DDIM with CFG
 [+ insertion guidance] -> 4x VAE decode (150 SMPL-X frames per clip at 15 fps).  Inputs are resident
 in HBM before the timed region.  The K timed steps are K complete batches: the guided workload goes through
-`model.submit()` / `model.flush()` (DESIGN.md 6b: the sampling loop of a batch shares its denoiser launches with the exemplar
+`model.submit()` / `model.flush()` (DESIGN.md 4: the sampling loop of a batch shares its denoiser launches with the exemplar
 inversion of a later batch; the pipeline fills and drains INSIDE the timed region), `--no-cobatch` = asynchronous
 `model(**data)` calls, `--no-pipeline` = one synchronous `model(**data)` per step (also reported under `also`).
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), clips sharded across ranks (weak scaling, B clips per

@@ -337,7 +337,7 @@ typedef struct rg_seq_args {
   int dump_stage, dump_layer;
   int l0, l1;              /* this launch runs layers [l0, l1): + the embedding when l0 == 0, + the head when l1 == L.  A forward
                               cut into several launches frees every compute unit between them (a workgroup holds its CU for the
-                              whole launch), which is what lets OTHER streams' kernels in promptly */
+                              whole launch), which lets OTHER streams' kernels in between them (measured without gain on the step: NOTEBOOK 8.4) */
   int pad_;
 } rg_seq_args;
 

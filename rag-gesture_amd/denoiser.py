@@ -233,7 +233,7 @@ class DenoiserSession:
         styl_in_gemm: the stylization in front of the SA-out and FFN-out GEMMs (LN, scale/shift, SiLU)
         runs inside those GEMMs, on the landed bf16 A tiles in LDS, instead of as two elementwise launches per layer.
         Parity-green and measured SLOWER (907 vs 887 us per forward at M = 1376): off by default.
-        styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain."""
+        styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain (NOTEBOOK section 6)."""
         if ln_mode not in ("auto", "folded", "prologue"):
             raise capi.RgError("ln_mode must be 'auto', 'folded' or 'prologue'")
         if engine not in (None, "seq", "chain"):

@@ -82,7 +82,7 @@ def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None
         out_b [S, B - n_a, T, D] receives every level.
     Step k runs the sampling at respaced index S-1-k and the inversion at index k.  Rows of a batch never mix in any
     kernel, so each group gets what its own loop would give; the point is the launch count and size: a forward over
-    M = 2 (8 + 24) 43 rows costs ~1.1x the forward over the 24 exemplars alone."""
+    M = 2 (8 + 24) 43 rows costs ~1.1x the forward over the 24 exemplars alone (NOTEBOOK 6b; with the seq engine: one workgroup per sequence, the launch time does not depend on the count up to 256)."""
     sch, w, h = sess.w.schedule, sess.w, sess.h
     S, B, T, D = sch.num_timesteps, sess.B, w.T, w.D
     n_b = B - n_a

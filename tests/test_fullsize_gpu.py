@@ -9,7 +9,7 @@ inputs and clip i's share of the noise.  The batched run's explicit noise tape i
 oracle's draw order, the rows that belong to one clip (VAE noise rows [10 i, 10 i + 10), the exemplar-encode draws of
 the clip's own exemplars, row i of every [B, 43, 512] draw).
 Bars: retrieved samples, bounds and placement exact; final latent <= 1e-2 relative over all kept rows and <= 3e-2 on the
-worst token row (bf16 operands vs fp32, rows 10/20/30 excluded as everywhere, DESIGN section 4); decoded translation
+worst token row (bf16 operands vs fp32, rows 10/20/30 excluded as everywhere, DESIGN section 5); decoded translation
 <= 3e-2.  Every measured value goes through the `parity` recorder (tests/conftest.py) and is printed with the run.
 
   config 3 as BENCHMARKED: three different B = 16 batches through model.submit() / flush() (asynchronous results, the

@@ -181,7 +181,7 @@ def test_longform_three_windows_vs_oracle(rg, parity):
     gm = torch.from_numpy(got["poses"])
     ma, mb = orot.axis_angle_to_matrix(gm.reshape(-1, 3)), orot.axis_angle_to_matrix(want_m.reshape(-1, 3))
     e_m, e_f, e_t = rel(ma, mb), rel(torch.from_numpy(got["expressions"]), want_f), rel(torch.from_numpy(got["trans"]), want_t)
-    # (what remains in fp32 mode is the reference's -1e6 LayerNorm quirk on rows 10/20/30, DESIGN.md section 4)
+    # (what remains in fp32 mode is the reference's -1e6 LayerNorm quirk on rows 10/20/30, DESIGN.md section 5)
     parity.check("longform 3 windows fp32 vs oracle loop: poses (rotation matrices)", e_m, 3e-3)
     parity.check("longform 3 windows fp32 vs oracle loop: expressions", e_f, 3e-3)
     parity.check("longform 3 windows fp32 vs oracle loop: trans", e_t, 3e-3)

@@ -168,7 +168,7 @@ def test_end_to_end_with_retrieval_database_vs_oracle(rg, parity, precision):
 def test_end_to_end_all_token_rows_vs_exact_ln_oracle(rg, parity, models, rtag, ikw, need_re):
     """Rows 20 and 30 are real hands / face tokens whose cross-attention queries the reference masks
     (diffusion_architecture.py:155); the goldens of the real reference cannot pin them tightly because torch's
-    LayerNorm of (y - 1e6) rounds platform-dependently (DESIGN section 4).  Against the oracle in masked_ln="exact"
+    LayerNorm of (y - 1e6) rounds platform-dependently (DESIGN section 5).  Against the oracle in masked_ln="exact"
     mode -- the same arithmetic with that LayerNorm evaluated exactly, which is what the kernels do -- EVERY token row
     (all but the three zero separators 10 / 21 / 32) must agree in the fp32-equivalent mode."""
     from oracle import denoiser as od, diffusion as odf
