@@ -289,7 +289,6 @@ class MotionDiffusion(torch.nn.Module):
         self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
         # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
-        self.max_inflight = int(os.environ.get("RG_MAX_INFLIGHT", self.max_inflight))
         self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
         # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
         # (one pipeline per lane when whole batches alternate between the lanes, cobatch_lanes="batch"; else one, key None)
@@ -298,7 +297,7 @@ class MotionDiffusion(torch.nn.Module):
         self.cobatch_lanes = str(cobatch_lanes)
         capi.require(self.cobatch_lanes in ("batch", "split"),
                 "unsupported argument: requires self.cobatch_lanes in (\"batch\", \"split\")")
-        self._lane_streams, self._search_stream, self._tail_stream, self._lanes_calibrated = [], None, None, None
+        self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -510,9 +509,8 @@ class MotionDiffusion(torch.nn.Module):
         if self._lanes_calibrated != want:
             # `want` lane streams + one more for the retrieval search, all on hardware queues of their own (the
             # runtime has 4 by default: the caller's stream, two lanes and the search stream use them up)
-            found = self._concurrent_streams(want + 2)
+            found = self._concurrent_streams(want + 1)
             self._lane_streams, self._search_stream = found[:want], (found[want] if len(found) > want else None)
-            self._tail_stream = found[want + 1] if len(found) > want + 1 else None   # (only with GPU_MAX_HW_QUEUES > 4)
             if not self._lane_streams:
                 self._lane_streams = [torch.cuda.Stream(device=self.device)]
             self._lanes_calibrated = want
@@ -964,8 +962,6 @@ class MotionDiffusion(torch.nn.Module):
         gre, results, main, S, T, D, B = self.model.gesture_rep_encoder, st.results, st.main, st.S, st.T, st.D, st.B
         # (asynchronous: the lanes take turns, so that the decode does not always delay the same lane's next chain)
         tail = st.plan_s[self._tail_turn % len(st.plan_s)][1] if st.run_async else main
-        if st.run_async and self._tail_stream is not None and os.environ.get("RG_TAIL_ASIDE") == "1":
-            tail = self._tail_stream
         self._tail_turn += 1
         for _, stream, _, _ in st.plan + st.plan_s:
             if stream is not tail:
