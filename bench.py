@@ -119,7 +119,8 @@ class Workload:
         self.model.eval()
         self.model.async_results = bool(pipelined) and kind != "longform"
         # guided workload: the sampling loop of batch n shares its denoiser launches with the inversion of batch n + 1
-        self.cobatch = self.model.async_results and kind == "guided" and cobatch and precision == "bf16"
+        # base workload: nothing to co-batch, but submit() lets whole batches alternate between model.base_lanes lanes
+        self.cobatch = self.model.async_results and kind in ("guided", "base") and cobatch and precision == "bf16"
         if kind == "longform":
             # BASELINE config 5: tools/longform_synthesis.py's loop -- overlapping 150-frame windows, every window a guided
             # forward with `use_inversion + insertion_guidance + use_prev_latent` (longform_synthesis.py:389-403) and
@@ -412,6 +413,8 @@ def main():
         return
     global torch
     import torch
+    # (before the first HIP call: importing the package sets GPU_MAX_HW_QUEUES for the runtime unless the user has)
+    rg = importlib.import_module("rag-gesture_amd")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -422,7 +425,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    rg = importlib.import_module("rag-gesture_amd")
     Workload.database_index = lambda self: self.model.model.database.index
     kind = args.workload
     B = args.batch or {"guided": 16, "base": 32, "longform": 10}[kind]
@@ -521,8 +523,9 @@ def main():
                 if w.kind != "longform" and roof:
                     r["roofline"] = w.gemm_roofline(local_rank)
                 return r
-            also["base_B32"] = dict(record(Workload(rg, "base", 32, dev, rank, args.db_size)),
-                                    workload="base diffusion len150 DDIM-50 (no guidance), 32 clips (BASELINE config 2)")
+            also["base_B32"] = dict(record(Workload(rg, "base", 32, dev, rank, args.db_size), steps=16, warmup=4),
+                                    workload="base diffusion len150 DDIM-50 (no guidance), 32 clips per batch (BASELINE config 2), "
+                                             "whole batches alternating between %d lanes through submit()" % wl.model.base_lanes)
             if wl.model.async_results:
                 # the same model (same calibrated lane streams) switched to one synchronous forward per batch
                 wl.drain()
@@ -572,8 +575,11 @@ def main():
                        "clips_per_gpu": B, "global_batch": world * B, "frames_per_clip": 150, "ddim_steps": 50,
                        "denoiser": "8 layers x 512, CFG x2 rows", "vae": "all_encoder, 8 layers, synthetic hparams",
                        "weights": "random-init at config shapes", "parallelism": "clip-sharded x%d" % world,
-                       "submission": (("asynchronous, co-batched: the sampling loop of batch n and the exemplar inversion of batch "
-                                       "n+1 advance in the same denoiser launches (sampler.cobatched_loop), the front end of "
+                       "submission": (("asynchronous, submit(): whole batches alternate between %d lanes (one 50-launch chain "
+                                       "each); every batch completes inside the timed region" % wl.model.base_lanes)
+                                      if wl.cobatch and kind == "base" else
+                                      ("asynchronous, co-batched: the sampling loop of batch n and the exemplar inversion of batch "
+                                       "n+2 advance in the same denoiser launches (sampler.cobatched_loop), the front end of "
                                        "batch n+1 runs beside them; the pipeline fills and drains inside the timed region, "
                                        "which holds exactly `steps` complete batches") if wl.cobatch else
                                       ("asynchronous, %d slots: the front end (conditions, VAE encodes, retrieval) of batch n+1 and "

@@ -266,7 +266,7 @@ class MotionDiffusion(torch.nn.Module):
                  diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
-                 vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", **kwargs):
+                 vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=3, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -286,6 +286,9 @@ class MotionDiffusion(torch.nn.Module):
         self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
         self.profile_phases, self.phase_ms = False, {}
         self.lanes = int(lanes)
+        # submit() of batches WITHOUT exemplar inversion (base diffusion: 2 B sequences per launch, 64 at B = 32) lets whole
+        # batches alternate between this many lanes -- a launch holds one CU per sequence, so three or four such chains fit the chip (3 measured as good as 4: profiles/r03g)
+        self.base_lanes = max(1, int(base_lanes))
         self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
         # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
@@ -504,17 +507,20 @@ class MotionDiffusion(torch.nn.Module):
         return chosen  # fewer than n if the runtime offers fewer independent queues
 
     def _lane_plan(self, B, n_lanes=None):
-        """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips (n_lanes <= self.lanes of them)."""
-        want = max(1, int(self.lanes))
-        if self._lanes_calibrated != want:
-            # `want` lane streams + one more for the retrieval search, all on hardware queues of their own (the
-            # runtime has 4 by default: the caller's stream, two lanes and the search stream use them up)
+        """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips (n_lanes of them, default self.lanes)."""
+        lanes = max(1, int(self.lanes))
+        want = max(lanes, self.base_lanes if self.async_results else 1)
+        if self._lanes_calibrated != (lanes, want):
+            # lane streams + one more for the retrieval search, all on hardware queues of their own (the runtime has
+            # GPU_MAX_HW_QUEUES of them: the first `lanes` streams found are the lanes, the next one searches, what is left
+            # serves as additional lanes of the base workload)
             found = self._concurrent_streams(want + 1)
-            self._lane_streams, self._search_stream = found[:want], (found[want] if len(found) > want else None)
+            self._search_stream = found[lanes] if len(found) > lanes else None
+            self._lane_streams = found[:lanes] + found[lanes + 1:]
             if not self._lane_streams:
                 self._lane_streams = [torch.cuda.Stream(device=self.device)]
-            self._lanes_calibrated = want
-        n = max(1, min(want if n_lanes is None else int(n_lanes), want, B, len(self._lane_streams)))
+            self._lanes_calibrated = (lanes, want)
+        n = max(1, min(lanes if n_lanes is None else int(n_lanes), want, B, len(self._lane_streams)))
         cuts = [(B * i) // n for i in range(n + 1)]
         return [(i, self._lane_streams[i], cuts[i], cuts[i + 1]) for i in range(n)]
 
@@ -581,6 +587,8 @@ class MotionDiffusion(torch.nn.Module):
         if cob is not None and cob.get("lane") is not None:
             # whole batches alternate between the lanes: this one runs (inversion now, sampling two calls later) on one
             # lane's stream, the batch submitted before it is still busy on the other
+            if not use_inversion:
+                plan = self._lane_plan(B, self.base_lanes)   # nothing to share launches with: more, smaller chains
             pid = cob["lane"] % len(plan)
             plan = plan_s = [(pid, plan[pid][1], 0, B)]
         self._slot = self._take_slot(pid, main) if run_async else 0
@@ -1002,7 +1010,7 @@ class MotionDiffusion(torch.nn.Module):
             results = AsyncResults(results)      # the first read of an entry waits for the batch on the reader's stream
             self._slot_done[(st.pid, st.slot)] = [done]
             self._inflight.append(done)
-            while len(self._inflight) > self.max_inflight:
+            while len(self._inflight) > (self.max_inflight if st.use_inversion else max(self.max_inflight, self.base_lanes)):
                 self._inflight.popleft().synchronize()
         elif tail is not main:
             main.wait_event(done)

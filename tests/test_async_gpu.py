@@ -200,3 +200,40 @@ def test_unchanged_tool_loop_and_three_line_pipelined_loop(rg):
     assert len(got) == len(want)
     for a, b in zip(got, want):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_base_batches_alternate_between_base_lanes(rg):
+    """submit() of batches without exemplar inversion: whole batches alternate between `base_lanes` lanes (a launch holds one
+    compute unit per sequence, so several such chains fit the chip side by side); every batch complete and bit-identical
+    to its own synchronous forward, results in submission order."""
+    dev = torch.device("cuda", 0)
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs), database=None, device=dev)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+    batches = _batches(rg, 3, 7, dev)
+
+    def args(i):
+        d = dict(batches[i])
+        d["trans"] = batches[i]["trans"].clone()
+        return dict(d, retrieval_method="discourse", inference_kwargs=dict(noise_tape=rg.synth.NoiseTape(4300 + i)))
+
+    ref = []
+    for i in range(len(batches)):
+        out = model(**args(i))
+        torch.cuda.synchronize()
+        ref.append({k: out[k].clone() for k in KEYS})
+    model.async_results = True
+    got = []
+    for i in range(len(batches)):
+        out = model.submit(**args(i))
+        assert out is not None, "a batch without inversion has nothing to wait for: its results are handed out at once"
+        got.append({k: out[k].clone() for k in KEYS})     # (first read waits on the reading stream)
+    assert model.flush() == []
+    torch.cuda.synchronize()
+    lanes_used = sorted(p for p in model._slots if p is not None)
+    assert lanes_used == list(range(min(model.base_lanes, len(model._lane_streams)))), lanes_used
+    for i in range(len(batches)):
+        for k in KEYS:
+            assert torch.equal(got[i][k], ref[i][k]), (i, k)
