@@ -260,7 +260,7 @@ class Workload:
         r = {"bound": "mfma", "kernel": kernel,
              "achieved": round(ach / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 5),
              "launches": n, "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "flops_per_launch_avg": round(fl / max(1, n)),
-             "lanes": model.lanes}
+             "lanes": model.lanes, "flops_per_step": round(fl / 2)}      # (2 recorded steps)
         if seq:
             # a launch holds one workgroup per sequence and a workgroup owns a CU (155 KiB of LDS): a lane of 2 x (16 + 48)
             # sequences runs on 128 of the 256 CUs and the other lane's launch on the rest, at the same time
@@ -498,6 +498,10 @@ def main():
             # HBM-side bytes per launch from the committed PMC passes over the same kernels
             # (profiles/r01e_pmc_gemm_traffic.txt explains how they were collected and corrected); null if absent
             roofline["traffic"] = None
+            # the same kernel over the whole timed region: its algorithmic FLOPs per step / the step time (all idle time,
+            # the front end, the decode and the pipeline's fill and drain included) -- what the chip did end to end
+            roofline["whole_step"] = {"achieved": round(roofline["flops_per_step"] / (ms_per_step * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                                      "frac": round(roofline["flops_per_step"] / (ms_per_step * 1e-3) / (roofline["peak"] * 1e12), 4)}
             try:
                 # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 gfx950
                 # correction + WRITE_SIZE; profiles/pmc_seq.py, pmc_seq_summarize.py; round 1-2: the rg_gemm shapes)
