@@ -539,6 +539,14 @@ def main():
                 (wl.cobatch, wl.model.async_results), wl.primed = mode, False
                 also["guided_B16_synchronous"] = dict(r, workload="the headline workload as one synchronous forward per batch "
                                                       "(results valid on the caller's stream at return, like the reference's tools)")
+            if B == 16:
+                # the same pipeline with 32 clips per step on ONE lane: every rg_seq launch then holds 2 x (32 + 96) = 256
+                # sequences = one per CU, which is what `roofline.frac` means for a launch that fills the chip
+                w32 = Workload(rg, "guided", 32, dev, rank, args.db_size, database=wl.database)
+                w32.model.lanes = 1
+                also["guided_B32_one_lane"] = dict(record(w32, steps=8, warmup=2),
+                                                   workload="the headline workload with 32 clips per step on one lane: 256 sequences per launch")
+                del w32
             also["guided_B16_fp32mode"] = dict(
                 record(Workload(rg, "guided", B, dev, rank, args.db_size, precision="fp32", database=wl.database)),
                 workload="the headline workload with bf16x3 split operands (~fp32 products): same-precision figure")
