@@ -558,6 +558,13 @@ def main():
                          "cached LLM answers (LLMResponseCache), use_inversion + insertion_guidance + use_prev_latent, window k of "
                          "all clips in one forward, 6D overlap blend, 30 fps; frames = model frames at 15 fps" % lw.windows,
                 llm_cache={"hits": lw.llm_cache.hits, "misses": lw.llm_cache.misses})
+            del lw
+            # the same loop over 32 clips at once: a pass costs about the same (a launch takes ~1 ms for any number of
+            # sequences up to one per CU), so the frames per second follow the clip count
+            lw = Workload(rg, "longform", 32, dev, rank, args.db_size, database=wl.database, clips=32)
+            also["longform_32clips"] = dict(record(lw, steps=3, roof=False), workload="the same with 32 clips per pass",
+                                            llm_cache={"hits": lw.llm_cache.hits, "misses": lw.llm_cache.misses})
+            del lw
     if dist is not None:
         dist.barrier()
 
