@@ -117,7 +117,7 @@ class Workload:
                                            database=self.database if self.guided else None, device=dev, precision=precision)
         self.model.load_state_dict(rg.synth.synth_full_state(0, self.cfg, self.vae_cfgs))
         self.model.eval()
-        self.model.async_results = bool(pipelined) and kind != "longform"
+        self.model.async_results = bool(pipelined)     # (long-form: run_many then pipelines the windows through submit())
         # guided workload: the sampling loop of batch n shares its denoiser launches with the inversion of batch n + 1
         # base workload: nothing to co-batch, but submit() lets whole batches alternate between model.base_lanes lanes
         self.cobatch = self.model.async_results and kind in ("guided", "base") and cobatch and precision == "bf16"
@@ -206,6 +206,12 @@ class Workload:
                     self.step()
                 self.drain()
                 n = 5 - n
+                quiet = quiet + 1 if len(self.model._graphs) == seen else 0
+                seen = len(self.model._graphs)
+            while quiet < 2 and self.kind == "longform" and self.model.async_results and n < 12:
+                # long-form: the windows go through submit() / flush(); passes until no pass captures a new graph
+                self.step()
+                n += 1
                 quiet = quiet + 1 if len(self.model._graphs) == seen else 0
                 seen = len(self.model._graphs)
             self.primed = True

@@ -146,9 +146,12 @@ class LongformSynthesizer:
 
     def run_many(self, clips, features, use_inversion=False, insertion_guidance=False, guidance_iters=None, guidance_lr=0.1,
                  outpaint=False, inversion_start_time=-1, retrieval_method="discourse", noise_tape=None, with_gt=False,
-                 shard=True, gather=False):
+                 shard=True, gather=False, pipelined=None):
         """clips: list of batch-of-one sample dicts (any lengths); features(clip_index, cidx, t0, t1, annotations) -> dict.
         shard: with torch.distributed initialised, this rank takes clips[shard_range(len(clips), rank, world)].
+        pipelined (default: model.async_results): the windows go through model.submit() / flush() -- window k + 1 is
+        submitted with window k's latent still PENDING (pipeline.PendingLatent): its retrieval and exemplar inversion do not
+        need it and share their denoiser launches with window k's sampling loop; same results as the sequential loop.
         Returns {clip_index: result dict as `run`} for this rank's clips (gather=True: for all clips on every rank,
         exchanged with all_gather_object -- the final result gather of mogen/apis/test.py:129-160)."""
         import torch.distributed as td
@@ -163,6 +166,28 @@ class LongformSynthesizer:
             state[ci] = dict(data=pad_tail(clips[ci], remainder), starts=starts, ends=ends, sample_len=sample_len,
                              prev=None, so_far=None, gt_so_far=None, latents=[])
         n_win = max((len(st["starts"]) for st in state.values()), default=0)
+        if pipelined is None:
+            pipelined = bool(getattr(self.model, "async_results", False)) and not outpaint
+        if pipelined:
+            capi.require(not self.model._pend and not self.model._ready,
+                         "long-form synthesis (pipelined): the model's submit() pipeline must be empty (call flush() first)")
+        queued = []          # (cidx, clips of the window) of the windows whose results are still in the pipeline
+
+        def take(out):
+            cidx, act = queued.pop(0)
+            motion = packing.scatter_parts(out["pred_upper"], out["pred_lower"], out["pred_hands"], out["pred_facepose"])
+            for j, ci in enumerate(act):
+                st = state[ci]
+                st["prev"] = out["prev_latentout"][j:j + 1]
+                st["latents"].append(st["prev"])
+                cur = (motion[j:j + 1], out["pred_exps"][j:j + 1].float(), out["pred_transl"][j:j + 1].float())
+                st["so_far"] = cur if cidx == 0 else blend_window(st["so_far"], cur, self.overlap)
+                if with_gt:
+                    dev = cur[0].device
+                    gt = tuple(out[k][j:j + 1].to(dev).float() for k in ("motion", "facial", "trans"))
+                    st["gt_so_far"] = gt if cidx == 0 else blend_window(st["gt_so_far"], gt, self.overlap)
+
+        pending, act_prev = None, None
         for cidx in range(n_win):
             act = [ci for ci in mine if cidx < len(state[ci]["starts"])]     # clips that still have a window cidx
             chunks = []
@@ -192,7 +217,12 @@ class LongformSynthesizer:
                     batch[k] = v0
             batch["motion_length"] = [self.seqlen] * len(act)
             batch["retrieval_method"] = retrieval_method
-            prev = None if cidx == 0 else torch.cat([state[ci]["prev"] for ci in act], dim=0)
+            if cidx == 0:
+                prev = None
+            elif pipelined:
+                prev = pending.select([act_prev.index(ci) for ci in act])    # bound when this window's sampling is queued
+            else:
+                prev = torch.cat([state[ci]["prev"] for ci in act], dim=0)
             ikw = dict(use_inversion=use_inversion, outpaint=outpaint, inversion_start_time=inversion_start_time,
                        insertion_guidance=insertion_guidance, guidance_lr=guidance_lr, use_prev_latent=True, prev_latent=prev)
             if guidance_iters is not None:
@@ -200,18 +230,18 @@ class LongformSynthesizer:
             if noise_tape is not None:
                 ikw["noise_tape"] = noise_tape.for_clips(act) if hasattr(noise_tape, "for_clips") else noise_tape
             batch["inference_kwargs"] = ikw
-            out = self.model(**batch)
-            motion = packing.scatter_parts(out["pred_upper"], out["pred_lower"], out["pred_hands"], out["pred_facepose"])
-            for j, ci in enumerate(act):
-                st = state[ci]
-                st["prev"] = out["prev_latentout"][j:j + 1]
-                st["latents"].append(st["prev"])
-                cur = (motion[j:j + 1], out["pred_exps"][j:j + 1].float(), out["pred_transl"][j:j + 1].float())
-                st["so_far"] = cur if cidx == 0 else blend_window(st["so_far"], cur, self.overlap)
-                if with_gt:
-                    dev = cur[0].device
-                    gt = tuple(out[k][j:j + 1].to(dev).float() for k in ("motion", "facial", "trans"))
-                    st["gt_so_far"] = gt if cidx == 0 else blend_window(st["gt_so_far"], gt, self.overlap)
+            queued.append((cidx, act))
+            if pipelined:
+                out = self.model.submit(**batch)
+                pending, act_prev = self.model.pending_latent(), act
+                if out is not None:
+                    take(out)
+            else:
+                take(self.model(**batch))
+        if pipelined:
+            for out in self.model.flush():
+                take(out)
+        capi.require(not queued, "long-form synthesis: windows left in the pipeline")
         results = {ci: self._finish(state[ci], with_gt) for ci in mine}
         if gather and td.is_available() and td.is_initialized() and td.get_world_size() > 1:
             parts = [None] * td.get_world_size()

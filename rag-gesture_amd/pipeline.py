@@ -196,6 +196,20 @@ class ReGestureTransformer:
 IncompatibleKeys = collections.namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys"])
 
 
+class PendingLatent:
+    """The final latent `prev_latentout` of a batch that has been submitted but not sampled yet, as a value for a LATER
+    batch's `inference_kwargs["prev_latent"]` (long-form synthesis: window k + 1 takes window k's latent, but only its
+    sampling loop needs it -- its retrieval and exemplar inversion do not, and share their launches with window k's sampling).
+    Bound when the consuming batch's sampling loop is queued; `select(rows)` picks clips of the producing batch."""
+
+    def __init__(self, state, rows=None):
+        self.state, self.rows = state, rows
+
+    def select(self, rows):
+        rows = [int(r) for r in rows]
+        return self if rows == list(range(self.state.B)) else PendingLatent(self.state, rows)
+
+
 class AsyncResults(dict):
     """Result dict of an asynchronously submitted batch (MotionDiffusion(async_results=True), submit() / flush()): the
     tensors are produced on the batch's own stream, and the FIRST READ of any entry makes the reader's current stream wait for
@@ -648,7 +662,12 @@ class MotionDiffusion(torch.nn.Module):
             rml = retrieval_dict["raw_motion_latents"]
             capi.require(rml.shape[1] == 1, "unsupported argument: requires rml.shape[1] == 1")
             retrieval_motion_latents = rml.squeeze(1).to(dev).float().contiguous()
-        if use_prev_latent and prev_latent is not None:
+        prev_future = None
+        if use_prev_latent and isinstance(prev_latent, PendingLatent):
+            capi.require(len(prev_latent.rows) == B if prev_latent.rows is not None else prev_latent.state.B == B,
+                         "prev_latent: the pending latent must hold one row per clip of this batch")
+            prev_future, prev_latent = prev_latent, torch.zeros(B, T, D, device=dev)    # filled by _fill_prev
+        elif use_prev_latent and prev_latent is not None:
             prev_latent = prev_latent.to(dev).float()
             masked = torch.zeros_like(prev_latent)
             for idx in (up_i, ha_i, fa_i, lt_i):
@@ -719,7 +738,9 @@ class MotionDiffusion(torch.nn.Module):
             use_insertion_guidance=use_insertion_guidance, guidance_iters=guidance_iters, guidance_lr=guidance_lr,
             visualize_inversion=visualize_inversion, inversion_start_time=inversion_start_time, vis_inv=[], vis_pairs=[],
             word=word, audio=audio, spk=spk, motion_mask=motion_mask, qmask=qmask, early_cond=early_cond,
-            use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot, pid=pid, seq=self._submitted)
+            use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot, pid=pid, seq=self._submitted,
+            prev_future=prev_future if in_seq is not None else None, latent_ready=None)
+        self._last_state = st
         if cob is not None:
             # the conditions of this batch's clips are projected in the NEXT call (into the sessions it shares with that
             # batch's exemplars): private copies, the caller may reuse its input buffers meanwhile
@@ -728,6 +749,33 @@ class MotionDiffusion(torch.nn.Module):
         self._inversion_pass(st)
         self._sampling_pass(st)
         return self._tail(st)
+
+    def pending_latent(self):
+        """PendingLatent of the batch passed to the most recent forward() / submit()."""
+        if getattr(self, "_last_state", None) is None:
+            raise capi.RgError("pending_latent(): no batch has been submitted")
+        return PendingLatent(self._last_state)
+
+    def _fill_prev(self, st, stream):
+        """Bind a pending prev_latent: on `stream`, once the producing batch's sampling is done, the first-token rows of its
+        final latent go into this batch's in_seq (what forward() does at once for a tensor; diffusion_architecture.py:243-262)."""
+        pf = st.prev_future
+        if pf is None:
+            return
+        st.prev_future = None
+        src = pf.state
+        if src.latent_ready is None:
+            raise capi.RgError("prev_latent: the batch this pending latent belongs to has not been queued for sampling yet "
+                               "(submit the windows in order)")
+        stream.wait_event(src.latent_ready)
+        self._used_on(stream, src.x_out, st.in_seq)
+        with torch.cuda.stream(stream):
+            lat = self.model.post_process(src.x_out)
+            if pf.rows is not None:
+                lat = lat.index_select(0, torch.tensor(pf.rows, device="cpu").pin_memory().to(self.device, non_blocking=True))
+            h = self.model.weights.h
+            for idx in st.idx_groups:
+                h.call("copy_rows", lat.contiguous(), st.in_seq, st.B, 1, st.D, st.T, idx[-1], st.T, idx[0])
 
     def _take_slot(self, pid, main):
         """Next set of sessions / graph buffers of pipeline `pid`; the caller's stream waits for the chain that used it last."""
@@ -824,6 +872,7 @@ class MotionDiffusion(torch.nn.Module):
             self._pend[st.pid] = st
             return None
         main = st.main
+        self._fill_prev(pend, main)
         guided = pend.use_insertion_guidance
         gi, lr = tuple(int(v) for v in pend.guidance_iters), float(pend.guidance_lr)
         work = []
@@ -934,6 +983,7 @@ class MotionDiffusion(torch.nn.Module):
     def _sampling_pass(self, st):
         """The sampling loops.  Every lane's inversion is queued before the first sampling graph is launched (a graph
         launch costs the host ~1.5 ms: lane 1 would otherwise start 3 ms behind lane 0)."""
+        self._fill_prev(st, st.main)
         T, x, in_seq, invl = st.T, st.x, st.in_seq, st.invl
         inverted = [(stream, stream.record_event()) for _, stream, _, _ in st.plan]
         for lane, stream, b0, b1 in st.plan_s:
@@ -974,6 +1024,7 @@ class MotionDiffusion(torch.nn.Module):
         for _, stream, _, _ in st.plan + st.plan_s:
             if stream is not tail:
                 tail.wait_stream(stream)
+        st.latent_ready = tail.record_event()      # (a later batch's pending prev_latent waits for this, not for the decode)
         self._used_on(tail, st.x_out, *st.vis_inv, *st.vis_pairs)
         with torch.cuda.stream(tail):
             output = self.model.post_process(st.x_out)

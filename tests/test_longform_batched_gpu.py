@@ -43,3 +43,47 @@ def test_run_many_equals_per_clip_runs(rg, precision):
             assert d <= 1e-5, (ci, k, d)
         assert np.isfinite(many[ci]["poses"]).all()
         assert np.abs(one["poses"] - many[ci]["poses"]).max() <= 1e-4
+
+
+@pytest.mark.parametrize("guided", [True, False])
+def test_pipelined_windows_equal_the_sequential_loop(rg, guided, tmp_path):
+    """run_many(pipelined=True): the windows go through submit() / flush() with the previous window's latent still pending
+    (pipeline.PendingLatent) -- retrieval + exemplar inversion of window k + 1 beside the sampling loop of window k.  Same
+    noise tape, clips of different lengths (the batch shrinks: the pending latent is row-selected), BASELINE config 5's
+    flags (llm retrieval on cached answers, inversion + insertion guidance + prev-latent): every latent and every output
+    must equal the sequential loop's, bit for bit."""
+    dev = torch.device("cuda", 0)
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder", num_layers=2)
+    ds = rg.synth.SyntheticDataset(300, seed=31, device=dev, feat_device=dev)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds, device=dev)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+    cache = rg.retrieval.LLMResponseCache(str(tmp_path / "llm_cache.json"), call=rg.synth.synth_llm_answer)
+    model.model.database.llm_output = cache.get
+    n_windows = [5, 2, 5, 5]          # windows 0-1: 4 clips, 2-4: 3 clips (window 4 shares its launches with window 2)
+    clips = [rg.synth.synth_longform_clip(40 + 100 * ci, windows=w, device=dev) for ci, w in enumerate(n_windows)]
+    feats = {(ci, w): rg.synth.synth_query(300 + 10 * ci + w)["text_features"].to(dev) for ci, n in enumerate(n_windows) for w in range(n)}
+    audio = {(ci, w): rg.synth.synth_batch(1, seed=1000 + 10 * ci + w, device=dev)["audio"] for ci, n in enumerate(n_windows) for w in range(n)}
+
+    def features(ci, cidx, t0, t1, ann):
+        text = " ".join(seg[1] for seg in ann["text_segments"][0])
+        return dict(audio=audio[(ci, cidx)], raw_word=[text], text_features=[feats[(ci, cidx)]])
+
+    synth = rg.longform.LongformSynthesizer(model, overlap=15)
+    copy = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    flags = dict(use_inversion=True, insertion_guidance=True, guidance_iters=[2] * 25 + [0] * 25, guidance_lr=0.1) if guided else {}
+    seq = synth.run_many([copy(c) for c in clips], features, noise_tape=rg.synth.NoiseTape(71), retrieval_method="llm",
+                         pipelined=False, **flags)
+    model.async_results = True
+    pip = synth.run_many([copy(c) for c in clips], features, noise_tape=rg.synth.NoiseTape(71), retrieval_method="llm", **flags)
+    torch.cuda.synchronize()
+    if guided:
+        assert any(k[0] == "cobatch" for k in model._graphs), "the pipelined run should have gone through co-batched chains"
+    assert not model._pend and not model._ready
+    for ci in range(len(clips)):
+        assert [len(seq[ci]["windows"]), len(pip[ci]["windows"])] == [n_windows[ci]] * 2
+        for w, (a, b) in enumerate(zip(seq[ci]["latents"], pip[ci]["latents"])):
+            assert torch.equal(a, b), (ci, w, (a - b).abs().max().item())
+        for k in ("poses", "expressions", "trans"):
+            assert np.array_equal(seq[ci][k], pip[ci][k]), (ci, k)
