@@ -89,14 +89,35 @@ class LongformSynthesizer:
         self.overlap = overlap if overlap is not None else model.model.cfg["frame_chunk_size"]
 
     def run(self, data, features, use_inversion=False, insertion_guidance=False, guidance_iters=None, guidance_lr=0.1,
-            outpaint=False, inversion_start_time=-1, retrieval_method="discourse", noise_tape=None, with_gt=False):
+            outpaint=False, inversion_start_time=-1, retrieval_method="discourse", noise_tape=None, with_gt=False,
+            pipelined=None):
         """with_gt: also carry the ground-truth triple (the model's returned motion / facial / trans inputs) through the
         same overlap blend and interpolation, as the tool does for gt_motion.npz (longform_synthesis.py:480-520, 722-745);
-        adds gt_poses / gt_expressions / gt_trans to the result."""
+        adds gt_poses / gt_expressions / gt_trans to the result.
+        pipelined (default: model.async_results): windows through model.submit() / flush(), see run_many."""
         sample_len = data["motion"].shape[1]
         starts, ends, remainder = window_bounds(sample_len, self.seqlen, self.overlap)
         data = pad_tail(data, remainder)
-        prev_latent, so_far, gt_so_far, latents = None, None, None, []
+        if pipelined is None:
+            pipelined = bool(getattr(self.model, "async_results", False)) and not outpaint
+        if pipelined:
+            capi.require(not self.model._pend and not self.model._ready,
+                         "long-form synthesis (pipelined): the model's submit() pipeline must be empty (call flush() first)")
+        state = dict(so_far=None, gt_so_far=None, n=0)
+        prev_latent, latents = None, []
+
+        def take(out):
+            cidx = state["n"]
+            state["n"] += 1
+            latents.append(out["prev_latentout"])
+            cur = (packing.scatter_parts(out["pred_upper"], out["pred_lower"], out["pred_hands"], out["pred_facepose"]),
+                   out["pred_exps"].float(), out["pred_transl"].float())
+            state["so_far"] = cur if cidx == 0 else blend_window(state["so_far"], cur, self.overlap)
+            if with_gt:
+                dev = cur[0].device
+                gt = tuple(out[k].to(dev).float() for k in ("motion", "facial", "trans"))
+                state["gt_so_far"] = gt if cidx == 0 else blend_window(state["gt_so_far"], gt, self.overlap)
+
         for cidx, (c0, c1) in enumerate(zip(starts, ends)):
             t0, t1 = c0 / self.fps, c1 / self.fps
             chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
@@ -117,16 +138,20 @@ class LongformSynthesizer:
             if noise_tape is not None:
                 ikw["noise_tape"] = noise_tape
             chunk["inference_kwargs"] = ikw
-            out = self.model(**chunk)
-            prev_latent = out["prev_latentout"]
-            latents.append(prev_latent)
-            cur = (packing.scatter_parts(out["pred_upper"], out["pred_lower"], out["pred_hands"], out["pred_facepose"]),
-                   out["pred_exps"].float(), out["pred_transl"].float())
-            so_far = cur if cidx == 0 else blend_window(so_far, cur, self.overlap)
-            if with_gt:
-                dev = cur[0].device
-                gt = tuple(out[k].to(dev).float() for k in ("motion", "facial", "trans"))
-                gt_so_far = gt if cidx == 0 else blend_window(gt_so_far, gt, self.overlap)
+            if pipelined:
+                out = self.model.submit(**chunk)
+                prev_latent = self.model.pending_latent()     # bound when the next window's sampling is queued
+                if out is not None:
+                    take(out)
+            else:
+                out = self.model(**chunk)
+                prev_latent = out["prev_latentout"]
+                take(out)
+        if pipelined:
+            for out in self.model.flush():
+                take(out)
+        capi.require(state["n"] == len(starts), "long-form synthesis: windows left in the pipeline")
+        so_far, gt_so_far = state["so_far"], state["gt_so_far"]
         motion, facial, trans = so_far
         scale = self.target_fps // self.fps
         if scale != 1:

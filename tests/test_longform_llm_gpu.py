@@ -106,10 +106,21 @@ def test_config5_one_clip_three_windows_l8_vs_oracle(rg, tmp_path, parity):
 
     synth = rg.longform.LongformSynthesizer(model, overlap=15)
     flags = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    seq = synth.run({k: (v.clone() if torch.is_tensor(v) else v) for k, v in clip.items()}, features, retrieval_method="llm",
+                    noise_tape=rg.synth.NoiseTape(5), **flags)
+    assert sum(bool(seen[c]["text"]) for c in range(3)) == 3 and cache.misses == 3
+    # the throughput path: the same loop with the windows pipelined through submit() / flush() (window k + 1's retrieval and
+    # inversion beside window k's sampling, its prev_latent bound late); this is what is compared with the oracle below
+    model.async_results = True
+    rdb.test_indexes.clear(); rdb.test_dbounds.clear(); rdb.test_qbounds.clear()
     got = synth.run({k: (v.clone() if torch.is_tensor(v) else v) for k, v in clip.items()}, features, retrieval_method="llm",
                     noise_tape=rg.synth.NoiseTape(5), **flags)
+    assert any(k[0] == "cobatch" for k in model._graphs)
+    for a, b in zip(seq["latents"], got["latents"]):
+        assert torch.equal(a, b)
+    assert np.array_equal(seq["poses"], got["poses"])
     assert got["windows"] == [(0, 150), (135, 285), (270, 420)] and got["poses"].shape == (810, 165)
-    assert sum(bool(seen[c]["text"]) for c in range(3)) == 3 and cache.misses == 3
+    assert cache.misses == 3
 
     # ---- oracle loop (same noise tape order, same cached answers)
     odb = oret.build_db_dicts(ds.retrieval_samples)
