@@ -175,6 +175,11 @@ typedef struct rg_gemm_desc {
 } rg_gemm_desc;
 
 int rg_gemm(rg_handle* h, const rg_gemm_desc* desc_host, void* stream);
+/* n GEMMs that share a shape signature (M, N, K, operand kinds, epilogue features) in one launch: descriptor i belongs to
+ * the workgroups with blockIdx.y = i (the four body-part VAEs run the same layer on different weights: 4x fewer dependent
+ * launches in the front end, which is what it costs beside running denoiser chains).  descs_host: array of n descriptors;
+ * groups that do not share a signature, or n > 4, are launched one by one.  Same result bits as n rg_gemm calls. */
+int rg_gemm_grouped(rg_handle* h, const rg_gemm_desc* descs_host, int n, void* stream);
 
 /* The A-operand prologue of rg_gemm as a standalone pass: out[row, s*seg_len + k] =
  * bf16(f_s(src_s[row,k])) for nseg fp32 segments (identity / LayerNorm / stylization front half,
@@ -381,6 +386,19 @@ int rg_time_groupnorm_gelu(rg_handle* h, const float* x, const float* gamma, con
                            float* out_f32, int T, int C, float eps, float* workspace, void* stream);
 int rg_im2col_grouped(rg_handle* h, const float* x, void* out_bf16, int T, int C, int groups, int ksize, int pad, void* stream);
 
+/* Grouped forms: n <= 4 problems of ONE shape in one launch (host arrays of n device pointers; everything else shared).
+ * The four body-part VAEs run the same layer sequence on different weights and rows: issuing a layer of all four as one
+ * launch divides the number of dependent launches of a VAE encode / decode by four (vae.py records the parts' launch
+ * sequences and zips them).  Result bits equal the single calls. */
+int rg_layernorm_grouped(rg_handle* h, int n, const float* const* x, const float* const* gamma, const float* const* beta,
+                         float* const* out, int rows, int dim, void* const* out_bf16, void* stream);
+int rg_add_rows_grouped(rg_handle* h, int n, const float* const* a, const float* const* b, float* const* out, int64_t n_elems,
+                        int64_t period, void* stream);
+int rg_copy_rows_grouped(rg_handle* h, int n, const float* const* src, float* const* dst, int groups, int nrows_per, int dim,
+                         int rows_src_per, int src_row0, int rows_dst_per, int dst_row0, void* stream);
+int rg_mha_bf16_grouped(rg_handle* h, int n, const float* const* q, int ldq, const float* const* k, int ldk,
+                        const float* const* v, int ldv, void* const* o, int ldo, int out_is_bf16, int B, int H, int Sq, int Sk,
+                        int hd, void* stream);
 /* out[i] = a[i] + b[i % period]: positional embeddings / `with_pos_embed` (detr_utils.py:357-358). */
 int rg_add_rows(rg_handle* h, const float* a, const float* b, float* out, int64_t n, int64_t period, void* stream);
 

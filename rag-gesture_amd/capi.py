@@ -115,6 +115,7 @@ class Handle:
         if rc != 0:
             raise RgError("rg_create failed with %d" % rc)
         self._h = h
+        self.recorder = None      # an OpRecorder while launches are being recorded instead of issued (vae.py)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -129,6 +130,9 @@ class Handle:
 
     def call(self, name, *args, stream=None):
         """Invoke rg_<name>(handle, *args, stream) and raise on a non-zero status."""
+        if self.recorder is not None and stream is None:
+            self.recorder.add(("call", name, args))     # (the tensors in args stay alive until the recorder has issued)
+            return
         fn = getattr(self.lib, "rg_" + name)
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream
         if fn.argtypes is None or len(fn.argtypes) != len(args) + 2:
@@ -140,6 +144,88 @@ class Handle:
             raise RgError("rg_%s: %s" % (name, e))
         if rc != 0:
             raise RgError("rg_%s failed (%d): %s" % (name, rc, self.lib.rg_last_error(self._h).decode()))
+
+
+class OpRecorder:
+    """Launch sequences of up to 4 independent, structurally identical jobs (the four body-part VAEs: same layers,
+    different weights and rows), recorded job by job and issued position by position: where the jobs' i-th launches are
+    the same operation on the same shapes they go out as ONE grouped launch (rg_gemm_grouped, rg_layernorm_grouped, ...),
+    otherwise one by one in job order.  Control flow never depends on device data, so recording is exact; recorded
+    arguments keep their tensors alive until `issue` (the allocator must not reuse a block of job 0 for job 1 while job 0's
+    later launches, issued later, still need it)."""
+    # name -> (indices of the per-job pointer arguments, grouped entry point, argument order of the grouped call)
+    GROUPED = {"layernorm": ((0, 1, 2, 3, 6), "layernorm_grouped", ("P0", "P1", "P2", "P3", 4, 5, "P6")),
+               "add_rows": ((0, 1, 2), "add_rows_grouped", ("P0", "P1", "P2", 3, 4)),
+               "copy_rows": ((0, 1), "copy_rows_grouped", ("P0", "P1", 2, 3, 4, 5, 6, 7, 8))}
+
+    def __init__(self):
+        self.jobs, self.cur = [], None
+
+    def begin_job(self):
+        self.cur = []
+        self.jobs.append(self.cur)
+
+    def add(self, op):
+        self.cur.append(op)
+
+    @staticmethod
+    def _ptr(a):
+        return None if a is None else (_convert(a) if isinstance(a, torch.Tensor) else a)
+
+    def _single(self, h, op, s):
+        if op[0] == "call":
+            h.call(op[1], *op[2], stream=s)
+        elif op[0] == "gemm":
+            rc = h.lib.rg_gemm(h._h, ctypes.byref(op[1]), ctypes.c_void_p(s))
+            if rc != 0:
+                raise RgError("rg_gemm failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
+        else:   # ("mha", fast, args)
+            fn = h.lib.rg_mha_bf16 if op[1] else h.lib.rg_mha
+            a = [self._ptr(x) for x in op[2]]
+            if fn(h._h, *a, s) != 0:
+                raise RgError("rg_mha failed: %s" % h.lib.rg_last_error(h._h).decode())
+
+    def issue(self, h):
+        """Launch everything that was recorded (on the current stream) and forget it."""
+        jobs, self.jobs, self.cur = self.jobs, [], None
+        s = torch.cuda.current_stream().cuda_stream
+        n = len(jobs)
+        if n == 0:
+            return
+        if n > 4 or len({len(j) for j in jobs}) != 1:
+            for j in jobs:
+                for op in j:
+                    self._single(h, op, s)
+            return
+        arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+        for ops in zip(*jobs):
+            kinds = {(op[0], op[1] if op[0] != "gemm" else None) for op in ops}
+            done = False
+            if n > 1 and len(kinds) == 1:
+                kind = ops[0][0]
+                if kind == "gemm":
+                    descs = (type(ops[0][1]) * n)(*[op[1] for op in ops])
+                    rc = h.lib.rg_gemm_grouped(h._h, descs, n, ctypes.c_void_p(s))
+                    if rc != 0:
+                        raise RgError("rg_gemm_grouped failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
+                    done = True
+                elif kind == "call" and ops[0][1] in self.GROUPED:
+                    pidx, entry, order = self.GROUPED[ops[0][1]]
+                    shared = [tuple(a for i, a in enumerate(op[2]) if i not in pidx) for op in ops]
+                    nulls = [tuple(op[2][i] is None for i in pidx) for op in ops]
+                    if len(set(shared)) == 1 and len(set(nulls)) == 1:
+                        args = [arr([self._ptr(op[2][int(o[1:])]) for op in ops]) if isinstance(o, str) else ops[0][2][o] for o in order]
+                        h.call(entry, n, *args, stream=s)
+                        done = True
+                elif kind == "mha" and ops[0][1]:
+                    a0 = ops[0][2]
+                    if all(tuple(op[2][i] for i in (1, 3, 5, 7, 8, 9, 10, 11, 12, 13)) == tuple(a0[i] for i in (1, 3, 5, 7, 8, 9, 10, 11, 12, 13)) for op in ops):
+                        q, k, v, o = (arr([self._ptr(op[2][i]) for op in ops]) for i in (0, 2, 4, 6))
+                        h.call("mha_bf16_grouped", n, q, a0[1], k, a0[3], v, a0[5], o, *a0[7:], stream=s)
+                        done = True
+            if not done:
+                for op in ops:
+                    self._single(h, op, s)
 
 
 _handles = {}

@@ -57,7 +57,8 @@ struct Stage {                 // one K-tile in flight in registers
 // loads it falls back to vmcnt(0) at the LDS store and the software pipeline degenerates into one
 // exposed memory latency per K-tile (measured ~1 us per tile).
 template <bool A_BF16, bool SPLIT, bool FAST>
-__global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_desc p) {
+__global__ void __launch_bounds__(NT) gemm_kernel(const rg_gemm_group grp) {
+  const rg_gemm_desc& p = grp.d[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPL = SPLIT ? 2 : 1;                       // hi (+ lo) planes
   constexpr int STAGE_BYTES = NPL * (A_TILE + W_TILE);
@@ -386,7 +387,7 @@ void launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
                               (int)lds_bytes<A_BF16, SPLIT>(RG_MAX_SEG));
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<A_BF16, SPLIT, FAST>), grid, dim3(NT), lds, s, *d);
+  hipLaunchKernelGGL((gemm_kernel<A_BF16, SPLIT, FAST>), rg_group_grid(grid), dim3(NT), lds, s, rg_group_of(d));
 }
 
 // aligned shapes whose K loop splits into quads of 64-wide tiles
@@ -407,7 +408,7 @@ bool rg_gemm_big_eligible(const rg_gemm_desc* d);          // rg_gemm_big.hip
 int rg_gemm_big_width(const rg_gemm_desc* d, int num_cus); // 0 = do not use, else 128 / 256
 void rg_gemm_big_launch(const rg_gemm_desc* d, int bn, void* stream);
 
-extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
+static int gemm_validate(rg_handle* h, const rg_gemm_desc* d) {
   RG_REQUIRE(h, d != nullptr, "null descriptor");
   RG_REQUIRE(h, d->M > 0 && d->N > 0 && d->K > 0, "empty problem");
   RG_REQUIRE(h, d->W && d->out, "null W/out");
@@ -440,6 +441,15 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
       if (d->seg[s].mode == RG_A_STYL) RG_REQUIRE(h, d->seg[s].scale_shift, "STYL segment needs scale_shift");
     }
   }
+  if (d->W_lo) RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
+  if (d->tile_n == 64)
+    RG_REQUIRE(h, d->a_is_bf16 && !d->W_lo && rg_gemm_dma_eligible(d) && d->N % 64 == 0 && d->split_col == 0,
+               "tile_n = 64 needs a bf16 A operand, aligned shapes and N % 64 == 0");
+  return RG_OK;
+}
+
+extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
+  if (int rc = gemm_validate(h, d)) return rc;
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + BN - 1) / BN;
   dim3 grid(mt * nt);
   rg_prof_rec rec;
@@ -451,10 +461,9 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
     };
     rec.start = get_ev(); rec.stop = get_ev();
     rec.variant = d->W_lo ? 2 : (d->a_is_bf16 ? 1 : 0);
-    rec.flops = 2.0 * (double)d->M * (double)d->N * (double)d->K;
+    rec.flops = 2.0 * (double)d->M * (double)d->N * (double)d->K * rg_group_n;
     (void)hipEventRecord(rec.start, rg_stream(stream));
   }
-  if (d->W_lo) RG_REQUIRE(h, !d->a_is_bf16, "the split (bf16x3) mode needs fp32 A segments");
   // gemm_path: 0 = auto (LDS-DMA kernel where eligible, else generic),
   //            1 = generic only, 2 = prefer LDS-DMA, 3 = prefer register-staged FAST
   //            4 = prefer the 128-row big-tile kernel (bf16 A), 5 = never use it
@@ -463,8 +472,6 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
   const bool big_ok = rg_gemm_big_eligible(d);
   const int big_bn = big_ok ? (path == 4 ? (d->N >= 256 ? 256 : 128) : path == 6 ? 128 : path == 7 ? 129 : (path == 0 ? rg_gemm_big_width(d, h->num_cus) : 0)) : 0;
   if (d->tile_n == 64) {
-    RG_REQUIRE(h, d->a_is_bf16 && !d->W_lo && dma_ok && d->N % 64 == 0 && d->split_col == 0,
-               "tile_n = 64 needs a bf16 A operand, aligned shapes and N % 64 == 0");
     rg_gemm_dma_launch(d, h->num_cus, h->gemm_waves, stream);
   } else if (big_bn) {
     rg_gemm_big_launch(d, big_bn, stream);
@@ -486,6 +493,42 @@ extern "C" int rg_gemm(rg_handle* h, const rg_gemm_desc* d, void* stream) {
     h->prof.push_back(rec);
   }
   return RG_OK;
+}
+
+// n GEMMs of one shape signature (same M, N, K, operand kinds and epilogue features; pointers, leading dimensions,
+// activation and output type per descriptor) in ONE launch: descriptor i is computed by the workgroups with blockIdx.y = i.
+// Descriptors that do not share a signature (or more than RG_GEMM_GROUP of them) are launched one by one.
+extern "C" int rg_gemm_grouped(rg_handle* h, const rg_gemm_desc* descs, int n, void* stream) {
+  RG_REQUIRE(h, descs != nullptr && n >= 1, "rg_gemm_grouped: no descriptors");
+  for (int i = 0; i < n; ++i)
+    if (int rc = gemm_validate(h, &descs[i])) return rc;
+  auto key = [&](const rg_gemm_desc& d, int* k) {
+    int j = 0;
+    k[j++] = d.M; k[j++] = d.N; k[j++] = d.K; k[j++] = d.a_is_bf16; k[j++] = d.nseg; k[j++] = d.seg_len; k[j++] = d.a_row_mod;
+    k[j++] = d.gb_group; k[j++] = d.tile_n; k[j++] = d.split_col; k[j++] = d.ln_stats ? d.ln_nparts : -1; k[j++] = d.W_lo != nullptr;
+    k[j++] = d.residual != nullptr; k[j++] = d.stats_out != nullptr; k[j++] = d.out2 != nullptr; k[j++] = d.softmax_cols;
+    k[j++] = d.tbias != nullptr; k[j++] = d.bias != nullptr;
+    for (int sg = 0; sg < RG_MAX_SEG; ++sg) { k[j++] = sg < d.nseg ? d.seg[sg].mode : -1; k[j++] = sg < d.nseg ? d.seg[sg].nparts : -1; }
+    k[j++] = reg_fast_eligible(&d); k[j++] = rg_gemm_dma_eligible(&d); k[j++] = rg_gemm_big_eligible(&d);
+    k[j++] = rg_gemm_big_eligible(&d) ? rg_gemm_big_width(&d, h->num_cus) : 0;
+    return j;
+  };
+  bool same = n <= RG_GEMM_GROUP;
+  int k0[64], ki[64];
+  const int nk = key(descs[0], k0);
+  for (int i = 1; i < n && same; ++i) {
+    key(descs[i], ki);
+    for (int j = 0; j < nk; ++j) same = same && ki[j] == k0[j];
+  }
+  if (!same || n == 1) {
+    for (int i = 0; i < n; ++i)
+      if (int rc = rg_gemm(h, &descs[i], stream)) return rc;
+    return RG_OK;
+  }
+  rg_group_n = n;
+  const int rc = rg_gemm(h, descs, stream);
+  rg_group_n = 1;
+  return rc;
 }
 
 // HIP-event instrumentation of the GEMM launches between begin and end (bench.py's roofline

@@ -20,7 +20,8 @@ __device__ __forceinline__ void wait_vmcnt_big() {
 }
 
 template <int BNT, int NS, int MINW = 1>
-__global__ void __launch_bounds__(512, MINW) gemm_bf16_big_kernel(const rg_gemm_desc p) {
+__global__ void __launch_bounds__(512, MINW) gemm_bf16_big_kernel(const rg_gemm_group grp) {
+  const rg_gemm_desc& p = grp.d[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int A_ST = BBM * ROW_BYTES;            // 16 KiB
   constexpr int W_ST = BNT * ROW_BYTES;            // 16 / 32 KiB
@@ -145,7 +146,7 @@ void big_launch(const rg_gemm_desc* d, hipStream_t s) {
   size_t lds = (size_t)NS * (BBM + BNT) * ROW_BYTES;
   const size_t epi = (size_t)2 * (BNT / 128) * BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
-  hipLaunchKernelGGL((gemm_bf16_big_kernel<BNT, NS, MINW>), dim3(mt * nt), dim3(512), lds, s, *d);
+  hipLaunchKernelGGL((gemm_bf16_big_kernel<BNT, NS, MINW>), rg_group_grid(dim3(mt * nt)), dim3(512), lds, s, rg_group_of(d));
 }
 
 }  // namespace

@@ -72,7 +72,8 @@ __device__ __forceinline__ void wait_tiles(int younger) {
 // (4.9 us per launch at M = 1376) or of the fragment-read prologue of the fp32-A kernel, which redoes the two
 // transcendentals in every wave column (x4) and fetches fp32 rows.
 template <bool A_BF16, bool SPLIT, int NS, int NW, int BN_ = BN, bool STYL = false, int MINW = 1>
-__global__ void __launch_bounds__(NW * 64, MINW) gemm_dma_kernel(const rg_gemm_desc p) {
+__global__ void __launch_bounds__(NW * 64, MINW) gemm_dma_kernel(const rg_gemm_group grp) {
+  const rg_gemm_desc& p = grp.d[blockIdx.y];
   static_assert(!STYL || (A_BF16 && !SPLIT && NS >= 3), "STYL: bf16 A, one weight plane, ring of >= 3");
   constexpr int NTH = NW * 64;
   constexpr int WN = NW / 2;            // waves along N (2 along M)
@@ -446,7 +447,7 @@ void dma_launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
     attr = true;
   }
   const size_t lds = dma_lds_bytes<A_BF16, SPLIT>(d->nseg, NS, stat_bytes(d));
-  hipLaunchKernelGGL((gemm_dma_kernel<A_BF16, SPLIT, NS, NW>), grid, dim3(NW * 64), lds, s, *d);
+  hipLaunchKernelGGL((gemm_dma_kernel<A_BF16, SPLIT, NS, NW>), rg_group_grid(grid), dim3(NW * 64), lds, s, rg_group_of(d));
 }
 
 // 64x64 tiles, bf16 A, 4 waves (2x2, 32x32 each), 4-stage ring of 16 KiB; the epilogue tile keeps its 128-column stride
@@ -462,7 +463,7 @@ void dma_launch_narrow_ns(const rg_gemm_desc* d, hipStream_t s) {
   const size_t epi = (size_t)BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
   const int mt = (d->M + BM - 1) / BM, nt = (d->N + 63) / 64;
-  hipLaunchKernelGGL((gemm_dma_kernel<true, false, NS, 4, 64>), dim3(mt * nt), dim3(256), lds, s, *d);
+  hipLaunchKernelGGL((gemm_dma_kernel<true, false, NS, 4, 64>), rg_group_grid(dim3(mt * nt)), dim3(256), lds, s, rg_group_of(d));
 }
 
 // Ring depth: 4.  Measured (M = 688..2064, K = 512..2048, graph-replayed chains on rotating operands): a 6-stage
@@ -485,7 +486,7 @@ void dma_launch_styl(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
   size_t lds = (size_t)NS * (A_TILE + W_TILE) + stat_bytes(d) + 2 * SEG_MAX * sizeof(float);
   const size_t epi = (size_t)BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
-  hipLaunchKernelGGL((gemm_dma_kernel<true, false, NS, NW, BN, true>), grid, dim3(NW * 64), lds, s, *d);
+  hipLaunchKernelGGL((gemm_dma_kernel<true, false, NS, NW, BN, true>), rg_group_grid(grid), dim3(NW * 64), lds, s, rg_group_of(d));
 }
 
 // 8 waves, ring of 3 (76.5 KiB), at most 128 VGPRs (no residual prefetch): two workgroups per CU
@@ -497,7 +498,7 @@ void dma_launch_pair(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
     attr = true;
   }
   const size_t lds = dma_lds_bytes<true, false>(0, 3, stat_bytes(d));
-  hipLaunchKernelGGL((gemm_dma_kernel<true, false, 3, 8, BN, false, 4>), grid, dim3(512), lds, s, *d);
+  hipLaunchKernelGGL((gemm_dma_kernel<true, false, 3, 8, BN, false, 4>), rg_group_grid(grid), dim3(512), lds, s, rg_group_of(d));
 }
 
 // ring depth for this descriptor (0: does not fit the 160 KiB LDS at all).  Grids with more

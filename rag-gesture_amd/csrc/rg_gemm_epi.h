@@ -104,6 +104,19 @@ __device__ __forceinline__ void lds_row_stats(const float* sp, int nparts, int K
   rs = rsqrtf(var + 1e-5f);
 }
 
+// Up to RG_GEMM_GROUP independent GEMMs of the SAME shape signature in one launch (blockIdx.y picks the descriptor): the four
+// body-part VAEs run the same layer on different weights and rows (rg_gemm_grouped).  Every kernel takes the group by
+// value and reads its descriptor from the kernel arguments, exactly as it read the single descriptor before.
+#define RG_GEMM_GROUP 4
+struct rg_gemm_group { rg_gemm_desc d[RG_GEMM_GROUP]; };
+inline thread_local int rg_group_n = 1;      // descriptors behind the pointer every launcher receives (set by rg_gemm_grouped)
+inline rg_gemm_group rg_group_of(const rg_gemm_desc* d) {
+  rg_gemm_group g;
+  for (int i = 0; i < RG_GEMM_GROUP; ++i) g.d[i] = d[i < rg_group_n ? i : 0];
+  return g;
+}
+inline dim3 rg_group_grid(dim3 grid) { grid.y = rg_group_n; return grid; }
+
 // statistics partials per row that the LDS-DMA kernel stages for a descriptor with a bf16 A operand
 __host__ __device__ inline int dma_stat_parts(const rg_gemm_desc& d) {
   if (d.a_is_bf16 && d.nseg == 1 && d.seg[0].mode == RG_A_STYL) return d.seg[0].nparts;

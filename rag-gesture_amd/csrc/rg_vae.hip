@@ -115,10 +115,10 @@ __device__ __forceinline__ unsigned int mh_pack(float a, float b) {
 
 // HD_ = head dim padded to a multiple of 32 (the MFMA k-step); HDR = real head dim (16 -> zero padded)
 template <int HD_, int HDR, int MAXSK = MH_MAX_SK>
-__global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
-                                                      int ldk, const float* __restrict__ v, int ldv,
-                                                      float* __restrict__ o, int ldo, int H, int Sq, int Sk, float scale,
-                                                      int out_bf16) {
+__device__ __forceinline__ void mha_mfma_body(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                              int ldk, const float* __restrict__ v, int ldv,
+                                              float* __restrict__ o, int ldo, int H, int Sq, int Sk, float scale,
+                                              int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
   constexpr int KST = HD_ + 8;                 // bf16 elements per K row (pad: 16 key rows hit 16 bank groups)
   constexpr int KS = HD_ / 32;                 // k-steps of S^T = K Q^T
@@ -256,6 +256,38 @@ __global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__
 }
 
 template <int HD_, int HDR, int MAXSK = MH_MAX_SK>
+__global__ void __launch_bounds__(256) mha_mfma_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                      int ldk, const float* __restrict__ v, int ldv,
+                                                      float* __restrict__ o, int ldo, int H, int Sq, int Sk, float scale,
+                                                      int out_bf16) {
+  mha_mfma_body<HD_, HDR, MAXSK>(q, ldq, k, ldk, v, ldv, o, ldo, H, Sq, Sk, scale, out_bf16);
+}
+
+// up to 4 independent problems of one shape in a launch (blockIdx.z picks the pointers): the four body-part VAEs
+struct mha_group { const float* q[4]; const float* k[4]; const float* v[4]; float* o[4]; };
+template <int HD_, int HDR, int MAXSK = MH_MAX_SK>
+__global__ void __launch_bounds__(256) mha_mfma_group_kernel(const mha_group g, int ldq, int ldk, int ldv, int ldo, int H, int Sq,
+                                                            int Sk, float scale, int out_bf16) {
+  const int z = blockIdx.z;
+  mha_mfma_body<HD_, HDR, MAXSK>(g.q[z], ldq, g.k[z], ldk, g.v[z], ldv, g.o[z], ldo, H, Sq, Sk, scale, out_bf16);
+}
+
+template <int HD_, int HDR, int MAXSK = MH_MAX_SK>
+static int launch_mha_mfma_group(const mha_group& g, int n, int ldq, int ldk, int ldv, int ldo, int B, int H, int Sq, int Sk,
+                                 int out_bf16, hipStream_t s) {
+  const int Skp = (Sk + 31) & ~31;
+  const size_t lds = ((size_t)Skp * (HD_ + 8) + (size_t)HD_ * (Skp + 8)) * sizeof(unsigned short);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)mha_mfma_group_kernel<HD_, HDR, MAXSK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((mha_mfma_group_kernel<HD_, HDR, MAXSK>), dim3(B * H, (Sq + 63) / 64, n), dim3(256), lds, s, g, ldq, ldk, ldv, ldo,
+                     H, Sq, Sk, 1.0f / sqrtf((float)HDR), out_bf16);
+  return 0;
+}
+
+template <int HD_, int HDR, int MAXSK = MH_MAX_SK>
 static int launch_mha_mfma(rg_handle* h, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                            float* o, int ldo, int B, int H, int Sq, int Sk, int out_bf16, hipStream_t s) {
   const int Skp = (Sk + 31) & ~31;
@@ -271,9 +303,9 @@ static int launch_mha_mfma(rg_handle* h, const float* q, int ldq, const float* k
 }
 
 // ------------------------------------------------------------------------------ LayerNorm, one wave per row
-__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                       const float* __restrict__ b, float* __restrict__ out, int rows,
-                                                       int dim, float eps, unsigned short* __restrict__ out_bf16) {
+__device__ __forceinline__ void layernorm_body(const float* __restrict__ x, const float* __restrict__ g,
+                                               const float* __restrict__ b, float* __restrict__ out, int rows,
+                                               int dim, float eps, unsigned short* __restrict__ out_bf16) {
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * dim;
@@ -296,6 +328,17 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
     orow[i] = v;
     if (out_bf16) out_bf16[(size_t)row * dim + i] = __builtin_bit_cast(unsigned short, (__bf16)v);   // next GEMM's A operand
   }
+}
+
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float* __restrict__ out, int rows,
+                                                       int dim, float eps, unsigned short* __restrict__ out_bf16) {
+  layernorm_body(x, g, b, out, rows, dim, eps, out_bf16);
+}
+struct ln_group { const float* x[4]; const float* g[4]; const float* b[4]; float* out[4]; unsigned short* o16[4]; };
+__global__ void __launch_bounds__(256) layernorm_group_kernel(const ln_group p, int rows, int dim, float eps) {
+  const int z = blockIdx.y;
+  layernorm_body(p.x[z], p.g[z], p.b[z], p.out[z], rows, dim, eps, p.o16[z]);
 }
 
 // LN(x + r) with a caller-supplied eps (post-norm encoder layers of BERT / wav2vec2); one wave per row
@@ -328,19 +371,29 @@ __global__ void __launch_bounds__(256) layernorm_res_kernel(const float* __restr
   }
 }
 
-__global__ void __launch_bounds__(256) add_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
-                                                      float4* __restrict__ out, int64_t n4, int64_t period4) {
+__device__ __forceinline__ void add_rows_body(const float4* __restrict__ a, const float4* __restrict__ b,
+                                              float4* __restrict__ out, int64_t n4, int64_t period4) {
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     float4 x = a[i], y = b[i % period4];
     out[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
   }
 }
 
+__global__ void __launch_bounds__(256) add_rows_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                      float4* __restrict__ out, int64_t n4, int64_t period4) {
+  add_rows_body(a, b, out, n4, period4);
+}
+struct ptr3_group { const float* a[4]; const float* b[4]; float* out[4]; };
+__global__ void __launch_bounds__(256) add_rows_group_kernel(const ptr3_group p, int64_t n4, int64_t period4) {
+  const int z = blockIdx.y;
+  add_rows_body((const float4*)p.a[z], (const float4*)p.b[z], (float4*)p.out[z], n4, period4);
+}
+
 // copy `nrows_per` rows per group from src (row stride ld_src, rows_src_per rows per group, starting at
 // src_row0 inside the group) to dst (rows_dst_per rows per group, starting at dst_row0).
-__global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                       int groups, int nrows_per, int dim, int rows_src_per,
-                                                       int src_row0, int rows_dst_per, int dst_row0) {
+__device__ __forceinline__ void copy_rows_body(const float* __restrict__ src, float* __restrict__ dst,
+                                               int groups, int nrows_per, int dim, int rows_src_per,
+                                               int src_row0, int rows_dst_per, int dst_row0) {
   const int64_t total = (int64_t)groups * nrows_per * dim;
   for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % dim);
@@ -349,6 +402,17 @@ __global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict_
     dst[((int64_t)g * rows_dst_per + dst_row0 + rr) * dim + c] =
         src[((int64_t)g * rows_src_per + src_row0 + rr) * dim + c];
   }
+}
+
+__global__ void __launch_bounds__(256) copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       int groups, int nrows_per, int dim, int rows_src_per,
+                                                       int src_row0, int rows_dst_per, int dst_row0) {
+  copy_rows_body(src, dst, groups, nrows_per, dim, rows_src_per, src_row0, rows_dst_per, dst_row0);
+}
+__global__ void __launch_bounds__(256) copy_rows_group_kernel(const ptr3_group p, int groups, int nrows_per, int dim,
+                                                             int rows_src_per, int src_row0, int rows_dst_per, int dst_row0) {
+  const int z = blockIdx.y;
+  copy_rows_body(p.a[z], p.out[z], groups, nrows_per, dim, rows_src_per, src_row0, rows_dst_per, dst_row0);
 }
 
 // z[b, row_off + c, :] = mu + exp(logvar)^0.5 * eps  with mu = enc[(b*n_chunks+c), 0, :], logvar = enc[.., 1, :]
@@ -659,6 +723,74 @@ extern "C" int rg_copy_rows(rg_handle* h, const float* src, float* dst, int grou
   RG_REQUIRE(h, groups > 0 && nrows_per > 0 && dim > 0, "bad shape");
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((int64_t)groups * nrows_per * dim)), dim3(256), 0,
                      rg_stream(stream), src, dst, groups, nrows_per, dim, rows_src_per, src_row0, rows_dst_per, dst_row0);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+// ---- up to 4 problems of one shape per launch (the four body-part VAEs; same bits as the single calls)
+extern "C" int rg_layernorm_grouped(rg_handle* h, int n, const float* const* x, const float* const* gamma, const float* const* beta,
+                                    float* const* out, int rows, int dim, void* const* out_bf16, void* stream) {
+  RG_REQUIRE(h, n >= 1 && n <= 4 && x && gamma && beta && out && out_bf16, "1..4 problems");
+  RG_REQUIRE(h, rows > 0 && dim > 0, "bad shape");
+  ln_group p{};
+  for (int i = 0; i < n; ++i) {
+    RG_REQUIRE(h, x[i] && gamma[i] && beta[i] && out[i], "null pointer");
+    p.x[i] = x[i]; p.g[i] = gamma[i]; p.b[i] = beta[i]; p.out[i] = out[i]; p.o16[i] = reinterpret_cast<unsigned short*>(out_bf16[i]);
+  }
+  hipLaunchKernelGGL(layernorm_group_kernel, dim3(((int64_t)rows * 64 + 255) / 256, n), dim3(256), 0, rg_stream(stream), p, rows,
+                     dim, 1e-5f);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_add_rows_grouped(rg_handle* h, int n, const float* const* a, const float* const* b, float* const* out,
+                                   int64_t nel, int64_t period, void* stream) {
+  RG_REQUIRE(h, n >= 1 && n <= 4 && a && b && out, "1..4 problems");
+  RG_REQUIRE(h, nel > 0 && period > 0 && nel % 4 == 0 && period % 4 == 0, "sizes must be multiples of 4");
+  ptr3_group p{};
+  for (int i = 0; i < n; ++i) {
+    RG_REQUIRE(h, a[i] && b[i] && out[i], "null pointer");
+    p.a[i] = a[i]; p.b[i] = b[i]; p.out[i] = out[i];
+  }
+  hipLaunchKernelGGL(add_rows_group_kernel, dim3(grid_for(nel / 4), n), dim3(256), 0, rg_stream(stream), p, nel / 4, period / 4);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_copy_rows_grouped(rg_handle* h, int n, const float* const* src, float* const* dst, int groups, int nrows_per,
+                                    int dim, int rows_src_per, int src_row0, int rows_dst_per, int dst_row0, void* stream) {
+  RG_REQUIRE(h, n >= 1 && n <= 4 && src && dst, "1..4 problems");
+  RG_REQUIRE(h, groups > 0 && nrows_per > 0 && dim > 0, "bad shape");
+  ptr3_group p{};
+  for (int i = 0; i < n; ++i) {
+    RG_REQUIRE(h, src[i] && dst[i], "null pointer");
+    p.a[i] = src[i]; p.out[i] = dst[i];
+  }
+  hipLaunchKernelGGL(copy_rows_group_kernel, dim3(grid_for((int64_t)groups * nrows_per * dim), n), dim3(256), 0,
+                     rg_stream(stream), p, groups, nrows_per, dim, rows_src_per, src_row0, rows_dst_per, dst_row0);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_mha_bf16_grouped(rg_handle* h, int n, const float* const* q, int ldq, const float* const* k, int ldk,
+                                   const float* const* v, int ldv, void* const* o, int ldo, int out_is_bf16, int B, int H, int Sq,
+                                   int Sk, int hd, void* stream) {
+  RG_REQUIRE(h, n >= 1 && n <= 4 && q && k && v && o, "1..4 problems");
+  RG_REQUIRE(h, B > 0 && H > 0 && Sq > 0 && Sk > 0 && (Sk <= MH_MAX_SK || (Sk <= MH_BIG_SK && hd == 64)),
+             "bad shape (Sk <= 192, or Sk <= 512 at head dim 64)");
+  RG_REQUIRE(h, hd == 128 || hd == 64 || hd == 32 || hd == 16, "head dim must be 16, 32, 64 or 128");
+  RG_REQUIRE(h, ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "row strides must be multiples of 4 floats");
+  mha_group g{};
+  for (int i = 0; i < n; ++i) {
+    RG_REQUIRE(h, q[i] && k[i] && v[i] && o[i], "null pointer");
+    g.q[i] = q[i]; g.k[i] = k[i]; g.v[i] = v[i]; g.o[i] = reinterpret_cast<float*>(o[i]);
+  }
+  hipStream_t s = rg_stream(stream);
+  if (hd == 128) launch_mha_mfma_group<128, 128>(g, n, ldq, ldk, ldv, ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else if (hd == 64 && Sk > MH_MAX_SK) launch_mha_mfma_group<64, 64, MH_BIG_SK>(g, n, ldq, ldk, ldv, ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else if (hd == 64) launch_mha_mfma_group<64, 64>(g, n, ldq, ldk, ldv, ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else if (hd == 32) launch_mha_mfma_group<32, 32>(g, n, ldq, ldk, ldv, ldo, B, H, Sq, Sk, out_is_bf16, s);
+  else launch_mha_mfma_group<32, 16>(g, n, ldq, ldk, ldv, ldo, B, H, Sq, Sk, out_is_bf16, s);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

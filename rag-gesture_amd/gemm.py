@@ -125,7 +125,10 @@ def make_desc(*, M, N, K, W, out, A=None, segs=None, seg_len=None, bias=None, tb
     return d
 
 
-def launch(h, desc, stream=None):
+def launch(h, desc, stream=None, keep=None):
+    if h.recorder is not None and stream is None:
+        h.recorder.add(("gemm", desc, keep))      # (keep: the tensors the descriptor points into)
+        return
     s = torch.cuda.current_stream().cuda_stream if stream is None else stream
     rc = h.lib.rg_gemm(h._h, ctypes.byref(desc), ctypes.c_void_p(s))
     if rc != 0:
@@ -133,7 +136,7 @@ def launch(h, desc, stream=None):
 
 
 def gemm(h, stream=None, **kw):
-    launch(h, make_desc(**kw), stream)
+    launch(h, make_desc(**kw), stream, keep=kw)
 
 
 def stylize(h, segs, seg_len, M, out, stream=None, m_cond=None, unc_nseg=0, unc_tab=None, qmask=None, groups=None):

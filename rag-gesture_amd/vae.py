@@ -155,6 +155,12 @@ class TransformerVAE:
     def _mha(self, q, ldq, k, ldk, v, ldv, o, B, heads, Sq, Sk):
         import ctypes
         hd = self.D // heads
+        if self.h.recorder is not None:
+            fast = self._mha_fast(hd, Sk, ldq, ldk, ldv)
+            capi.require(fast or o.dtype == torch.float32, "unsupported argument: requires o.dtype == torch.float32")
+            tail = (self.D, 1 if o.dtype == torch.bfloat16 else 0, B, heads, Sq, Sk, hd) if fast else (self.D, B, heads, Sq, Sk, hd)
+            self.h.recorder.add(("mha", fast, (q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, o.data_ptr()) + tail, (q, k, v, o)))
+            return
         s = torch.cuda.current_stream().cuda_stream
         vp = ctypes.c_void_p
         # bf16 path: attention on the matrix cores; fp32 ("bf16x3") path: the exact fp32 VALU kernel
@@ -267,9 +273,11 @@ class GestureRepEncoder:
     """diffusion_transformer.py:131-330: four VAEs, 6D rotation packing, separator tokens."""
 
     def __init__(self, state, vae_cfgs, device="cuda", precision="bf16", prefix="gesture_rep_encoder.", part_streams=True,
-                 chain=True):
+                 chain=True, grouped=True):
         """part_streams: run the four body-part VAEs as concurrent launch chains (False: one chain); chain: see
-        TransformerVAE."""
+        TransformerVAE; grouped: where the parts run as ONE chain (asynchronous submission), layer i of all four parts goes out
+        as one grouped launch (capi.OpRecorder): a quarter of the dependent launches, same bits."""
+        self.grouped = bool(grouped)
         self.dev = torch.device(device)
         self.h = capi.get_handle(self.dev.index if self.dev.index is not None else torch.cuda.current_device())
         self.vaes = {}
@@ -296,6 +304,17 @@ class GestureRepEncoder:
         """Run the per-part jobs (callables) concurrently: job i on part stream i, all ordered after the work already
         queued on the current stream, which in turn waits for all of them.  Tensors that cross the fork or the join
         are allocated on the current stream by the caller; everything a job allocates stays on its stream."""
+        if self.part_streams is None and self.grouped and len(jobs) <= 4:
+            # record the parts' launch sequences, then issue them zipped: layer i of all four parts in one launch
+            rec = self.h.recorder = capi.OpRecorder()
+            try:
+                for job in jobs:
+                    rec.begin_job()
+                    job()
+            finally:
+                self.h.recorder = None
+            rec.issue(self.h)
+            return
         if self.part_streams is None:
             for job in jobs:
                 job()
