@@ -106,3 +106,76 @@ def test_lmdb_cache_reader_with_stub_modules(rg, tmp_path, monkeypatch):
     # an empty cache (fresh checkout) is "not readable": the caller rebuilds from the dataset, like the reference
     stores[str(tmp_path / "idx_2_sense")] = {}
     assert rg.retrieval.read_lmdb_dicts(str(tmp_path)) is None
+
+
+def test_op_recorder_zips_identical_jobs_into_grouped_launches(rg):
+    """capi.OpRecorder (the four body-part VAEs as grouped launches): jobs with the same launch sequence go out position by
+    position, uniform positions as ONE grouped call with per-job pointer arrays, anything else one by one in job order;
+    jobs of different lengths are not zipped at all.  (Host logic only: a fake handle records what would be launched.)"""
+    import ctypes
+    import types
+
+    class FakeLib:
+        def __init__(self, log):
+            self.log = log
+
+        def rg_gemm(self, h, d, s):
+            self.log.append(("gemm", d._obj.M))
+            return 0
+
+        def rg_gemm_grouped(self, h, descs, n, s):
+            self.log.append(("gemm_grouped", n, [descs[i].M for i in range(n)]))
+            return 0
+
+        def rg_last_error(self, h):
+            return b""
+
+    class FakeHandle:
+        def __init__(self):
+            self.log, self._h, self.recorder = [], None, None
+            self.lib = FakeLib(self.log)
+
+        def call(self, name, *args, stream=None):
+            if self.recorder is not None and stream is None:
+                return self.recorder.add(("call", name, args))
+            self.log.append((name,) + tuple(list(a) if isinstance(a, ctypes.Array) else a for a in args))
+
+    torch_stream = types.SimpleNamespace(cuda_stream=0)
+    import torch
+    real = torch.cuda.current_stream
+    torch.cuda.current_stream = lambda *a, **k: torch_stream
+    try:
+        h = FakeHandle()
+        G = rg.gemm.GemmDesc
+        def job(rec, j, extra=False):
+            rec.begin_job()
+            d = G(); d.M = 100 + j
+            rec.add(("gemm", d, None))
+            rec.add(("call", "layernorm", (1000 + j, 2000 + j, 3000 + j, 4000 + j, 64, 512, None)))
+            rec.add(("call", "copy_cols" if j != 2 else "add_rows", (1, 2, 3, 4, 5)))          # position 2 is not uniform
+            rec.add(("call", "add_rows", (10 + j, 20 + j, 30 + j, 4096, 4096 if not extra or j else 2048)))
+        rec = rg.capi.OpRecorder()
+        for j in range(4):
+            job(rec, j)
+        rec.issue(h)
+        assert h.log[0] == ("gemm_grouped", 4, [100, 101, 102, 103])
+        assert h.log[1] == ("layernorm_grouped", 4, [1000, 1001, 1002, 1003], [2000, 2001, 2002, 2003], [3000, 3001, 3002, 3003],
+                            [4000, 4001, 4002, 4003], 64, 512, [None] * 4)
+        assert [e[0] for e in h.log[2:6]] == ["copy_cols", "copy_cols", "add_rows", "copy_cols"]      # singles, in job order
+        assert h.log[6] == ("add_rows_grouped", 4, [10, 11, 12, 13], [20, 21, 22, 23], [30, 31, 32, 33], 4096, 4096)
+        assert len(h.log) == 7 and rec.jobs == []
+        # a shared (non-pointer) argument that differs between the jobs: not grouped
+        h.log.clear()
+        for j in range(4):
+            job(rec, j, extra=True)
+        rec.issue(h)
+        assert [e[0] for e in h.log[-4:]] == ["add_rows"] * 4
+        # jobs of different lengths: job by job
+        h.log.clear()
+        job(rec, 0)
+        job(rec, 1)
+        rec.add(("call", "vae_reparam", (1, 2)))
+        rec.issue(h)
+        assert [e[0] for e in h.log] == ["gemm", "layernorm", "copy_cols", "add_rows", "gemm", "layernorm", "copy_cols", "add_rows", "vae_reparam"]
+    finally:
+        torch.cuda.current_stream = real
