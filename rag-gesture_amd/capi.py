@@ -3,7 +3,9 @@
 The product path has no CPU or PyTorch fallback: if librg_gesture.so is missing or fails
 to load, or no GPU is present, every op raises.
 """
+import contextlib
 import ctypes
+import gc
 import os
 import re
 
@@ -144,6 +146,21 @@ class Handle:
             raise RgError("rg_%s: %s" % (name, e))
         if rc != 0:
             raise RgError("rg_%s failed (%d): %s" % (name, rc, self.lib.rg_last_error(self._h).decode()))
+
+
+@contextlib.contextmanager
+def capture(graph):
+    """torch.cuda.graph(graph) with Python's cyclic garbage collector off: a collection that starts in the middle of a
+    capture can finalise objects that own device resources (graphs, events, streams of an earlier model), and a HIP call
+    from a finaliser aborts a capturing process.  torch's context collects once before the capture begins."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class OpRecorder:

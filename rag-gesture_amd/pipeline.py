@@ -401,7 +401,7 @@ class MotionDiffusion(torch.nn.Module):
                 if v is not None:
                     static[k].copy_(v)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with capi.capture(graph):
                 outs = fn(static)
             ent = self._graphs[key] = (graph, static, outs)
         graph, static, outs = ent

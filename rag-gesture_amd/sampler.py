@@ -113,7 +113,7 @@ class GraphedLoop:
                 fn()
             torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capi.capture(self.graph):
             fn()
 
     def replay(self):
