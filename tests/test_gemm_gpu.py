@@ -197,3 +197,68 @@ def test_bf16_A_kernel_variants_epilogue_features(rg, h, waves, path, M, N, K):
     o = out.cpu().view(M, N // 128, 128)
     assert (st.cpu()[..., 0] - o.sum(-1)).abs().max() <= 4e-3 * scale
     assert (st.cpu()[..., 1] - (o * o).sum(-1)).abs().max() <= 4e-2 * scale * scale
+
+
+@pytest.mark.parametrize("M,N,K,bf16_a", [(5760, 1536, 512, True), (192, 512, 512, True), (2400, 1024, 512, False), (576, 512, 1024, True)])
+def test_grouped_launch_equals_single_launches(rg, h, M, N, K, bf16_a):
+    """rg_gemm_grouped / rg_layernorm_grouped / rg_add_rows_grouped / rg_copy_rows_grouped / rg_mha_bf16_grouped: four
+    problems of one shape in one launch (the four body-part VAEs) must give the bits of four single launches; descriptors
+    of different shapes fall back to single launches inside the call."""
+    import ctypes
+    G = rg.gemm
+    dev = "cuda"
+    ws = [G.pack_weight(_rand((N, K), 20 + i, 0.05), dev) for i in range(4)]
+    a = [_rand((M, K), 30 + i).to(dev) for i in range(4)]
+    b = [_rand((N,), 40 + i).to(dev) for i in range(4)]
+    res = [_rand((M, N), 50 + i).to(dev) for i in range(4)]
+
+    def desc(i, out):
+        kw = dict(M=M, N=N, K=K, W=ws[i], out=out, bias=b[i], residual=res[i], act=1 if i % 2 else 0)
+        if bf16_a:
+            kw["A"] = a[i].bfloat16()
+        else:
+            kw.update(segs=[G.Seg(a[i])], seg_len=K)
+        return G.make_desc(**kw), kw
+
+    single = [torch.empty(M, N, device=dev) for _ in range(4)]
+    keep = []
+    for i in range(4):
+        d, kw = desc(i, single[i])
+        keep.append(kw)
+        G.launch(h, d)
+    grouped = [torch.zeros(M, N, device=dev) for _ in range(4)]
+    ds = [desc(i, grouped[i]) for i in range(4)]
+    arr = (G.GemmDesc * 4)(*[d for d, _ in ds])
+    s = torch.cuda.current_stream().cuda_stream
+    assert h.lib.rg_gemm_grouped(h._h, arr, 4, ctypes.c_void_p(s)) == 0
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(single[i], grouped[i]), i
+    # a group whose members differ in shape is launched one by one (same results)
+    d_small, kw_small = G.make_desc(M=64, N=N, K=K, W=ws[0], out=(o_small := torch.zeros(64, N, device=dev)),
+                                    **({"A": a[0][:64].bfloat16().contiguous()} if bf16_a else {"segs": [G.Seg(a[0][:64].contiguous())], "seg_len": K})), None
+    grouped2 = torch.zeros(M, N, device=dev)
+    d1, kw1 = desc(1, grouped2)
+    arr2 = (G.GemmDesc * 2)(d_small, d1)
+    assert h.lib.rg_gemm_grouped(h._h, arr2, 2, ctypes.c_void_p(s)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(grouped2, single[1]) and o_small.abs().sum().item() > 0
+
+    # row-wise grouped ops
+    vp = lambda ts: (ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+    D = 512
+    x = [_rand((M, D), 60 + i).to(dev) for i in range(4)]
+    g_, b_ = [_rand((D,), 70 + i).to(dev) for i in range(4)], [_rand((D,), 80 + i).to(dev) for i in range(4)]
+    o1, o16a = [torch.empty(M, D, device=dev) for _ in range(4)], [torch.empty(M, D, device=dev, dtype=torch.bfloat16) for _ in range(4)]
+    o2, o16b = [torch.empty(M, D, device=dev) for _ in range(4)], [torch.empty(M, D, device=dev, dtype=torch.bfloat16) for _ in range(4)]
+    for i in range(4):
+        h.call("layernorm", x[i], g_[i], b_[i], o1[i], M, D, o16a[i])
+    h.call("layernorm_grouped", 4, vp(x), vp(g_), vp(b_), vp(o2), M, D, vp(o16b))
+    pos = [_rand((64, D), 90 + i).to(dev) for i in range(4)]
+    s1, s2 = [torch.empty(M, D, device=dev) for _ in range(4)], [torch.empty(M, D, device=dev) for _ in range(4)]
+    for i in range(4):
+        h.call("add_rows", x[i], pos[i], s1[i], M * D, 64 * D)
+    h.call("add_rows_grouped", 4, vp(x), vp(pos), vp(s2), M * D, 64 * D)
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(o1[i], o2[i]) and torch.equal(o16a[i], o16b[i]) and torch.equal(s1[i], s2[i]), i
