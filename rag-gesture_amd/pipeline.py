@@ -251,6 +251,36 @@ class AsyncResults(dict):
         if k not in self._PLAIN:
             self._ready()
         return dict.pop(self, k, *default)
+    def popitem(self):
+        self._ready()
+        return dict.popitem(self)
+
+    def setdefault(self, k, default=None):
+        if k not in self._PLAIN:
+            self._ready()
+        return dict.setdefault(self, k, default)
+
+    # dict(out), {**out}, f(**out) and other.update(out) copy a dict SUBCLASS entry by entry in C, without calling any
+    # of the methods above, as long as the subclass inherits dict's own __iter__: overriding it sends them through
+    # keys() + __getitem__ (CPython dict_merge), i.e. through the wait.
+    def __iter__(self):
+        self._ready()
+        return dict.__iter__(self)
+
+    def copy(self):
+        """A plain dict of finished tensors (the wait is issued on the current stream)."""
+        self._ready()
+        return dict(dict.items(self))
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        self._ready()
+        return {k: copy.deepcopy(v, memo) for k, v in dict.items(self) if k not in self._PLAIN}
+
+    def __reduce__(self):
+        self._ready()
+        return (dict, (), None, None, iter([(k, v) for k, v in dict.items(self) if k not in self._PLAIN]))
 
 
 @register_module
@@ -273,6 +303,9 @@ class MotionDiffusion(torch.nn.Module):
                         front of / behind it.  Batches alternate between `slots` sets of sessions and graph buffers so that
                         a front end never writes what the chain in flight still reads; at most `max_inflight` batches
                         are queued before forward() blocks on the oldest.
+      lane_streams      the caller's own streams for the lanes / the search / the base lanes (max(lanes, base_lanes) + 1 of them)
+      calibrate_lanes   pick streams that were measured to run concurrently (distinct hardware queues) first; performance only:
+                        the NUMBER of lanes and the presence of the search stream never depend on a measurement
       session_options   keyword arguments of denoiser.DenoiserSession (engine, ln_mode, ...)
       vae_options       keyword arguments of vae.GestureRepEncoder (part_streams, chain)"""
 
@@ -280,7 +313,8 @@ class MotionDiffusion(torch.nn.Module):
                  diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
-                 vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=3, **kwargs):
+                 vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=3,
+                 lane_streams=None, calibrate_lanes=False, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -298,6 +332,8 @@ class MotionDiffusion(torch.nn.Module):
         self._sessions = {}
         self._graphs = {}
         self.use_graphs = True  # capture the fixed launch sequences (loops, VAEs) into HIP graphs
+        self.graph_captures = self.graph_cross_stream_waits = 0     # counters (tests, bench line)
+        self._jitter = None     # test hook: callable(stream, tag) run before a graph use / a tail is queued on `stream`
         self.profile_phases, self.phase_ms = False, {}
         self.lanes = int(lanes)
         # submit() of batches WITHOUT exemplar inversion (base diffusion: 2 B sequences per launch, 64 at B = 32) lets whole
@@ -315,6 +351,8 @@ class MotionDiffusion(torch.nn.Module):
         capi.require(self.cobatch_lanes in ("batch", "split"),
                 "unsupported argument: requires self.cobatch_lanes in (\"batch\", \"split\")")
         self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
+        self._given_streams = None if lane_streams is None else list(lane_streams)
+        self.calibrate_lanes, self.lane_report = bool(calibrate_lanes), None
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state, strict=True):
@@ -375,41 +413,56 @@ class MotionDiffusion(torch.nn.Module):
         """Run fn(static_inputs) -> outputs through a cached HIP graph: `inputs` (dict of device
         tensors or None) are copied into static buffers, the captured launch sequence is replayed
         and clones of the outputs are returned.  Falls back to eager launches if use_graphs is off.
-        owner: key of the session whose buffers the graph is bound to (evicted together)."""
-        self._used_on(torch.cuda.current_stream(), *inputs.values())
+        owner: key of the session whose buffers the graph is bound to (evicted together).
+
+        A graph owns ONE set of static inputs, intermediates and outputs, so its uses must not overlap: each use
+        (copy-in, replay, clone-out) ends with an event, and a use on another stream than the previous one waits for it
+        first.  Uses on the same stream are ordered by the stream.  (Keys that name a lane and a slot are only ever
+        replayed on that lane's stream; the chain is what makes every other key -- VAE encode / decode -- safe whatever
+        stream the caller or the tail of a batch happens to run on.)"""
+        cur = torch.cuda.current_stream()
+        self._used_on(cur, *inputs.values())
         if not self.use_graphs:
             return fn(inputs)
         ent = self._graphs.pop(key, None)
         if ent is not None:
             self._graphs[key] = ent                               # most recently used goes last
         if ent is None:
+            torch.cuda.synchronize()  # capture from a quiet device; an evicted graph must not be in flight when it dies
             while len(self._graphs) >= self.MAX_GRAPHS:
                 old = next(iter(self._graphs))
                 del self._graphs[old]
                 self._graph_owner.pop(old, None)
             if owner is not None:
                 self._graph_owner[key] = owner
-            torch.cuda.synchronize()  # other lanes may have work in flight: capture from a quiet device
             static = {k: (None if v is None else torch.empty(v.shape, dtype=v.dtype, device=v.device).copy_(v))
                       for k, v in inputs.items()}
             side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(cur)
             with torch.cuda.stream(side):  # warm-up outside capture (lazy module loads, allocator)
                 fn(static)
-            torch.cuda.current_stream().wait_stream(side)
+            cur.wait_stream(side)
             for k, v in inputs.items():
                 if v is not None:
                     static[k].copy_(v)
             graph = torch.cuda.CUDAGraph()
             with capi.capture(graph):
                 outs = fn(static)
-            ent = self._graphs[key] = (graph, static, outs)
-        graph, static, outs = ent
+            ent = self._graphs[key] = (graph, static, outs, [None, None])
+            self.graph_captures += 1
+        graph, static, outs, last = ent
+        if last[0] is not None and last[1] != cur.cuda_stream:
+            cur.wait_event(last[0])                               # the previous use ran on another stream
+            self.graph_cross_stream_waits += 1
+        if self._jitter is not None:
+            self._jitter(cur, key)
         for k, v in inputs.items():
             if v is not None:
                 static[k].copy_(v)
         graph.replay()
-        return tuple(o.clone() for o in outs)
+        res = tuple(o.clone() for o in outs)
+        last[0], last[1] = cur.record_event(), cur.cuda_stream
+        return res
 
     @staticmethod
     def wait_results(results, stream=None):
@@ -485,10 +538,11 @@ class MotionDiffusion(torch.nn.Module):
         return sess
 
     def _concurrent_streams(self, n):
-        """n HIP streams that really run concurrently.  ROCm multiplexes streams onto a few hardware queues
-        (4 by default) and two streams on the same queue serialise -- observed for the first two side streams of
-        a process, which made `lanes` a pure loss.  Candidates are therefore checked pairwise with a short spin
-        kernel on each (concurrent: ~1x the spin time, same queue: ~2x) and a mutually concurrent set is kept."""
+        """Up to n HIP streams that were MEASURED to run concurrently (calibrate_lanes=True only; a performance
+        refinement, never a correctness condition).  ROCm multiplexes streams onto a few hardware queues and two
+        streams on the same queue serialise -- observed for the first two side streams of a process.  Candidates are
+        checked pairwise with a short spin kernel on each (concurrent: ~1x the spin time, same queue: ~2x) and a mutually
+        concurrent set is kept; the caller pads it to the count it needs."""
         spin = 2_000_000  # cycles (~1 ms): long against launch latency, short against anything else
 
         def together(a, b):
@@ -518,22 +572,41 @@ class MotionDiffusion(torch.nn.Module):
                 break
             if all(min(together(c, o) for _ in range(2)) < 1.5 * base for o in fixed + chosen):
                 chosen.append(c)
-        return chosen  # fewer than n if the runtime offers fewer independent queues
+        rest = [c for c in cands if all(c is not o for o in chosen)]
+        return chosen, rest
+
+    def _make_streams(self):
+        """The stream topology: `lanes` lane streams, one search stream, then the additional lanes of the base workload --
+        max(lanes, base_lanes) + 1 streams, ALWAYS that many, whatever the machine, the load on the host or the number of
+        ranks starting at once (the schedule a test pins is the schedule every box runs).  Sources, in order: the
+        `lane_streams=` constructor argument (the caller's own streams); `calibrate_lanes=True`: streams measured to be
+        concurrent first, unmeasured ones to make up the count; otherwise fresh streams."""
+        lanes = max(1, int(self.lanes))
+        need = max(lanes, self.base_lanes) + 1
+        report = dict(lanes=lanes, base_lanes=self.base_lanes, streams=need, source="fresh", measured_concurrent=None)
+        if self._given_streams is not None:
+            found = list(self._given_streams)
+            capi.require(len(found) >= need, "lane_streams: %d streams needed (max(lanes, base_lanes) + 1 for the search), got %d"
+                         % (need, len(found)))
+            report["source"] = "caller"
+        elif self.calibrate_lanes:
+            chosen, rest = self._concurrent_streams(need)
+            found = (chosen + rest)[:need]
+            report.update(source="calibrated", measured_concurrent=len(chosen))
+        else:
+            found = [torch.cuda.Stream(device=self.device) for _ in range(need)]
+        found = found[:need]
+        self._search_stream = found[lanes]
+        self._lane_streams = found[:lanes] + found[lanes + 1:]
+        self._lanes_calibrated = (lanes, self.base_lanes)
+        self.lane_report = report
 
     def _lane_plan(self, B, n_lanes=None):
         """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips (n_lanes of them, default self.lanes)."""
         lanes = max(1, int(self.lanes))
+        if self._lanes_calibrated != (lanes, self.base_lanes):
+            self._make_streams()
         want = max(lanes, self.base_lanes if self.async_results else 1)
-        if self._lanes_calibrated != (lanes, want):
-            # lane streams + one more for the retrieval search, all on hardware queues of their own (the runtime has
-            # GPU_MAX_HW_QUEUES of them: the first `lanes` streams found are the lanes, the next one searches, what is left
-            # serves as additional lanes of the base workload)
-            found = self._concurrent_streams(want + 1)
-            self._search_stream = found[lanes] if len(found) > lanes else None
-            self._lane_streams = found[:lanes] + found[lanes + 1:]
-            if not self._lane_streams:
-                self._lane_streams = [torch.cuda.Stream(device=self.device)]
-            self._lanes_calibrated = (lanes, want)
         n = max(1, min(lanes if n_lanes is None else int(n_lanes), want, B, len(self._lane_streams)))
         cuts = [(B * i) // n for i in range(n + 1)]
         return [(i, self._lane_streams[i], cuts[i], cuts[i + 1]) for i in range(n)]
@@ -605,7 +678,11 @@ class MotionDiffusion(torch.nn.Module):
                 plan = self._lane_plan(B, self.base_lanes)   # nothing to share launches with: more, smaller chains
             pid = cob["lane"] % len(plan)
             plan = plan_s = [(pid, plan[pid][1], 0, B)]
-        self._slot = self._take_slot(pid, main) if run_async else 0
+        if run_async:
+            self._slot = self._take_slot(pid, main, self._lanes_of(plan, plan_s))
+        else:
+            self._slot = 0
+            self._wait_slot(main, self._lanes_of(plan, plan_s), 0)   # (asynchronous batches of an earlier mode still in flight)
         gre.concurrent_parts(not run_async)   # one launch chain per VAE graph when graphs are queued behind a running batch
         word, audio, spk = kwargs["word"], kwargs["audio"], kwargs["speaker_ids"]
         with self._phase("conditions"):
@@ -740,7 +817,8 @@ class MotionDiffusion(torch.nn.Module):
             word=word, audio=audio, spk=spk, motion_mask=motion_mask, qmask=qmask, early_cond=early_cond,
             use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot, pid=pid, seq=self._submitted,
             prev_future=prev_future if in_seq is not None else None, latent_ready=None)
-        self._last_state = st
+        # what a later batch's pending prev_latent needs of this one (not the whole state: invl alone is 140 MB at B = 32)
+        st.handle = self._last_state = types.SimpleNamespace(B=B, x_out=st.x_out, latent_ready=None)
         if cob is not None:
             # the conditions of this batch's clips are projected in the NEXT call (into the sessions it shares with that
             # batch's exemplars): private copies, the caller may reuse its input buffers meanwhile
@@ -777,13 +855,22 @@ class MotionDiffusion(torch.nn.Module):
             for idx in st.idx_groups:
                 h.call("copy_rows", lat.contiguous(), st.in_seq, st.B, 1, st.D, st.T, idx[-1], st.T, idx[0])
 
-    def _take_slot(self, pid, main):
-        """Next set of sessions / graph buffers of pipeline `pid`; the caller's stream waits for the chain that used it last."""
+    def _take_slot(self, pid, main, lanes):
+        """Next set of sessions / graph buffers of pipeline `pid`; the caller's stream waits for the chains that last used
+        it on any of `lanes` (sessions and graphs are keyed by (lane, slot) whatever pipeline drove them)."""
         slot = self._slots[pid] = (self._slots.get(pid, 0) + 1) % self.slots
-        for ev in self._slot_done.get((pid, slot), ()):
-            main.wait_event(ev)
+        self._wait_slot(main, lanes, slot)
         self._slot = slot
         return slot
+
+    def _wait_slot(self, main, lanes, slot):
+        for lane in dict.fromkeys(lanes):
+            for ev in self._slot_done.get((lane, slot), ()):
+                main.wait_event(ev)
+
+    @staticmethod
+    def _lanes_of(*plans):
+        return list(dict.fromkeys(lane for plan in plans for lane, _, _, _ in plan))
 
     # ------------------------------------------------------------------ co-batched pipeline
     def submit(self, **kwargs):
@@ -815,7 +902,7 @@ class MotionDiffusion(torch.nn.Module):
     def _finish_alone(self, st):
         """Sampling loop + tail of a batch whose exemplars are already inverted and spliced."""
         main = st.main = torch.cuda.current_stream()
-        st.slot = self._take_slot(st.pid, main)
+        st.slot = self._take_slot(st.pid, main, self._lanes_of(st.plan_s))
         for lane, stream, b0, b1 in st.plan_s:
             self._set_conditions(b1 - b0, "sample", lane, st.word[b0:b1], st.audio[b0:b1], st.spk[b0:b1],
                                  st.motion_mask[b0:b1], {c: st.qmask[b0:b1] for c in denoiser.CONDS})
@@ -845,7 +932,9 @@ class MotionDiffusion(torch.nn.Module):
         pend, S, T, D, dev = self._pend.get(st.pid), st.S, st.T, st.D, self.device
         lanes = [(lane, stream, b0, b1, self._exemplars(st, b0, b1)) for lane, stream, b0, b1 in st.plan] if st.use_inversion else []
         so = self.session_options
-        groups_ok = self.precision == "bf16" and (so.get("engine") != "chain" or (
+        # (the engine a session RESOLVES to: without sequence streams -- L > 8, ff_size != 1024, T > 48 -- it is the chain)
+        seq = so.get("engine") != "chain" and getattr(self.model.weights, "seq_streams", None) is not None
+        groups_ok = self.precision == "bf16" and (seq or (
             so.get("styl_prepass", True) and not so.get("styl_in_gemm") and not so.get("sa_fused")))
         can_defer = (groups_ok and st.use_inversion and not st.visualize_inversion and not st.ddpm and st.plan == st.plan_s
                      and all(ex for *_, ex in lanes))
@@ -868,7 +957,8 @@ class MotionDiffusion(torch.nn.Module):
             return None
         if pend is None:                               # the pipeline fills: inversion alone
             self._inversion_pass(st)
-            self._slot_done[(st.pid, st.slot)] = [stream.record_event() for _, stream, _, _ in st.plan]   # (no tail marks it)
+            for lane, stream, _, _ in st.plan:                                     # (no tail marks it)
+                self._slot_done[(lane, st.slot)] = [stream.record_event()]
             self._pend[st.pid] = st
             return None
         main = st.main
@@ -1019,18 +1109,21 @@ class MotionDiffusion(torch.nn.Module):
         submission (where that one is already queueing the next batch), on the first sampling lane's stream."""
         gre, results, main, S, T, D, B = self.model.gesture_rep_encoder, st.results, st.main, st.S, st.T, st.D, st.B
         # (asynchronous: the lanes take turns, so that the decode does not always delay the same lane's next chain)
-        tail = st.plan_s[self._tail_turn % len(st.plan_s)][1] if st.run_async else main
+        tail_lane, tail = st.plan_s[self._tail_turn % len(st.plan_s)][:2] if st.run_async else (-1, main)
         self._tail_turn += 1
+        if self._jitter is not None:
+            self._jitter(tail, "tail")
         for _, stream, _, _ in st.plan + st.plan_s:
             if stream is not tail:
                 tail.wait_stream(stream)
-        st.latent_ready = tail.record_event()      # (a later batch's pending prev_latent waits for this, not for the decode)
+        st.latent_ready = st.handle.latent_ready = tail.record_event()   # (a later batch's pending prev_latent waits for this, not for the decode)
         self._used_on(tail, st.x_out, *st.vis_inv, *st.vis_pairs)
         with torch.cuda.stream(tail):
             output = self.model.post_process(st.x_out)
             results["prev_latentout"] = output
             with self._phase("vae_decode"):
-                up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B, gre.part_streams is None), dict(z=output), lambda s: gre.decode(s["z"]))
+                up, lo, fa, ha, tr, ex_, co = self._graph_run(("dec", B, gre.part_streams is None, tail_lane), dict(z=output),
+                                                                lambda s: gre.decode(s["z"]))
             results["pred_upper"], results["pred_lower"], results["pred_facepose"] = up, lo, fa
             results["pred_hands"], results["pred_transl"], results["pred_exps"] = ha, tr, ex_
             results["pred_contact"] = co
@@ -1059,7 +1152,8 @@ class MotionDiffusion(torch.nn.Module):
             # caller's / search / lane streams shares its queue, and with it the next batch's front end)
             results["done_event"], results["done_stream"] = done, tail
             results = AsyncResults(results)      # the first read of an entry waits for the batch on the reader's stream
-            self._slot_done[(st.pid, st.slot)] = [done]
+            for lane in self._lanes_of(st.plan, st.plan_s):
+                self._slot_done[(lane, st.slot)] = [done]
             self._inflight.append(done)
             while len(self._inflight) > (self.max_inflight if st.use_inversion else max(self.max_inflight, self.base_lanes)):
                 self._inflight.popleft().synchronize()

@@ -16,6 +16,44 @@ def rg():
     return importlib.import_module("rag-gesture_amd")
 
 
+def _where(model):
+    """The schedule a comparison ran under (part of every failure message: a mismatch must be sizeable from the log)."""
+    return dict(lane_streams=len(model._lane_streams), search_stream=model._search_stream is not None,
+                topology=model.lane_report, graphs=len(model._graphs), cross_stream_waits=model.graph_cross_stream_waits,
+                use_graphs=model.use_graphs)
+
+
+def _same(got, want, model, tag):
+    """Bit identity of two result lists (dicts of tensors or lists of numpy arrays), reporting the first mismatch in full."""
+    import numpy as np
+    assert len(got) == len(want), (tag, len(got), len(want))
+    for i, (a, b) in enumerate(zip(got, want)):
+        items = [(k, a[k], b[k]) for k in b] if isinstance(b, dict) else [(j, x, y) for j, (x, y) in enumerate(zip(a, b))]
+        for k, x, y in items:
+            x, y = (t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t) for t in (x, y))
+            assert x.shape == y.shape, (tag, i, k, x.shape, y.shape)
+            if not np.array_equal(x, y):
+                d = np.abs(x.astype(np.float64) - y.astype(np.float64))
+                raise AssertionError("%s: batch %d key %s differs: max abs %.3e, %d of %d elements, first at %s; schedule %s"
+                                     % (tag, i, k, np.nanmax(d), int((x != y).sum()), x.size,
+                                        np.argwhere(x != y)[0].tolist(), _where(model)))
+
+
+class Jitter:
+    """Random device-side delays (torch.cuda._sleep, 0-3 ms) in front of every graph use and every tail: moves the lanes
+    against each other so that a missing ordering between streams shows up as a bit mismatch instead of once a week."""
+
+    def __init__(self, seed, max_cycles=6_000_000):
+        import random
+        self.rng, self.max_cycles, self.calls = random.Random(seed), max_cycles, 0
+
+    def __call__(self, stream, tag):
+        self.calls += 1
+        if self.rng.random() < 0.5:
+            with torch.cuda.stream(stream):
+                torch.cuda._sleep(self.rng.randrange(1, self.max_cycles))
+
+
 def _batches(rg, B, n, dev):
     out = []
     for i in range(n):
@@ -72,9 +110,7 @@ def test_async_pipeline_equals_synchronous_forwards(rg, guided):
             junk = [torch.full((B, 43, 512), float(i), device=dev) for _ in range(8)]   # reuse freed blocks on the caller's stream
             del junk
     torch.cuda.synchronize()
-    for i in range(N):
-        for k in KEYS:
-            assert torch.equal(got[i][k], ref[i][k]), (i, k, (got[i][k] - ref[i][k]).abs().max().item())
+    _same(got, ref, model, "async forward()")
     # synchronous mode again: no event, tensors valid on the caller's stream
     model.async_results = False
     out = run(0)
@@ -130,11 +166,7 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
             with torch.cuda.stream(out["done_stream"]):
                 got.append({k: out[k].clone() for k in KEYS})
         torch.cuda.synchronize()
-        assert len(got) == len(batches)
-        for i in range(len(batches)):
-            for k in KEYS:
-                assert got[i][k].shape == ref[i][k].shape, (i, k)
-                assert torch.equal(got[i][k], ref[i][k]), (rep, i, kinds[i], k, (got[i][k] - ref[i][k]).abs().max().item())
+        _same(got, ref, model, "submit()/flush() mode %s pass %d kinds %s" % (mode, rep, kinds))
     assert model.flush() == []
     # the pipeline is an asynchronous-mode feature
     model.async_results = False
@@ -187,8 +219,7 @@ def test_unchanged_tool_loop_and_three_line_pipelined_loop(rg):
             output = model(**args(i))
         assert isinstance(output, rg.pipeline.AsyncResults)
         got.append(_tool_body(rg, output))
-    for a, b in zip(got, want):
-        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    _same(got, want, model, "unchanged loop on async_results=True")
     got = []
     for i in range(len(batches)):           # (ii) three changed lines
         with torch.no_grad():
@@ -197,9 +228,9 @@ def test_unchanged_tool_loop_and_three_line_pipelined_loop(rg):
             continue
         got.append(_tool_body(rg, output))
     got += [_tool_body(rg, output) for output in model.flush()]
-    assert len(got) == len(want)
-    for a, b in zip(got, want):
-        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    _same(got, want, model, "submit()/flush() loop")
+    # the schedule is fixed by the constructor arguments alone: two lanes + search + the third base lane
+    assert (len(model._lane_streams), model._search_stream is not None) == (3, True), _where(model)
 
 
 def test_base_batches_alternate_between_base_lanes(rg):
@@ -234,6 +265,54 @@ def test_base_batches_alternate_between_base_lanes(rg):
     torch.cuda.synchronize()
     lanes_used = sorted(p for p in model._slots if p is not None)
     assert lanes_used == list(range(min(model.base_lanes, len(model._lane_streams)))), lanes_used
-    for i in range(len(batches)):
-        for k in KEYS:
-            assert torch.equal(got[i][k], ref[i][k]), (i, k)
+    _same(got, ref, model, "base lanes")
+
+
+@pytest.mark.parametrize("use_graphs,calibrate", [(True, False), (True, True), (False, False)])
+def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate):
+    """The regression test of the round-3 race (two tails on two lanes shared ONE decode graph): guided batches through
+    submit() / flush() without any host synchronisation between them -- so tails, chains and front ends of neighbouring
+    batches really overlap -- with random delays injected on every stream, repeatedly; then base batches over three lanes.
+    Every pass must reproduce the synchronous forwards bit for bit.  Also with graphs off (eager launches: bisects graph
+    buffers against everything else) and with the measured stream choice."""
+    dev = torch.device("cuda", 0)
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    db = rg.synth.SyntheticDataset(512, seed=11, device=dev, feat_device=dev)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=db, device=dev,
+                                  calibrate_lanes=calibrate)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+    model.use_graphs = use_graphs
+    batches = _batches(rg, 4, 6, dev)
+    guided = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+
+    def args(i, flags):
+        d = dict(batches[i])
+        d["trans"] = batches[i]["trans"].clone()
+        return dict(d, retrieval_method="discourse", inference_kwargs=dict(flags, noise_tape=rg.synth.NoiseTape(4500 + i)))
+
+    want = {}
+    for name, flags in (("guided", guided), ("base", {})):
+        want[name] = []
+        for i in range(len(batches)):
+            out = model(**args(i, flags))
+            torch.cuda.synchronize()
+            want[name].append({k: out[k].clone() for k in KEYS})
+    model.async_results = True
+    for rep in range(6 if use_graphs else 2):
+        model._jitter = Jitter(100 + rep)
+        for name, flags in (("guided", guided), ("base", {})):
+            outs = []
+            for i in range(len(batches)):
+                out = model.submit(**args(i, flags))
+                if out is not None:
+                    outs.append(out)                 # NOT read here: nothing makes the host or the caller's stream wait
+            outs += model.flush()
+            got = [{k: o[k].clone() for k in KEYS} for o in outs]
+            torch.cuda.synchronize()
+            _same(got, want[name], model, "jitter pass %d %s" % (rep, name))
+        assert model._jitter.calls > 0
+    assert model.lane_report["streams"] == 4 and len(model._lane_streams) == 3 and model._search_stream is not None
+    if use_graphs:
+        assert any(k[0] == "dec" and k[-1] != -1 for k in model._graphs), "decode graphs are per tail lane"

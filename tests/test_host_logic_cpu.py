@@ -179,3 +179,57 @@ def test_op_recorder_zips_identical_jobs_into_grouped_launches(rg):
         assert [e[0] for e in h.log] == ["gemm", "layernorm", "copy_cols", "add_rows", "gemm", "layernorm", "copy_cols", "add_rows", "vae_reparam"]
     finally:
         torch.cuda.current_stream = real
+
+
+def test_async_results_wait_before_every_way_of_handing_tensors_out(rg, monkeypatch):
+    """pipeline.AsyncResults promises code written against the reference's synchronous results (tools/visualize.py:201-260)
+    finished tensors: the wait (`_ready`) must be issued by every idiom that copies entries out, including the ones CPython
+    implements in C for dict subclasses (dict(out), {**out}, f(**out), other.update(out), out.copy(), copy.copy(out))."""
+    import copy
+    import pickle
+    AR = rg.pipeline.AsyncResults
+    calls = []
+    monkeypatch.setattr(AR, "_ready", lambda self: calls.append(1))
+    out = AR(pred_upper=1, pred_lower=2, done_event="ev", done_stream="st")
+    idioms = {
+        "getitem": lambda: out["pred_upper"], "get": lambda: out.get("pred_upper"), "values": lambda: list(out.values()),
+        "items": lambda: list(out.items()), "iter": lambda: list(out), "dict()": lambda: dict(out), "{**}": lambda: {**out},
+        "f(**)": lambda: (lambda **kw: kw)(**out), "update": lambda: {}.update(out), "copy": lambda: out.copy(),
+        "copy.copy": lambda: copy.copy(out), "deepcopy": lambda: copy.deepcopy(out), "pickle": lambda: pickle.dumps(out),
+        "setdefault": lambda: out.setdefault("pred_upper", 0),
+    }
+    for name, f in idioms.items():
+        del calls[:]
+        f()
+        assert calls, "%s hands tensors out without waiting for the batch" % name
+    # bookkeeping entries and membership tests need no wait
+    del calls[:]
+    assert out["done_event"] == "ev" and out.get("done_stream") == "st" and "pred_upper" in out and len(out) == 4
+    assert not calls
+    assert type(out.copy()) is dict and type(copy.copy(out)) is dict
+    del calls[:]
+    assert out.pop("pred_lower") == 2 and calls
+
+
+def test_slot_bookkeeping_is_per_lane(rg):
+    """Sessions and graphs are keyed by (lane, slot): the events a new batch waits for must be found under the same key
+    whichever pipeline (split batches: lanes 0..n-1 under one pipeline id; whole batches per lane: one id per lane) left them."""
+    MD = rg.pipeline.MotionDiffusion
+    plan = [(0, "s0", 0, 2), (1, "s1", 2, 4)]
+    assert MD._lanes_of(plan, plan) == [0, 1] and MD._lanes_of([(1, "s1", 0, 4)]) == [1]
+
+    class _Main:
+        def __init__(self):
+            self.waited = []
+
+        def wait_event(self, ev):
+            self.waited.append(ev)
+
+    m = MD.__new__(MD)
+    m.slots, m._slots, m._slot_done, m._slot = 2, {}, {(0, 1): ["a"], (1, 1): ["b"], (0, 0): ["c"]}, 0
+    main = _Main()
+    assert m._take_slot(None, main, [0, 1]) == 1 and main.waited == ["a", "b"]
+    main = _Main()
+    assert m._take_slot(0, main, [0]) == 1 and main.waited == ["a"]      # pipeline 0 meets what pipeline None left on lane 0
+    main = _Main()
+    assert m._take_slot(0, main, [0]) == 0 and main.waited == ["c"]
