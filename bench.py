@@ -82,6 +82,7 @@ def launch_ranks(n, argv, dry=False):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("GPU_MAX_HW_QUEUES", "8")     # read by the HIP runtime at its first call: in place before the rank starts
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE, stderr=None if r == 0 else subprocess.PIPE, text=True))
     rc, outs = 0, []
@@ -106,6 +107,10 @@ class Workload:
         import collections
         self.rg, self.kind, self.B, self.dev, self.precision = rg, kind, B, dev, precision
         self._submitted, self._latency = collections.deque(), []
+        # every random draw of a batch comes from this generator, inside submit(): the state in front of a submission is all
+        # it takes to repeat that batch later (verify(): the last timed batches against synchronous forwards)
+        self.noise = rg.pipeline.DeviceNoise(dev, seed=4242 + rank)
+        self._done = collections.deque(maxlen=2)
         self.cfg = rg.synth.default_model_cfg(num_layers=8)
         self.vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
         self.guided = kind in ("guided", "longform")
@@ -118,6 +123,7 @@ class Workload:
         self.model.load_state_dict(rg.synth.synth_full_state(0, self.cfg, self.vae_cfgs))
         self.model.eval()
         self.model.async_results = bool(pipelined)     # (long-form: run_many then pipelines the windows through submit())
+        self.model.calibrate_lanes = True              # which streams, never how many: performance only (pipeline._make_streams)
         # guided workload: the sampling loop of batch n shares its denoiser launches with the inversion of batch n + 1
         # base workload: nothing to co-batch, but submit() lets whole batches alternate between model.base_lanes lanes
         self.cobatch = self.model.async_results and kind in ("guided", "base") and cobatch and precision == "bf16"
@@ -153,18 +159,71 @@ class Workload:
             def features(ci, cidx, t0, t1, ann):     # the per-window callback of longform_synthesis.py:320-343
                 text = " ".join(seg[1] for seg in ann["text_segments"][0])
                 return dict(audio=self.audio[cidx], raw_word=[text], text_features=[self.feats[ci][cidx]])
-            self.last = self.synth.run_many([dict(c, trans=c["trans"].clone()) for c in self.clips], features, use_inversion=True,
-                                            insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1, retrieval_method="llm",
-                                            shard=False)
+            self._features = features
+            self._done.append((self.noise.state(), None))
+            self.last = self._longform_pass()
             return None
         d = dict(self.data)
         d["trans"] = self.trans0.clone()  # forward re-zeroes trans in place like the reference
         ev = torch.cuda.Event(enable_timing=True)      # submission time of this batch (per-batch latency, see pack())
         ev.record()
-        self._submitted.append(ev)
-        ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1) if self.kind == "guided" else {}
+        self._submitted.append((ev, self.noise.state()))
         call = self.model.submit if self.cobatch else self.model
-        return self.pack(call(**dict(d, retrieval_method="discourse", inference_kwargs=ikw)))
+        return self.pack(call(**dict(d, retrieval_method="discourse", inference_kwargs=self._ikw())))
+
+    def _ikw(self):
+        ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1) if self.kind == "guided" else {}
+        return dict(ikw, noise_tape=self.noise)
+
+    def _longform_pass(self, **kw):
+        return self.synth.run_many([dict(c, trans=c["trans"].clone()) for c in self.clips], self._features, use_inversion=True,
+                                   insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1, retrieval_method="llm",
+                                   shard=False, noise_tape=self.noise, **kw)
+
+    @staticmethod
+    def _cat(out):
+        return torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
+                          out["pred_transl"], out["pred_exps"]], dim=-1)
+
+    def verify(self):
+        """OUTSIDE the timed region: the last batches the timed loop produced (two: one per batch lane) against ONE
+        SYNCHRONOUS forward each of the same inputs and the same noise (the generator state saved in front of their
+        submission) -- `torch.equal`, bit for bit.  What is timed is therefore a throughput of verified results: a race
+        between lanes, a stale graph buffer or a mis-ordered hand-out shows up here (every batch has its own noise, so no
+        two batches have equal results).  Long-form: the last pass against the sequential window loop."""
+        import numpy as np
+        torch.cuda.synchronize()
+        recs = list(self._done)
+        self.drain()
+        torch.cuda.synchronize()
+        model = self.model
+        mode, keep = (self.cobatch, model.async_results), self.noise.state()
+        self.cobatch, model.async_results = False, False
+        res = {"verified": bool(recs), "batches": len(recs), "against": "synchronous forward, same inputs and noise (torch.equal)"}
+        try:
+            for n, (state, got) in enumerate(recs):
+                self.noise.set_state(state)
+                if self.kind == "longform":
+                    ref, got = self._longform_pass(pipelined=False), self.last
+                    pairs = [("clip %d %s" % (c, k), np.asarray(ref[c][k]), np.asarray(got[c][k])) for c in sorted(ref)
+                             for k in ("poses", "expressions", "trans")]
+                    res["against"] = "sequential window loop (pipelined=False), same inputs and noise (array_equal)"
+                else:
+                    d = dict(self.data)
+                    d["trans"] = self.trans0.clone()
+                    ref = self._cat(model(**dict(d, retrieval_method="discourse", inference_kwargs=self._ikw())))
+                    torch.cuda.synchronize()
+                    pairs = [("packed", ref.cpu().numpy(), got.cpu().numpy())]
+                for name, a, b in pairs:
+                    if a.shape != b.shape or not np.array_equal(a, b):
+                        res["verified"] = False
+                        res.setdefault("first_mismatch", {"batch_from_end": len(recs) - 1 - n, "key": name,
+                                                          "max_abs": float(np.nanmax(np.abs(a - b))) if a.shape == b.shape else None,
+                                                          "elements": int((a != b).sum()) if a.shape == b.shape else None})
+        finally:
+            (self.cobatch, model.async_results) = mode
+            self.noise.set_state(keep)
+        return res
 
     def pack(self, out):
         """The packed [B,150,268] result of a finished (or, with asynchronous submission, queued) batch; None while the
@@ -174,12 +233,13 @@ class Workload:
         # asynchronous submission (model.async_results): the batch is only queued; its packed result is assembled on
         # the stream the batch ends on, so the caller's stream is free for the next batch's front end
         with torch.cuda.stream(out.get("done_stream") or torch.cuda.current_stream()):
-            packed = torch.cat([out["pred_upper"], out["pred_lower"], out["pred_facepose"], out["pred_hands"],
-                                out["pred_transl"], out["pred_exps"]], dim=-1)
+            packed = self._cat(out)
             done = torch.cuda.Event(enable_timing=True)
             done.record()
         if self._submitted:     # results come back in submission order: device time from a batch's submission to its packed result
-            self._latency.append((self._submitted.popleft(), done))
+            ev, state = self._submitted.popleft()
+            self._latency.append((ev, done))
+            self._done.append((state, packed))
         return packed
 
     def latency_ms(self):
@@ -413,9 +473,12 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or unset WORLD_SIZE "
                          "to let bench.py start the ranks itself)" % (args.gpus, world, args.gpus))
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # (torchrun-started ranks: still before torch is imported)
     if args.dry_launch:
         print(json.dumps(dict(rank=rank, local_rank=local_rank, world=world, master_addr=os.environ.get("MASTER_ADDR"),
-                              master_port=os.environ.get("MASTER_PORT"), pid=os.getpid())))
+                              master_port=os.environ.get("MASTER_PORT"), pid=os.getpid(),
+                              hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"), torch_imported="torch" in sys.modules,
+                              ipc_legacy=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))))
         return
     global torch
     import torch
@@ -457,6 +520,14 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * wl.frames_per_step * args.steps / dt
     lat_med, lat_max = wl.latency_ms()
+    # ---- what was timed is checked (outside the clock): the last batches of the timed loop against synchronous forwards
+    verified = wl.verify()
+    all_ok = verified["verified"]
+    if dist is not None:
+        t = torch.tensor([1.0 if all_ok else 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        all_ok = bool(t.item() == 1.0)
+        verified = dict(verified, all_ranks=all_ok)
 
     if args.phases and rank == 0 and kind != "longform":
         # phase walls need device syncs at phase boundaries, which serialise concurrent lanes: the breakdown is taken
@@ -530,6 +601,7 @@ def main():
                 d = w.timed(steps, warmup, torch.cuda.synchronize)
                 r = {"value": round(w.frames_per_step * steps / d, 1), "unit": "frames/s", "ms_per_step": round(d / steps * 1e3, 2),
                      "steps": steps, "warmup": warmup, "dtype": "bf16" if w.precision == "bf16" else "bf16x3 (fp32-equivalent)"}
+                r["verified"] = w.verify()
                 if w.kind != "longform" and roof:
                     r["roofline"] = w.gemm_roofline(local_rank)
                 return r
@@ -611,11 +683,18 @@ def main():
                                        "the decode of batch n run beside the inversion -> sampling chain; every batch completes "
                                        "inside the timed region" % wl.model.slots)) if wl.model.async_results
                        else "synchronous forwards"},
+            "verified": all_ok, "verification": verified,
+            "stream_topology": wl.model.lane_report,
             "roofline": roofline, "roofline_retrieval": roof_retr, "also": also or None, "cpu_baseline": cpu,
         }
+        all_ok = all_ok and all(v.get("verified", {}).get("verified", True) for v in (also or {}).values())
+        line["verified"] = all_ok
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+    if not all_ok:
+        sys.stderr.write("bench.py: a timed batch does not equal its synchronous forward -- the figure above is not a result\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -130,6 +130,24 @@ class _TorchNoise:
         return torch.randn(*shape, device=self.device, generator=self.generator)
 
 
+class DeviceNoise(_TorchNoise):
+    """`inference_kwargs["noise_tape"]` drawing on the device from a generator of its own: a run can be repeated with the
+    same noise (`state()` before the call, `set_state()` before the repetition) without host-side noise tensors --
+    every draw of a batch is made inside forward() / submit(), in one fixed order, whichever schedule then executes it.
+    bench.py verifies the batches it times this way."""
+
+    def __init__(self, device, seed=0):
+        g = torch.Generator(device=device)
+        g.manual_seed(int(seed))
+        super().__init__(torch.device(device), g)
+
+    def state(self):
+        return self.generator.get_state()
+
+    def set_state(self, state):
+        self.generator.set_state(state)
+
+
 @register_module
 class ReGestureTransformer:
     """Configuration holder mirroring raggesture.py:887-922 / diffusion_transformer.py:335-420

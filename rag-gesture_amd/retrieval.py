@@ -797,7 +797,8 @@ class RetrievalDatabase:
                 eps = [[noise.draw((L, 1, D)) for _ in range(4)] for _ in range(E)]
                 eps_list = [torch.cat([e[p].to(dev) for e in eps], dim=0) for p in range(4)]
             else:
-                eps_list = [torch.randn(E * L, 1, D, device=dev) for _ in range(4)]  # generator noise: order is immaterial
+                draw = noise.draw if noise is not None else (lambda shape: torch.randn(*shape, device=dev))
+                eps_list = [draw((E * L, 1, D)) for _ in range(4)]  # generator noise: order is immaterial
             fork = torch.cuda.Event()     # work started by on_exemplars orders itself after this point, not after the encode
             fork.record()
             # batch of Ep = E rounded up to a multiple of 4 (padding = copies of exemplar 0 with zero noise, dropped below):

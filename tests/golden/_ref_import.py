@@ -16,6 +16,10 @@ import os
 import sys
 import types
 
+# /root/reference is read-only by contract: from the moment this harness is imported no import writes a __pycache__
+# (set here, at import time, so that it precedes the first reference import whatever script drives the harness)
+sys.dont_write_bytecode = True
+
 REF_ROOT = os.environ.get("RG_REFERENCE_ROOT", "/root/reference")
 
 

@@ -8,6 +8,7 @@ stores outputs).  Also checks the oracle restatement against the reference befor
 import contextlib
 import os
 import sys
+sys.dont_write_bytecode = True   # /root/reference is read-only: no __pycache__ there
 import tempfile
 
 import numpy as np

@@ -7,6 +7,7 @@ import json
 import os
 import random
 import sys
+sys.dont_write_bytecode = True   # /root/reference is read-only: no __pycache__ there
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))

@@ -82,6 +82,19 @@ def test_bench_launcher_starts_one_process_per_gpu():
     assert [x["rank"] for x in ranks] == [0, 1, 2] and [x["local_rank"] for x in ranks] == [0, 1, 2]
     assert all(x["world"] == 3 and x["master_addr"] == "127.0.0.1" for x in ranks)
     assert len({x["master_port"] for x in ranks}) == 1 and len({x["pid"] for x in ranks}) == 3
+    # the 8-GPU node of BASELINE config 4: eight ranks, each on its own device, each with the hardware-queue setting in its
+    # environment BEFORE torch is imported (the HIP runtime reads it once, at its first call), dmabuf IPC for RCCL
+    env8 = {k: v for k, v in env.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-launch"], env=env8,
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    ranks = json.loads(r.stdout.strip().splitlines()[-1])
+    assert sorted(x["local_rank"] for x in ranks) == list(range(8)) and len({x["pid"] for x in ranks}) == 8
+    assert all(x["hw_queues"] == "8" and x["torch_imported"] is False and x["ipc_legacy"] == "0" for x in ranks), ranks
+    # a value the user has set wins
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                       env=dict(env8, GPU_MAX_HW_QUEUES="6"), capture_output=True, text=True, timeout=120)
+    assert [x["hw_queues"] for x in json.loads(r.stdout.strip().splitlines()[-1])] == ["6", "6"]
     # under an external launcher the flag and the environment must agree
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-launch"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)

@@ -39,7 +39,12 @@ def test_bf16_A_gelu_bf16_out(rg, h):
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     G.gemm(h, M=M, N=N, K=K, W=G.pack_weight(w, "cuda"), out=out, A=a.cuda().bfloat16(), bias=b.cuda(), act=1)
     ref = F.gelu(F.linear(bf(a), bf(w), b))
-    assert (out.float().cpu() - ref).abs().max() <= 2e-2
+    got = out.float().cpu()
+    d = (got - ref).abs()
+    m, n = divmod(int(d.argmax()), N)
+    # a bf16 result: half an ulp of the largest magnitude this seed produces (7.3 -> ulp 2^-5) plus the fp32 accumulation slack
+    assert d.max() <= 2 ** -6 + 1e-3, "max abs %.4e at (%d, %d): got %.6f, fp32 reference %.6f; %d elements beyond the bound" % (
+        d.max(), m, n, got[m, n], ref[m, n], int((d > 2 ** -6 + 1e-3).sum()))
 
 
 def test_ragged_vae_shapes(rg, h):
