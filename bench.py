@@ -193,7 +193,7 @@ class Workload:
         two batches have equal results).  Long-form: the last pass against the sequential window loop."""
         import numpy as np
         torch.cuda.synchronize()
-        recs = list(self._done)
+        recs = list(self._done)[-1:] if self.kind == "longform" else list(self._done)   # (long-form keeps its last pass only)
         self.drain()
         torch.cuda.synchronize()
         model = self.model

@@ -161,3 +161,91 @@ def test_config5_one_clip_three_windows_l8_vs_oracle(rg, tmp_path, parity):
     parity.check("config 5 (llm, L8, bf16): 30-fps poses vs oracle loop (rotation matrices)", rel(ma, orot.axis_angle_to_matrix(want_m.reshape(-1, 3))), 3e-2)
     parity.check("config 5 (llm, L8, bf16): expressions", rel(torch.from_numpy(got["expressions"]), want_f), 3e-2)
     parity.check("config 5 (llm, L8, bf16): trans", rel(torch.from_numpy(got["trans"]), want_t), 3e-2)
+
+
+def test_config5_two_clips_run_many_pipelined_l8_vs_oracle(rg, tmp_path, parity):
+    """The batched, PIPELINED long-form driver (longform.run_many: window k of all clips in one forward, submitted through
+    submit() / flush() with the previous window's latent still pending -- pipeline.PendingLatent) at full depth against
+    the oracle's per-clip loop of tools/longform_synthesis.py:256-403: two clips of different lengths (3 and 2 windows:
+    the batch SHRINKS at window 2, the pending latent is row-selected, longform_synthesis.py:389-403), the flags of BASELINE
+    config 5 (llm retrieval on cached answers, inversion + insertion guidance + prev-latent).  Per clip: retrieval results
+    exact per window, every window's latent and the blended 30-fps outputs within the bf16 bars."""
+    from oracle import diffusion as odf, fuzzy as ofz, packing as opk, pipeline as opipe, rotation as orot
+    GI = [0] * 25 + list(range(25))
+    cfg = rg.synth.default_model_cfg(num_layers=8)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    ds = rg.synth.SyntheticDataset(300, seed=31)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds, precision="bf16",
+                                  async_results=True)
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    model.load_state_dict(P)
+    model.eval()
+    rdb = model.model.database
+    cache = rg.retrieval.LLMResponseCache(str(tmp_path / "llm_cache.json"), call=rg.synth.synth_llm_answer)
+    rdb.llm_output = cache.get
+    n_windows, seeds = [3, 2], [40, 140]
+    clips = [rg.synth.synth_longform_clip(s, windows=w) for s, w in zip(seeds, n_windows)]
+    feats = {(ci, w): rg.synth.synth_query(200 + 10 * ci + w) for ci in range(2) for w in range(3)}
+    audio = {(ci, w): rg.synth.synth_batch(1, seed=100 + 10 * ci + w)["audio"] for ci in range(2) for w in range(3)}
+    seen = {}
+
+    def features(ci, cidx, t0, t1, ann):
+        text = " ".join(s[1] for s in ann["text_segments"][0])
+        seen[(ci, cidx)] = dict(text=text, ann=ann)
+        return dict(audio=audio[(ci, cidx)], raw_word=[text], text_features=[feats[(ci, cidx)]["text_features"]])
+
+    synth = rg.longform.LongformSynthesizer(model, overlap=15)
+    flags = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+    copy = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    got = synth.run_many([copy(c) for c in clips], features, retrieval_method="llm", noise_tape=rg.synth.ClipTapes([5, 6]), **flags)
+    torch.cuda.synchronize()
+    assert any(k[0] == "cobatch" for k in model._graphs), "the pipelined run should have gone through co-batched chains"
+    assert not model._pend and not model._ready
+    assert [len(got[c]["windows"]) for c in range(2)] == n_windows
+
+    # ---- the oracle: each clip on its own, window after window (same per-clip noise tape, same cached answers)
+    odb = oret.build_db_dicts(ds.retrieval_samples)
+    sim = lambda a, b: ofz.partial_ratio(a, b) / 100
+    sch = odf.SpacedSchedule()
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    rel = lambda x, y: ((x - y).norm() / y.norm()).item()
+    n_ex = 0
+    for ci, clip in enumerate(clips):
+        otape = rg.synth.NoiseTape(5 + ci)
+        sample_len = clip["motion"].shape[1]
+        starts, ends, rem = opk.window_bounds(sample_len)
+        od = rg.longform.pad_tail(copy(clip), rem)
+        spk = int(clip["speaker_ids"][0, 0])
+        prev, so_far = None, None
+        for cidx, (c0, c1) in enumerate(zip(starts, ends)):
+            chunk = {k: od[k][:, c0:c1] for k in od if torch.is_tensor(od[k])}
+            chunk["audio"] = audio[(ci, cidx)]
+            ann, name = seen[(ci, cidx)]["ann"], "9_longform_%d_0/%d" % (seeds[ci], cidx)
+            f = feats[(ci, cidx)]["text_features"]
+            want = oret.llm_retrieval(seen[(ci, cidx)]["text"], ann["text_segments"][0], spk, ann["prominence"][0],
+                                      odb["idx_2_gesture_labels"], odb["idx_2_gestprom"], f, odb["idx_2_text"], sim, cache.get)
+            assert rdb.test_indexes[name]["llm"] == want[0], "clip %d window %d: llm retrieval differs from the oracle" % (ci, cidx)
+            assert rdb.test_dbounds[name]["llm"] == want[1] and rdb.test_qbounds[name]["llm"] == want[2]
+            n_ex += len(want[0])
+            cond = dict(text_features=[f], speaker_ids=chunk["speaker_ids"])
+            with torch.no_grad():
+                o = opipe.motion_diffusion_forward(
+                    P, cfg, vae_cfgs, sch, chunk, otape, use_prev_latent=True, prev_latent=prev,
+                    re_dict=lambda tp: oret.database_forward(P, vae_cfgs, odb, ds, cond, [name], tp, retrieval_method="llm",
+                                                             retrieve=lambda b: want), **flags)
+            lat = got[ci]["latents"][cidx].cpu()
+            parity.check("config 5 run_many pipelined (llm, L8, bf16) clip %d window %d: final latent vs oracle" % (ci, cidx),
+                         ((lat - o["prev_latentout"])[:, KEEP].norm() / o["prev_latentout"][:, KEEP].norm()).item(), 1.5e-2)
+            prev = o["prev_latentout"]
+            cur = (opk.scatter_parts(o["pred_upper"], o["pred_lower"], o["pred_hands"], o["pred_facepose"]), o["pred_exps"], o["pred_transl"])
+            so_far = cur if cidx == 0 else opk.blend_window(*so_far, *cur, 15)
+        n_out = 2 * sample_len
+        want_m = opk.interp_motion(so_far[0], 2)[0, :n_out]
+        want_f, want_t = opk.interp_features(so_far[1], 2)[0, :n_out], opk.interp_features(so_far[2], 2)[0, :n_out]
+        assert got[ci]["poses"].shape == (n_out, 165)
+        ma = orot.axis_angle_to_matrix(torch.from_numpy(got[ci]["poses"]).reshape(-1, 3))
+        parity.check("config 5 run_many pipelined clip %d: 30-fps poses vs oracle loop (rotation matrices)" % ci,
+                     rel(ma, orot.axis_angle_to_matrix(want_m.reshape(-1, 3))), 3e-2)
+        parity.check("config 5 run_many pipelined clip %d: expressions" % ci, rel(torch.from_numpy(got[ci]["expressions"]), want_f), 3e-2)
+        parity.check("config 5 run_many pipelined clip %d: trans" % ci, rel(torch.from_numpy(got[ci]["trans"]), want_t), 3e-2)
+    assert n_ex >= 3, "the windows should retrieve exemplars"

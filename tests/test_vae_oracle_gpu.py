@@ -1,0 +1,108 @@
+"""GPU: the four body-part VAEs AT FULL DEPTH against the CPU oracle (oracle/vae.py, pinned on the reference's goldens in
+test_oracle_golden.py), through every launch path the product uses:
+
+  * part streams  -- four concurrent launch chains (synchronous forwards),
+  * grouped       -- one chain, layer i of all four parts as ONE grouped launch (capi.OpRecorder: rg_gemm_grouped,
+                     rg_layernorm_grouped, rg_mha_bf16_grouped, ...; the asynchronous pipeline),
+  * single chain  -- one chain, launches one by one,
+  * fused         -- the block-fused kernels (rg_vblk), where the shape supports them,
+
+at the sizes of BASELINE config 3: 16 clips (encode + decode) and 48 exemplars (encode), 8 layers, both decoder
+architectures (gesture_vae.py:124-239, detr_utils.py:101-210).  Until this file the grouped launches were only compared
+with the ungrouped HIP path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("upper", "lower", "face", "hands", "transl", "exps", "contact")
+ROT = ("upper", "lower", "face", "hands")
+
+
+def relerr(a, b):
+    return ((a - b).norm() / b.norm()).item()
+
+
+def rot_relerr(a, b):
+    from oracle import rotation as orot
+    ma, mb = orot.axis_angle_to_matrix(a.reshape(-1, 3)), orot.axis_angle_to_matrix(b.reshape(-1, 3))
+    return ((ma - mb).norm() / mb.norm()).item()
+
+
+def _state(rg, vae_cfgs):
+    P = {}
+    for i, part in enumerate(rg.synth.PARTS):
+        P.update(rg.synth.synth_vae_state(101 + i, vae_cfgs[part], prefix="gesture_rep_encoder.%s_vae." % part))
+    return P
+
+
+PATHS = {"part_streams": dict(part_streams=True), "grouped": dict(part_streams=False, grouped=True),
+         "single_chain": dict(part_streams=False, grouped=False)}
+
+
+@pytest.fixture(scope="module")
+def oracle_results(rg):
+    """The oracle's answers, once per architecture (CPU, fp32): encode of 16 clips and of 48 exemplars, decode of 16."""
+    from oracle import vae as ovae
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    out = {}
+    for arch in ("all_encoder", "encoder_decoder"):
+        vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch=arch)           # 8 layers, 512 wide, FF 1024
+        P = _state(rg, vae_cfgs)
+        res = dict(vae_cfgs=vae_cfgs, P=P, enc={}, eps={}, data={})
+        with torch.no_grad():
+            data = rg.synth.synth_batch(48, seed=7748)
+            tape = rg.synth.NoiseTape(648)
+            eps = [tape.draw((48 * 10, 1, 512)) for _ in range(4)]
+            d = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+            lat, mask = ovae.gesture_encode(P, vae_cfgs, d, eps)          # one oracle pass: clips never interact,
+            for B in (16, 48):                                            # the first 16 clips ARE the B = 16 case
+                res["enc"][B] = (lat[:B], mask[:B], d["trans"][:B])
+                res["eps"][B] = [e[:B * 10] for e in eps]
+                res["data"][B] = {k: (v[:B] if torch.is_tensor(v) else v) for k, v in data.items()}
+            g = np.random.Generator(np.random.PCG64(99))
+            z = torch.from_numpy(g.standard_normal((16, 43, 512)).astype(np.float32))
+            z[:, [10, 21, 32]] = 0
+            res["z"], res["dec"] = z, ovae.gesture_decode(P, vae_cfgs, z)
+        out[arch] = res
+    return out
+
+
+@pytest.mark.parametrize("path", list(PATHS))
+@pytest.mark.parametrize("arch", ["all_encoder", "encoder_decoder"])
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_full_depth_vaes_against_the_oracle(rg, parity, oracle_results, precision, arch, path):
+    o = oracle_results[arch]
+    gre = rg.vae.GestureRepEncoder(o["P"], o["vae_cfgs"], "cuda", precision, **PATHS[path])
+    tag = "VAE L8 %s %s %s" % (arch, precision, path)
+    for B in (16, 48):
+        data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o["data"][B].items()}
+        lat, mask = gre.encode(data["motion_upper"], data["motion_lower"], data["motion_face"], data["motion_hands"],
+                               data["trans"], data["facial"], data["contact"], data["motion_mask"], o["eps"][B])
+        ref_lat, ref_mask, ref_trans = o["enc"][B]
+        parity.check("%s: encode B=%d latent vs oracle" % (tag, B), relerr(lat.cpu(), ref_lat), 1e-2 if precision == "bf16" else 5e-5)
+        assert torch.equal(mask.cpu(), ref_mask)
+        assert torch.allclose(data["trans"], ref_trans, atol=1e-6)            # the in-place re-zeroing of trans x / z
+        assert lat[:, [10, 21, 32]].abs().max() == 0                           # separator rows
+    dec = gre.decode(o["z"].cuda())
+    for nm, a, r in zip(NAMES, dec, o["dec"]):
+        e = rot_relerr(a.cpu(), r) if nm in ROT else relerr(a.cpu(), r)
+        parity.check("%s: decode B=16 %s vs oracle" % (tag, nm), e, 3e-2 if precision == "bf16" else 2e-4)
+
+
+@pytest.mark.parametrize("arch", ["all_encoder", "encoder_decoder"])
+def test_launch_paths_agree_bit_for_bit(rg, oracle_results, arch):
+    """grouped == single chain == part streams (same kernels on the same rows in another order of issue)."""
+    o = oracle_results[arch]
+    outs = {}
+    for path, kw in PATHS.items():
+        gre = rg.vae.GestureRepEncoder(o["P"], o["vae_cfgs"], "cuda", "bf16", **kw)
+        data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o["data"][16].items()}
+        lat, _ = gre.encode(data["motion_upper"], data["motion_lower"], data["motion_face"], data["motion_hands"],
+                            data["trans"], data["facial"], data["contact"], data["motion_mask"], o["eps"][16])
+        outs[path] = [lat] + list(gre.decode(o["z"].cuda()))
+    torch.cuda.synchronize()
+    for path in ("grouped", "single_chain"):
+        for i, (a, b) in enumerate(zip(outs[path], outs["part_streams"])):
+            assert torch.equal(a, b), (path, i, (a - b).abs().max().item())
