@@ -110,7 +110,7 @@ class Workload:
         # every random draw of a batch comes from this generator, inside submit(): the state in front of a submission is all
         # it takes to repeat that batch later (verify(): the last timed batches against synchronous forwards)
         self.noise = rg.pipeline.DeviceNoise(dev, seed=4242 + rank)
-        self._done = collections.deque(maxlen=2)
+        self._done = collections.deque(maxlen=max(1, int(os.environ.get("RG_BENCH_VERIFY_BATCHES", "2"))))
         self.cfg = rg.synth.default_model_cfg(num_layers=8)
         self.vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
         self.guided = kind in ("guided", "longform")
@@ -217,6 +217,10 @@ class Workload:
                 for name, a, b in pairs:
                     if a.shape != b.shape or not np.array_equal(a, b):
                         res["verified"] = False
+                        res["mismatching"] = res.get("mismatching", 0) + 1
+                        if os.environ.get("RG_BENCH_DUMP_MISMATCH") and a.shape == b.shape:
+                            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                            np.savez_compressed(os.path.join(ROOT, "gpurun_out", "bench_mismatch_%s_%d.npz" % (self.kind, n)), ref=a, got=b)
                         res.setdefault("first_mismatch", {"batch_from_end": len(recs) - 1 - n, "key": name,
                                                           "max_abs": float(np.nanmax(np.abs(a - b))) if a.shape == b.shape else None,
                                                           "elements": int((a != b).sum()) if a.shape == b.shape else None})

@@ -15,8 +15,20 @@ DIAG = os.environ.get("RG_DIAG") == "1"   # diagnostic build with in-kernel phas
 LIB_PATH = os.path.join(PKG_DIR, "librg_gesture_diag.so" if DIAG else "librg_gesture.so")
 OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj_diag" if DIAG else "_obj")
 ARCH = "gfx950"
+# NO_PACKED_FP32: the device code is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 /
+# v_pk_fma_f32, which the compiler forms from pairs of independent fp32 operations on gfx90a and later).
+# Measured on MI355X with ROCm 7.2 (NOTEBOOK section 9, profiles/r04d_packed_fp32_hazard.txt): the HIGH half of a
+# v_pk_add_f32 result, read by the next instructions, was occasionally STALE in lanes 48-63 -- the last of the four 16-lane
+# passes -- when the SIMD was shared with waves of other kernels (other streams): in rg_6d_to_aa one term of a quaternion
+# came out as the partial sum the register held before, i.e. 16 consecutive joints of a decoded pose wrong about once per
+# 10^4 launches.  That was the second source of the round-3 "flaky" bit mismatches (the other one was the shared decode
+# graph): 12-37 mismatching batches per 200 pipelined passes with packed ops, 0 per 200 without (same box, same script:
+# profiles/dbg/hands_flake_probe.py); the GELU epilogue of rg_gemm showed the same signature once in 70 test runs.
+# More wait states behind the producers (s_nop patched into the assembly: behind transcendentals, in front of lane-mask
+# readers) did NOT help; not forming the packed instructions does.  Cost: see NOTEBOOK section 9 (rg_seq launch time).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-mllvm", "-amdgpu-early-inline-all=true"]
+         "-mllvm", "-amdgpu-early-inline-all=true"] + NO_PACKED_FP32 + os.environ.get("RG_EXTRA_FLAGS", "").split()
 
 
 def _hipcc():
@@ -45,8 +57,10 @@ def _compile(src, hdr_mtime, force):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    # (the host pass of hipcc sees the device-only feature switch too and says so: not a problem of this build)
+    err = "\n".join(l for l in r.stderr.splitlines() if "packed-fp32-ops" not in l)
+    if err.strip():
+        sys.stderr.write(err + "\n")
     return obj
 
 

@@ -344,6 +344,8 @@ class GestureRepEncoder:
         return latent, self.latent_mask(motion_mask)
 
     graph_runner = None  # callable(key, inputs, fn) -> outputs; set by MotionDiffusion (HIP-graph cache)
+    debug_poison = False
+    debug_keep = None    # diagnostics only: a list that receives (part, decoder output [B * frames, nfeats]) of every decode
 
     def encode_device_graphed(self, up, lo, fa, ha, tr, fac, con, eps_list):
         """encode_device through the owner's graph cache (one captured launch sequence per batch size)."""
@@ -410,6 +412,10 @@ class GestureRepEncoder:
 
         def job(i, part):
             d = self.vaes[part].decode_latent(z, i * (n_lat + 1), n_lat)
+            if self.debug_keep is not None:      # diagnostics: the decoder output in front of the rotation conversion
+                self.debug_keep.append((part, d))
+                if self.debug_poison and self.h.recorder is not None:
+                    d.fill_(float("nan"))        # runs now, i.e. BEFORE the recorded GEMM that writes d is issued
             if part == "upper":
                 aa(d, upper, self.uj)
             elif part == "hands":

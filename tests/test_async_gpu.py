@@ -34,6 +34,14 @@ def _same(got, want, model, tag):
             assert x.shape == y.shape, (tag, i, k, x.shape, y.shape)
             if not np.array_equal(x, y):
                 d = np.abs(x.astype(np.float64) - y.astype(np.float64))
+                try:       # keep the evidence: where a mismatch sits tells which kernel produced it
+                    import os
+                    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+                    os.makedirs(out, exist_ok=True)
+                    np.savez_compressed(os.path.join(out, "mismatch_%s_b%d_%s.npz" % ("".join(c if c.isalnum() else "_" for c in tag)[:40], i, k)),
+                                        got=x, want=y)
+                except OSError:
+                    pass
                 raise AssertionError("%s: batch %d key %s differs: max abs %.3e, %d of %d elements, first at %s; schedule %s"
                                      % (tag, i, k, np.nanmax(d), int((x != y).sum()), x.size,
                                         np.argwhere(x != y)[0].tolist(), _where(model)))

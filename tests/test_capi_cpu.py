@@ -54,3 +54,24 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(rg, tmp_path):
     assert int(out["size"]) == ctypes.sizeof(G.GemmDesc)
     for f in fields:
         assert int(out[f]) == getattr(G.GemmDesc, f).offset, "field %s: C offset %s, ctypes %d" % (f, out[f], getattr(G.GemmDesc, f).offset)
+
+
+def test_device_code_has_no_packed_fp32_instructions(tmp_path):
+    """The device code is built without v_pk_{add,mul,fma}_f32 (build.NO_PACKED_FP32; NOTEBOOK section 9: on MI355X with ROCm
+    7.2 the high half of a packed-fp32 result was occasionally stale in lanes 48-63 when the SIMD was shared with other
+    kernels' waves -- 16 consecutive joints of a decoded pose wrong about once per 10^4 launches).  Compiles one translation
+    unit with the product's flags and looks at the instructions."""
+    import importlib
+    import os
+    import re
+    import subprocess
+    b = importlib.import_module("rag-gesture_amd.build")
+    assert all(f in b.FLAGS for f in b.NO_PACKED_FP32)
+    src = os.path.join(b.CSRC, "rg_sampler.hip")
+    out = str(tmp_path / "dev.s")
+    r = subprocess.run([b._hipcc()] + b.FLAGS + ["--cuda-device-only", "-S", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    with open(out) as f:
+        asm = f.read()
+    assert "v_fma_f32" in asm or "v_mul_f32" in asm
+    assert not re.search(r"\bv_pk_(?:add|mul|fma)_f32\b", asm)
