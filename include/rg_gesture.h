@@ -348,6 +348,35 @@ typedef struct rg_seq_args {
 
 int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);
 
+/* Sequence-stationary body-part VAE encoder: the whole skip-transformer stack of `TransformerVAE.encode_to_dist`
+ * (mogen/models/transformers/gesture_vae.py:111-193: chunk sequences of frame_chunk_size frames + the two distribution
+ * tokens; mogen/models/utils/detr_utils.py:101-152 SkipTransformerEncoder, :335-393 TransformerEncoderLayer.forward_post with
+ * torch.nn.MultiheadAttention) in ONE launch, one workgroup per two chunk sequences; replaces the per-op launch chain
+ * (rg_gemm / rg_mha_bf16 / rg_layernorm) for the shape it is specialised for: latent_dim 512, 4 heads, ff_size 1024, GELU,
+ * post-norm, S <= 24 tokens, bf16 operands with fp32 accumulation, fp32 residual stream / LayerNorm / softmax.
+ *   x       fp32 [nseq][S][512]   the embedded sequences (skel_embedding + the distribution tokens + positional table)
+ *   out     fp32 [nseq][S][512]   encoder output behind the final LayerNorm (rows 0 / 1 = mu / logvar: rg_vae_reparam)
+ *   wstream bf16 [NU][8 waves][64 fragments][64 lanes][8]   unit GEMMs (512 x 512) in consumption order, per block:
+ *           [skip W[:, :D], skip W[:, D:]] (output blocks only), Q (x 1/sqrt(128)), K, V, out_proj, linear1[:512],
+ *           linear2[:, :512], linear1[512:], linear2[:, 512:];  NU = 8 (2 nb + 1) + 2 nb
+ *   pstream fp32 [NU + 1][8 waves][4][64]   per unit: vector 0 = bias (zero for the second half of a split unit), vectors
+ *           1 / 2 = gamma / beta of the LayerNorm that follows the unit (out_proj: norm1, linear2 first half: norm2);
+ *           slot NU: vectors 0 / 1 = gamma / beta of the encoder's final norm
+ *   xbuf    fp32 [ceil(nseq / 2)][nb][8][12][64][4]   the skip stack (states behind the input blocks)
+ *   nb      input blocks = output blocks ((num_layers - 1) / 2 for odd num_layers, num_layers / 2 for even: detr_utils.py:108)
+ *   dump / dump_block: diagnostics (state behind block dump_block as fp32 [workgroup][48][512]); dump_block < 0: off. */
+typedef struct rg_venc_args {
+  const void* wstream;
+  const void* pstream;
+  const float* x;
+  float* out;
+  float* xbuf;
+  float* dump;
+  int nseq, S, nb, dump_block;
+} rg_venc_args;
+
+int rg_venc_forward(rg_handle* h, const rg_venc_args* args_host, void* stream);
+
 /* ---------------------------------------------------------------- body-part VAEs + rotations
  * Softmax multi-head attention core of torch.nn.MultiheadAttention for short sequences
  * (detr_utils.py:364-366, 427-433): o[b,i,h,:] = softmax_j(q[b,i,h,:].k[b,j,h,:]/sqrt(hd)) v[b,j,h,:].

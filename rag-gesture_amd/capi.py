@@ -130,10 +130,11 @@ class Handle:
         except Exception:
             pass
 
-    def call(self, name, *args, stream=None):
-        """Invoke rg_<name>(handle, *args, stream) and raise on a non-zero status."""
+    def call(self, name, *args, stream=None, keep=None):
+        """Invoke rg_<name>(handle, *args, stream) and raise on a non-zero status.  keep: objects (argument blocks, tensors an
+        argument block points into) that must stay alive until the launch has been issued (recording)."""
         if self.recorder is not None and stream is None:
-            self.recorder.add(("call", name, args))     # (the tensors in args stay alive until the recorder has issued)
+            self.recorder.add(("call", name, args, keep))   # (the tensors in args / keep stay alive until the recorder has issued)
             return
         fn = getattr(self.lib, "rg_" + name)
         s = torch.cuda.current_stream().cuda_stream if stream is None else stream

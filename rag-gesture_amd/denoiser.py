@@ -34,6 +34,8 @@ def _timestep_embedding(timesteps, dim, max_period=10000):
 
 
 class DenoiserWeights:
+    KV_GROUP = 2      # layers per condition K / V projection GEMM (output [rows, KV_GROUP * 2 D] fp32: 260 MB for 64 x 499 audio tokens)
+
     @staticmethod
     def _fold_ln(W, b, gamma, beta, pw, f32):
         """LN(x) W^T + b = rstd (x W'^T - mean c1) + c2 with W' = W diag(gamma), c1 = rowsum(bf16(W')) (what the
@@ -132,6 +134,35 @@ class DenoiserWeights:
             lw["w_ffo"], lw["b_ffo"] = pw(g(p + "ffn.proj_out.out_layers.2.weight")), f32(g(p + "ffn.proj_out.out_layers.2.bias"))
             self.layers.append(lw)
 
+        # --- condition K / V projections of SEVERAL layers as one GEMM per condition (bf16 path): the conditions' LayerNorm
+        # differs between layers only in its affine (efficient_attention.py:74-80: `text_norm`), so the normalised rows
+        # xhat = (xf - mean) * rstd are materialised ONCE as bf16 and every layer's gain / offset is folded into its weights,
+        #   LN_l(xf) W_l^T + b_l = xhat (W_l diag(gamma_l))^T + (b_l + W_l beta_l),
+        # and the [key | value] weights of KV_GROUP consecutive layers are stacked along N: 3 x L / KV_GROUP launches of
+        # N = KV_GROUP x 1024 with a bf16 A operand instead of 3 x L launches of N = 1024 that each convert fp32 A tiles and
+        # redo the LayerNorm in every column tile (NOTEBOOK section 9; was gemm_dma_kernel<false, ...>, 4 % of the step)
+        self.kv_group = None
+        if precision == "bf16":
+            KVG = self.KV_GROUP if L % self.KV_GROUP == 0 else 1
+            self.kv_group = KVG
+            self.w_kv_grp, self.b_kv_grp = [], []      # [group][condition]
+            for g0 in range(0, L, KVG):
+                ws, bs = [], []
+                for ci in range(3):
+                    wl, bl = [], []
+                    for l in range(g0, g0 + KVG):
+                        q = "temporal_decoder_blocks.%d.ca_blocks.%s." % (l, CONDS[ci])
+                        wkv = torch.cat([g(q + "key.weight"), g(q + "value.weight")], 0).double()
+                        bkv = torch.cat([g(q + "key.bias"), g(q + "value.bias")], 0).double()
+                        ga, be = g(q + "text_norm.weight").double(), g(q + "text_norm.bias").double()
+                        wl.append((wkv * ga[None, :]).float())
+                        bl.append((bkv + wkv @ be).float())
+                    ws.append(pw(torch.cat(wl, 0)))
+                    bs.append(f32(torch.cat(bl, 0)))
+                self.w_kv_grp.append(ws)
+                self.b_kv_grp.append(bs)
+            self.ln_ones, self.ln_zeros = torch.ones(D, device=self.dev), torch.zeros(D, device=self.dev)
+
         # --- timestep tables: ss[step][layer][block] = emb_layers(SiLU(time_embed(t_step)))  (fp32, exact)
         S = schedule.num_timesteps
         self.S = S
@@ -215,7 +246,7 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False, xcd_affine=True, engine=None,
-                 styl_in_gemm=False, seq_launches=1):
+                 styl_in_gemm=False, seq_launches=1, kv_grouped=True):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
@@ -234,6 +265,9 @@ class DenoiserSession:
         runs inside those GEMMs, on the landed bf16 A tiles in LDS, instead of as two elementwise launches per layer.
         Parity-green and measured SLOWER (907 vs 887 us per forward at M = 1376): off by default.
         styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain (NOTEBOOK section 6)."""
+        # kv_grouped (bf16): the conditions' K / V projections of DenoiserWeights.KV_GROUP layers per GEMM on a bf16 normalised
+        # operand (set_conditions); False = one fp32-A GEMM with a LayerNorm prologue per layer and condition (round 1-3)
+        self.kv_grouped = bool(kv_grouped)
         if ln_mode not in ("auto", "folded", "prologue"):
             raise capi.RgError("ln_mode must be 'auto', 'folded' or 'prologue'")
         if engine not in (None, "seq", "chain"):
@@ -357,14 +391,29 @@ class DenoiserSession:
         h.call("row_stats", xf, st, B * n_tok, D)
         srcs.append((xf, st, n_tok))
         kv_max = max(s[2] for s in srcs)
-        kv = torch.empty(B * kv_max, 2 * D, device=dev)
-        for l, lw in enumerate(w.layers):
+        if w.kv_group is not None and self.kv_grouped:
+            KVG = w.kv_group
+            ldk = KVG * 2 * D
+            kv = torch.empty(B * kv_max, ldk, device=dev)
+            scratch = torch.empty(B * kv_max, D, device=dev)
             for ci in range(3):
-                xf, st, n_tok = srcs[ci]
-                G.gemm(h, M=B * n_tok, N=2 * D, K=D, W=lw["w_kv"][ci], out=kv,
-                       segs=[G.Seg(xf, mode=G.A_LN, stats=st, gamma=lw["tn_g"][ci], beta=lw["tn_b"][ci])],
-                       seg_len=D, bias=lw["b_kv"][ci], ldo=2 * D)
-                h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci, o0:o1], B, n_tok, D)
+                xf, _, n_tok = srcs[ci]
+                M = B * n_tok
+                xhat = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+                h.call("layernorm", xf, w.ln_ones, w.ln_zeros, scratch, M, D, xhat)      # exact two-pass statistics, no affine
+                for gi in range(w.L // KVG):
+                    G.gemm(h, M=M, N=ldk, K=D, W=w.w_kv_grp[gi][ci], out=kv, A=xhat, bias=w.b_kv_grp[gi][ci], ldo=ldk)
+                    for j in range(KVG):
+                        h.call("kv_reduce", kv.data_ptr() + 4 * j * 2 * D, ldk, self.a_pre[gi * KVG + j, ci, o0:o1], B, n_tok, D)
+        else:
+            kv = torch.empty(B * kv_max, 2 * D, device=dev)
+            for l, lw in enumerate(w.layers):
+                for ci in range(3):
+                    xf, st, n_tok = srcs[ci]
+                    G.gemm(h, M=B * n_tok, N=2 * D, K=D, W=lw["w_kv"][ci], out=kv,
+                           segs=[G.Seg(xf, mode=G.A_LN, stats=st, gamma=lw["tn_g"][ci], beta=lw["tn_b"][ci])],
+                           seg_len=D, bias=lw["b_kv"][ci], ldo=2 * D)
+                    h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci, o0:o1], B, n_tok, D)
         if self.sq is not None:
             self.sq.set_a(self.a_pre[:, :, o0:o1], o0, o1)
         elif self.abf is not None and finalize:

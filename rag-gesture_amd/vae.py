@@ -14,7 +14,7 @@ nothing here is specialised to one width/depth/arch.
 
 import torch
 
-from . import capi, gemm as G
+from . import capi, gemm as G, vencfwd
 
 PARTS = ("upper", "hands", "face", "lowertrans")  # reference encode / RNG order
 ACT = {"relu": 2, "gelu": 1}
@@ -68,9 +68,11 @@ class TransformerVAE:
     decoder_arch, position_embedding, nfeats, num_frames, frame_chunk_size,
     transformer_activation, transformer_normalize_before, vae_dist)."""
 
-    def __init__(self, state, vcfg, device="cuda", precision="bf16", chain=True):
+    def __init__(self, state, vcfg, device="cuda", precision="bf16", chain=True, fused_encoder=True):
         """chain: bf16 path only -- producers hand bf16 copies to the GEMMs that consume them (False: every GEMM converts
-        its fp32 operand tiles itself; a measurement knob)."""
+        its fp32 operand tiles itself; a measurement knob).
+        fused_encoder: run the encoder stack as ONE launch (rg_venc_forward: two chunk sequences per workgroup, activations
+        resident on chip, weights streamed) where the shape supports it (vencfwd.supported); False: the per-op launch chain."""
         capi.require(vcfg.get("vae_dist", "normal") == "normal", "only the Normal posterior is supported")
         self.cfg = vcfg
         self.dev = torch.device(device)
@@ -93,6 +95,9 @@ class TransformerVAE:
                                                  ("query_pos_encoder", "query_pos_decoder", "mem_pos_decoder"))
         self.tok_pe = (f("global_motion_token") + self.pe_enc[:2]).contiguous()  # host-side constant fold
         self.encoder = _Stack(state, "encoder", dev, split, vcfg["num_layers"], cross=False)
+        self.venc = None
+        if fused_encoder and vencfwd.supported(vcfg, precision):
+            self.venc = vencfwd.VencForward(self.h, vencfwd.VencStreams(state, "encoder", vcfg["num_layers"], self.heads, dev))
         if self.arch == "all_encoder":
             self.decoder = _Stack(state, "decoder", dev, split, vcfg["num_layers"], cross=False)
             self.dec_heads = self.heads * 8
@@ -240,7 +245,10 @@ class TransformerVAE:
         xseq = torch.empty(Bn * S, D, device=self.dev)
         self.h.call("copy_rows", self.tok_pe, xseq, Bn, 2, D, 0, 0, S, 0)
         self.h.call("copy_rows", x, xseq, Bn, self.chunk, D, self.chunk, 0, S, 2)
-        enc = self._skip_stack(self.encoder, xseq, lambda blk, t: self._enc_layer(blk, t, Bn, S, self.heads))
+        if self.venc is not None:
+            enc = self.venc.run(xseq, Bn, S)
+        else:
+            enc = self._skip_stack(self.encoder, xseq, lambda blk, t: self._enc_layer(blk, t, Bn, S, self.heads))
         self.h.call("vae_reparam", enc, S, eps.contiguous(), latent, B, n_chunks, D, latent.shape[1], row_off)
 
     def decode_latent(self, latent, row_off, n_chunks):
@@ -273,7 +281,7 @@ class GestureRepEncoder:
     """diffusion_transformer.py:131-330: four VAEs, 6D rotation packing, separator tokens."""
 
     def __init__(self, state, vae_cfgs, device="cuda", precision="bf16", prefix="gesture_rep_encoder.", part_streams=True,
-                 chain=True, grouped=True):
+                 chain=True, grouped=True, fused_encoder=True):
         """part_streams: run the four body-part VAEs as concurrent launch chains (False: one chain); chain: see
         TransformerVAE; grouped: where the parts run as ONE chain (asynchronous submission), layer i of all four parts goes out
         as one grouped launch (capi.OpRecorder): a quarter of the dependent launches, same bits."""
@@ -284,7 +292,7 @@ class GestureRepEncoder:
         for part in PARTS:
             p = "%s%s_vae." % (prefix, part)
             sd = {k[len(p):]: v for k, v in state.items() if k.startswith(p)}
-            self.vaes[part] = TransformerVAE(sd, vae_cfgs[part], device, precision, chain=chain)
+            self.vaes[part] = TransformerVAE(sd, vae_cfgs[part], device, precision, chain=chain, fused_encoder=fused_encoder)
         self.vae_latent_dim = vae_cfgs["upper"]["latent_dim"]
         self.frame_chunk_size = vae_cfgs["upper"]["frame_chunk_size"]
         self.uj = self.lj = self.fj = self.hj = self.tj = None

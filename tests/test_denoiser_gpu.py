@@ -276,3 +276,33 @@ def test_seq_forward_cut_into_several_launches_is_bit_identical(rg, setup):
         outs.append(sess.forward(x, 23, 40, 1).clone())
         torch.cuda.synchronize()
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
+
+
+@pytest.mark.parametrize("grouped", [True, False])
+def test_condition_side_attention_matrices_vs_oracle(rg, parity, setup, grouped):
+    """DenoiserSession.set_conditions: A[layer][condition][clip][head] = softmax_N(K)^T V (efficient_attention.py:74-90) of the
+    text / audio / speaker conditions at full depth against the fp32 oracle -- for the grouped projections (bf16 normalised rows,
+    the layers' LayerNorm affines folded into stacked [key | value] weights, DenoiserWeights.KV_GROUP layers per GEMM) and for
+    the per-layer fp32-A GEMMs with a LayerNorm prologue they replace."""
+    import torch.nn.functional as F
+    cfg, P, W = setup[8]
+    data, x, mm = _inputs(rg, B=3)
+    sess = rg.denoiser.DenoiserSession(W, 3, kv_grouped=grouped)
+    sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, None)
+    torch.cuda.synchronize()
+    got = sess.a_pre.cpu()                                                  # [L, 3, B, H, 32, 32]
+    H, D = cfg["num_heads"], cfg["latent_dim"]
+    xf = {"xf_text": od.linear(P, "text_pre_proj", data["word"].float()), "xf_audio": od.linear(P, "audio_pre_proj", data["audio"].float()),
+          "xf_spk": P["speaker_embedding.weight"][data["speaker_ids"].long()].float()}
+    worst = 0.0
+    for l in range(cfg["num_layers"]):
+        for ci, c in enumerate(od.COND_ORDER):
+            name = "temporal_decoder_blocks.%d.ca_blocks.%s" % (l, c)
+            xn = od.layer_norm(P, name + ".text_norm", xf[c])
+            B, N = xn.shape[:2]
+            key = F.softmax(od.linear(P, name + ".key", xn).view(B, N, H, -1), dim=1)
+            val = od.linear(P, name + ".value", xn).view(B, N, H, -1)
+            ref = torch.einsum("bnhd,bnhl->bhdl", key, val)
+            worst = max(worst, relerr(got[l, ci], ref))
+    parity.check("condition-side A = softmax_N(K)^T V, L8, %s projections (bf16 operands): worst (layer, condition) vs oracle"
+                 % ("grouped" if grouped else "per-layer"), worst, 6e-3)

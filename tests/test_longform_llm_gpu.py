@@ -166,17 +166,20 @@ def test_config5_one_clip_three_windows_l8_vs_oracle(rg, tmp_path, parity):
 def test_config5_two_clips_run_many_pipelined_l8_vs_oracle(rg, tmp_path, parity):
     """The batched, PIPELINED long-form driver (longform.run_many: window k of all clips in one forward, submitted through
     submit() / flush() with the previous window's latent still pending -- pipeline.PendingLatent) at full depth against
-    the oracle's per-clip loop of tools/longform_synthesis.py:256-403: two clips of different lengths (3 and 2 windows:
-    the batch SHRINKS at window 2, the pending latent is row-selected, longform_synthesis.py:389-403), the flags of BASELINE
-    config 5 (llm retrieval on cached answers, inversion + insertion guidance + prev-latent).  Per clip: retrieval results
-    exact per window, every window's latent and the blended 30-fps outputs within the bf16 bars."""
+    the oracle driven by the loop of tools/longform_synthesis.py:256-403 over the same window batches (the oracle pipeline is
+    batch-capable and consumes one noise tape in the reference's order, exactly like the product): two clips of different
+    lengths (3 and 2 windows: the batch SHRINKS at window 2, the pending latent is row-selected, :389-403), the flags of
+    BASELINE config 5 (llm retrieval on cached answers, inversion + insertion guidance + prev-latent).  Per clip and window:
+    retrieval results exact, latents and the blended 30-fps outputs within the bf16 bars."""
     from oracle import diffusion as odf, fuzzy as ofz, packing as opk, pipeline as opipe, rotation as orot
     GI = [0] * 25 + list(range(25))
     cfg = rg.synth.default_model_cfg(num_layers=8)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
     ds = rg.synth.SyntheticDataset(300, seed=31)
+    # (cobatch_lanes="split": every window batch is cut over the two lanes, so consecutive windows share their launches even with
+    #  two clips; with whole batches alternating between the lanes a lane sees every other window only)
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds, precision="bf16",
-                                  async_results=True)
+                                  async_results=True, cobatch_lanes="split")
     P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
     model.load_state_dict(P)
     model.eval()
@@ -197,49 +200,61 @@ def test_config5_two_clips_run_many_pipelined_l8_vs_oracle(rg, tmp_path, parity)
     synth = rg.longform.LongformSynthesizer(model, overlap=15)
     flags = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
     copy = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
-    got = synth.run_many([copy(c) for c in clips], features, retrieval_method="llm", noise_tape=rg.synth.ClipTapes([5, 6]), **flags)
+    got = synth.run_many([copy(c) for c in clips], features, retrieval_method="llm", noise_tape=rg.synth.NoiseTape(5), **flags)
     torch.cuda.synchronize()
-    assert any(k[0] == "cobatch" for k in model._graphs), "the pipelined run should have gone through co-batched chains"
     assert not model._pend and not model._ready
     assert [len(got[c]["windows"]) for c in range(2)] == n_windows
+    assert any(k[0] == "cobatch" for k in model._graphs), "the pipelined run should have gone through co-batched chains"
 
-    # ---- the oracle: each clip on its own, window after window (same per-clip noise tape, same cached answers)
+    # ---- the oracle: window k of the clips that still have one as ONE oracle forward (same tape, same cached answers)
     odb = oret.build_db_dicts(ds.retrieval_samples)
     sim = lambda a, b: ofz.partial_ratio(a, b) / 100
-    sch = odf.SpacedSchedule()
+    sch, otape = odf.SpacedSchedule(), rg.synth.NoiseTape(5)
     torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
     rel = lambda x, y: ((x - y).norm() / y.norm()).item()
-    n_ex = 0
-    for ci, clip in enumerate(clips):
-        otape = rg.synth.NoiseTape(5 + ci)
+    st = []
+    for clip in clips:
         sample_len = clip["motion"].shape[1]
         starts, ends, rem = opk.window_bounds(sample_len)
-        od = rg.longform.pad_tail(copy(clip), rem)
-        spk = int(clip["speaker_ids"][0, 0])
-        prev, so_far = None, None
-        for cidx, (c0, c1) in enumerate(zip(starts, ends)):
-            chunk = {k: od[k][:, c0:c1] for k in od if torch.is_tensor(od[k])}
-            chunk["audio"] = audio[(ci, cidx)]
+        st.append(dict(od=rg.longform.pad_tail(copy(clip), rem), starts=starts, ends=ends, n=sample_len, prev=None, so_far=None,
+                       spk=int(clip["speaker_ids"][0, 0])))
+    n_ex = 0
+    for cidx in range(max(n_windows)):
+        act = [ci for ci in range(2) if cidx < n_windows[ci]]
+        chunks, wants, names = [], [], []
+        for ci in act:
+            c0, c1 = st[ci]["starts"][cidx], st[ci]["ends"][cidx]
+            ch = {k: st[ci]["od"][k][:, c0:c1] for k in st[ci]["od"] if torch.is_tensor(st[ci]["od"][k])}
+            ch["audio"] = audio[(ci, cidx)]
+            chunks.append(ch)
             ann, name = seen[(ci, cidx)]["ann"], "9_longform_%d_0/%d" % (seeds[ci], cidx)
             f = feats[(ci, cidx)]["text_features"]
-            want = oret.llm_retrieval(seen[(ci, cidx)]["text"], ann["text_segments"][0], spk, ann["prominence"][0],
+            want = oret.llm_retrieval(seen[(ci, cidx)]["text"], ann["text_segments"][0], st[ci]["spk"], ann["prominence"][0],
                                       odb["idx_2_gesture_labels"], odb["idx_2_gestprom"], f, odb["idx_2_text"], sim, cache.get)
             assert rdb.test_indexes[name]["llm"] == want[0], "clip %d window %d: llm retrieval differs from the oracle" % (ci, cidx)
             assert rdb.test_dbounds[name]["llm"] == want[1] and rdb.test_qbounds[name]["llm"] == want[2]
             n_ex += len(want[0])
-            cond = dict(text_features=[f], speaker_ids=chunk["speaker_ids"])
-            with torch.no_grad():
-                o = opipe.motion_diffusion_forward(
-                    P, cfg, vae_cfgs, sch, chunk, otape, use_prev_latent=True, prev_latent=prev,
-                    re_dict=lambda tp: oret.database_forward(P, vae_cfgs, odb, ds, cond, [name], tp, retrieval_method="llm",
-                                                             retrieve=lambda b: want), **flags)
-            lat = got[ci]["latents"][cidx].cpu()
+            wants.append(want)
+            names.append(name)
+        batch = {k: torch.cat([c[k] for c in chunks], dim=0) for k in chunks[0]}
+        cond = dict(text_features=[feats[(ci, cidx)]["text_features"] for ci in act], speaker_ids=batch["speaker_ids"])
+        prev = None if cidx == 0 else torch.cat([st[ci]["prev"] for ci in act], dim=0)
+        with torch.no_grad():
+            o = opipe.motion_diffusion_forward(
+                P, cfg, vae_cfgs, sch, batch, otape, use_prev_latent=True, prev_latent=prev,
+                re_dict=lambda tp: oret.database_forward(P, vae_cfgs, odb, ds, cond, names, tp, retrieval_method="llm",
+                                                         retrieve=lambda b: wants[b]), **flags)
+        for j, ci in enumerate(act):
+            lat, ref = got[ci]["latents"][cidx].cpu(), o["prev_latentout"][j:j + 1]
             parity.check("config 5 run_many pipelined (llm, L8, bf16) clip %d window %d: final latent vs oracle" % (ci, cidx),
-                         ((lat - o["prev_latentout"])[:, KEEP].norm() / o["prev_latentout"][:, KEEP].norm()).item(), 1.5e-2)
-            prev = o["prev_latentout"]
-            cur = (opk.scatter_parts(o["pred_upper"], o["pred_lower"], o["pred_hands"], o["pred_facepose"]), o["pred_exps"], o["pred_transl"])
-            so_far = cur if cidx == 0 else opk.blend_window(*so_far, *cur, 15)
-        n_out = 2 * sample_len
+                         ((lat - ref)[:, KEEP].norm() / ref[:, KEEP].norm()).item(), 1.5e-2)
+            st[ci]["prev"] = ref
+            cur = (opk.scatter_parts(o["pred_upper"][j:j + 1], o["pred_lower"][j:j + 1], o["pred_hands"][j:j + 1], o["pred_facepose"][j:j + 1]),
+                   o["pred_exps"][j:j + 1], o["pred_transl"][j:j + 1])
+            st[ci]["so_far"] = cur if cidx == 0 else opk.blend_window(*st[ci]["so_far"], *cur, 15)
+    for ci in range(2):
+        n_out = 2 * st[ci]["n"]
+        so_far = st[ci]["so_far"]
         want_m = opk.interp_motion(so_far[0], 2)[0, :n_out]
         want_f, want_t = opk.interp_features(so_far[1], 2)[0, :n_out], opk.interp_features(so_far[2], 2)[0, :n_out]
         assert got[ci]["poses"].shape == (n_out, 165)
