@@ -534,6 +534,15 @@ int rg_select_workspace_doubles(int n_entries);
 int rg_select_top_scores_batched(rg_handle* h, const double* score, const int* top, int n_entries, int n_queries,
                                  double* workspace, int* cursor, int cap, int* out_idx, int* out_top,
                                  double* out_score, void* stream);
+/* rg_discourse_scores_batched + rg_select_top_scores_batched in TWO launches without the [n_queries][n_entries] score / relation
+ * arrays (rag/discourse_retrieval.py:86-300 for all query relations of a batch): the scores stay in registers, the per-slice
+ * top-10 lists give every query's threshold, and a second pass over the integer-coded DB (L2-resident) appends the entries
+ * that reach it.  Same arithmetic and comparisons as the two-step form: identical survivor sets.  params [n_queries][4]
+ * doubles as for rg_discourse_scores_batched; workspace [n_queries][rg_select_workspace_doubles(n)]; cursor [n_queries]
+ * (zeroed by the call); out_* [n_queries][cap]. */
+int rg_discourse_select_fused(rg_handle* h, const int* spk, const int* rel_off, const int* rel_sense, const int* rel_conn,
+                              const double* rel_prom, int n_entries, const double* params, int n_queries, double* workspace,
+                              int* cursor, int cap, int* out_idx, int* out_top, double* out_score, void* stream);
 
 /* Tie-break similarity (rag/utils.py:109-121): out[j] = mean_{i < min(Lq, L_c)} q[i,:].feats_c[i,:]
  * for candidate entries c = cand[j]; feats is the ragged [sum L, dim] fp32 token-feature table with

@@ -15,10 +15,10 @@
 
 namespace {
 
-__device__ __forceinline__ void discourse_score_entry(
+__device__ __forceinline__ void discourse_score_value(
     const int e, const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
     const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int q_sense, int q_conn,
-    int q_spk, double q_prom, double* __restrict__ score_out, int* __restrict__ top_out) {
+    int q_spk, double q_prom, double& score_ret, int& top_ret) {
   const int r0 = rel_off[e], r1 = rel_off[e + 1];
   double score = 0.0;
   int top = -1;
@@ -61,8 +61,19 @@ __device__ __forceinline__ void discourse_score_entry(
     }
     top -= r0;
   }
-  score_out[e] = score;
-  top_out[e] = top;
+  score_ret = score;
+  top_ret = top;
+}
+
+__device__ __forceinline__ void discourse_score_entry(
+    const int e, const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
+    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int q_sense, int q_conn,
+    int q_spk, double q_prom, double* __restrict__ score_out, int* __restrict__ top_out) {
+  double sc;
+  int tp;
+  discourse_score_value(e, spk, rel_off, rel_sense, rel_conn, rel_prom, q_sense, q_conn, q_spk, q_prom, sc, tp);
+  score_out[e] = sc;
+  top_out[e] = tp;
 }
 
 
@@ -327,6 +338,99 @@ __global__ void __launch_bounds__(256) compact_kernel(const double* __restrict__
 }
 
 
+// ---- sweep + selection fused (round 4): the scores never go to memory ---------------------------------------------------
+// The batched sweep above writes a float64 score and an int32 relation index per (query, entry) -- 12 B x Q x N, 19 MB for
+// the 48 query relations of a guided batch over 32 768 entries -- which three selection launches then read back twice.
+// Only the 10th largest score of every query (the threshold) and the few entries that reach it are ever used.  Two launches:
+//   sweep_tops    : grid (entry slices of 1024, queries): every thread scores its 4 entries in registers, the workgroup
+//                   extracts the slice's 10 largest scores (block_top_rounds) -> block_tops[query][slice][10];
+//                   the (0, query) workgroup also zeroes the query's cursor;
+//   sweep_compact : same grid: every workgroup first folds the query's per-slice lists into the threshold (n_slices x 10
+//                   values: one block_top_rounds pass per 1014 of them), then scores its 4 entries AGAIN (the integer-coded
+//                   CSR is 1.2 MB: it stays in L2) and appends the survivors.
+// Same arithmetic, same comparisons: identical survivors (order arbitrary as before; the host sorts them by index).
+__global__ void __launch_bounds__(256) sweep_tops_kernel(
+    const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
+    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int n_entries,
+    const double* __restrict__ params, double* __restrict__ block_tops, int* __restrict__ cursor, size_t ws_stride) {
+  __shared__ double red[4];
+  const double* qp = params + 4 * blockIdx.y;
+  const int q_sense = (int)qp[0], q_conn = (int)qp[1], q_spk = (int)qp[2];
+  const double q_prom = qp[3];
+  double v[SEL_IPT], tops[SEL_K];
+#pragma unroll
+  for (int i = 0; i < SEL_IPT; ++i) {
+    const int e = blockIdx.x * (256 * SEL_IPT) + i * 256 + threadIdx.x;
+    v[i] = -1.0;
+    if (e < n_entries) {
+      int tp;
+      discourse_score_value(e, spk, rel_off, rel_sense, rel_conn, rel_prom, q_sense, q_conn, q_spk, q_prom, v[i], tp);
+    }
+  }
+  block_top_rounds(v, red, tops);
+  if (threadIdx.x == 0) {
+    double* bt = block_tops + blockIdx.y * ws_stride + blockIdx.x * SEL_K;
+    for (int r = 0; r < SEL_K; ++r) bt[r] = tops[r];
+    if (blockIdx.x == 0) cursor[blockIdx.y] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) sweep_compact_kernel(
+    const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
+    const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int n_entries,
+    const double* __restrict__ params, const double* __restrict__ block_tops, int n_lists, int* __restrict__ cursor,
+    int cap, int* __restrict__ out_idx, int* __restrict__ out_top, double* __restrict__ out_score, size_t ws_stride) {
+  __shared__ double red[4];
+  block_tops += blockIdx.y * ws_stride;
+  // threshold = 10th largest of the query's per-slice lists (as topk_merge_kernel)
+  double carry[SEL_K];
+  for (int r = 0; r < SEL_K; ++r) carry[r] = -1.0;
+  const int total = n_lists * SEL_K;
+  for (int base = 0; base < total; base += 256 * SEL_IPT - SEL_K) {
+    double v[SEL_IPT], tops[SEL_K];
+#pragma unroll
+    for (int i = 0; i < SEL_IPT; ++i) {
+      const int j = i * 256 + threadIdx.x;
+      double x = -1.0;
+      if (j >= SEL_K && base + j - SEL_K < total) x = block_tops[base + j - SEL_K];
+      v[i] = x;
+    }
+    if (threadIdx.x < SEL_K) {
+      double c = -1.0;
+      for (int r = 0; r < SEL_K; ++r) c = ((int)threadIdx.x == r) ? carry[r] : c;
+      v[0] = c;
+    }
+    block_top_rounds(v, red, tops);
+    for (int r = 0; r < SEL_K; ++r) carry[r] = tops[r];
+  }
+  double thr = carry[SEL_K - 1];
+  if (n_entries <= 64 || thr < 0.0) thr = 0.0;
+  const double* qp = params + 4 * blockIdx.y;
+  const int q_sense = (int)qp[0], q_conn = (int)qp[1], q_spk = (int)qp[2];
+  const double q_prom = qp[3];
+  cursor += blockIdx.y;
+  out_idx += (size_t)blockIdx.y * cap;
+  out_top += (size_t)blockIdx.y * cap;
+  out_score += (size_t)blockIdx.y * cap;
+#pragma unroll
+  for (int i = 0; i < SEL_IPT; ++i) {
+    const int e = blockIdx.x * (256 * SEL_IPT) + i * 256 + threadIdx.x;
+    if (e >= n_entries) continue;
+    double sc;
+    int tp;
+    discourse_score_value(e, spk, rel_off, rel_sense, rel_conn, rel_prom, q_sense, q_conn, q_spk, q_prom, sc, tp);
+    if (sc >= thr && sc > 0.0) {
+      const int pos = atomicAdd(cursor, 1);
+      if (pos < cap) {
+        out_idx[pos] = e;
+        out_top[pos] = tp;
+        out_score[pos] = sc;
+      }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------ fuzzy word similarity
 // fuzzywuzzy 0.18 `fuzz.partial_ratio` (pure-python flavour: difflib.SequenceMatcher) of one query string against every
 // word of the DB vocabulary, one thread per word -- the similarity `get_word_similarity_score` effectively returns
@@ -463,6 +567,24 @@ extern "C" int rg_select_top_scores_batched(rg_handle* h, const double* score, c
   RG_REQUIRE(h, score && top && workspace && cursor && out_idx && out_top && out_score, "null pointer");
   RG_REQUIRE(h, n_entries > 0 && cap > 0 && n_queries > 0 && n_queries <= 65535, "bad shape");
   return select_launch(h, score, top, n_entries, n_queries, workspace, cursor, cap, out_idx, out_top, out_score, stream);
+}
+
+extern "C" int rg_discourse_select_fused(rg_handle* h, const int* spk, const int* rel_off, const int* rel_sense,
+                                        const int* rel_conn, const double* rel_prom, int n_entries, const double* params,
+                                        int n_queries, double* workspace, int* cursor, int cap, int* out_idx, int* out_top,
+                                        double* out_score, void* stream) {
+  RG_REQUIRE(h, spk && rel_off && rel_sense && rel_conn && rel_prom && params, "null pointer");
+  RG_REQUIRE(h, workspace && cursor && out_idx && out_top && out_score, "null pointer");
+  RG_REQUIRE(h, n_entries > 0 && cap > 0 && n_queries > 0 && n_queries <= 65535, "bad shape");
+  const int nb = (n_entries + 256 * SEL_IPT - 1) / (256 * SEL_IPT);
+  const size_t ws_stride = (size_t)nb * SEL_K + 1;
+  hipStream_t s = rg_stream(stream);
+  hipLaunchKernelGGL(sweep_tops_kernel, dim3(nb, n_queries), dim3(256), 0, s, spk, rel_off, rel_sense, rel_conn, rel_prom,
+                     n_entries, params, workspace, cursor, ws_stride);
+  hipLaunchKernelGGL(sweep_compact_kernel, dim3(nb, n_queries), dim3(256), 0, s, spk, rel_off, rel_sense, rel_conn, rel_prom,
+                     n_entries, params, workspace, nb, cursor, cap, out_idx, out_top, out_score, ws_stride);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
 }
 
 extern "C" int rg_select_workspace_doubles(int n_entries) {

@@ -127,6 +127,8 @@ class DiscourseIndex:
         self._score = torch.empty(self.n, dtype=torch.float64, device=self.dev)
         self._top = torch.empty(self.n, dtype=torch.int32, device=self.dev)
 
+    fused_sweep = True     # sweep_async: rg_discourse_select_fused (two launches, no score arrays); False: sweep + 3-launch selection
+
     def scores(self, sense, conn, speaker_id, q_prom):
         """HIP sweep for one query relation -> (scores float64 [N], top_rel int32 [N]) on the host."""
         lib, vp = self.h.lib, ctypes.c_void_p
@@ -148,8 +150,9 @@ class DiscourseIndex:
         Q, n = len(queries), self.n
         cap = n
         nws = lib.rg_select_workspace_doubles(n)
-        score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
-        top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
+        if not self.fused_sweep:
+            score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
+            top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
         ws = torch.empty(Q, nws, dtype=torch.float64, device=self.dev)
         cursor = torch.zeros(Q, dtype=torch.int32, device=self.dev)
         o_idx = torch.empty(Q, cap, dtype=torch.int32, device=self.dev)
@@ -160,6 +163,16 @@ class DiscourseIndex:
         params = to_device_async(torch.tensor([[float(self.sense_code.get(sense, -2)), float(self.conn_code.get(conn, -1)),
                                                 float(int(spk)), nan if q_prom is None else float(q_prom)]
                                                for sense, conn, spk, q_prom in queries], dtype=torch.float64), self.dev)
+        if self.fused_sweep:
+            # two launches: scores in registers, per-slice top lists -> thresholds, second pass appends the survivors
+            rc = lib.rg_discourse_select_fused(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
+                                               vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
+                                               vp(self.rel_prom.data_ptr()), n, vp(params.data_ptr()), Q, vp(ws.data_ptr()),
+                                               vp(cursor.data_ptr()), cap, vp(o_idx.data_ptr()), vp(o_top.data_ptr()),
+                                               vp(o_score.data_ptr()), vp(s))
+            if rc != 0:
+                raise capi.RgError("retrieval sweep failed: %s" % lib.rg_last_error(self.h._h).decode())
+            return dict(cursor=cursor, idx=o_idx, top=o_top, score=o_score, keep=(ws, params))
         # one sweep launch and one three-launch selection for the whole batch of queries
         rc = lib.rg_discourse_scores_batched(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
                                              vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),

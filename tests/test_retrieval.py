@@ -122,6 +122,38 @@ def test_hip_sweep_matches_oracle_large_db(rg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_entries", [50, 4096, 32768])
+def test_fused_sweep_selects_exactly_what_the_two_step_form_selects(rg, n_entries):
+    """rg_discourse_select_fused (scores in registers, two launches) against rg_discourse_scores_batched +
+    rg_select_top_scores_batched (scores through memory, four launches) and against the full score rows: the same survivors
+    with bit-identical float64 scores and the same relation indices for every query relation of a batch (BASELINE DB size
+    included; 50 entries: the `fewer than 64 entries: keep every positive score` branch)."""
+    import numpy as np
+    smp = rg.synth.synth_retrieval_samples(n_entries, seed=2025)
+    index = rg.retrieval.DiscourseIndex(rg.retrieval.build_db_dicts(smp), "cuda")
+    queries = []
+    for i in range(16):
+        q = rg.synth.synth_query(1000 + i)
+        queries += rg.retrieval.discourse_queries(q["discourse"], q["prominence"], q["speaker_id"])
+    assert len(queries) >= 16
+    index.fused_sweep = True
+    fused = index.collect(index.sweep_async(queries))
+    index.fused_sweep = False
+    plain = index.collect(index.sweep_async(queries))
+    n_surv = 0
+    for qi, ((fi, fs, ft), (pi, ps, pt)) in enumerate(zip(fused, plain)):
+        assert np.array_equal(fi, pi) and np.array_equal(fs, ps) and np.array_equal(ft, pt), qi
+        # ... and against the whole score row of the single-query sweep
+        sc, tp = index.scores(*queries[qi])
+        pos = np.sort(sc[sc > 0])[::-1]
+        thr = pos[9] if (len(pos) >= 10 and n_entries > 64) else 0.0
+        keep = np.nonzero((sc >= thr) & (sc > 0))[0]
+        assert np.array_equal(fi, keep) and np.array_equal(fs, sc[keep]) and np.array_equal(ft, tp[keep]), qi
+        n_surv += len(keep)
+    assert n_surv > 0
+
+
+@pytest.mark.gpu
 def test_retrieval_database_forward_vs_reference(rg, golden_dir):
     g = _golden(golden_dir)
     lat = np.load(os.path.join(golden_dir, "retrieval_L2_allenc.npz"))
