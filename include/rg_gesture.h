@@ -376,6 +376,9 @@ typedef struct rg_venc_args {
 } rg_venc_args;
 
 int rg_venc_forward(rg_handle* h, const rg_venc_args* args_host, void* stream);
+/* n <= 4 independent stacks (the four body-part VAEs: different weights, inputs and widths of nothing -- the stacks share D = 512)
+ * in ONE launch: args_host[n], gridDim.y = n. */
+int rg_venc_forward_grouped(rg_handle* h, const rg_venc_args* args_host, int n, void* stream);
 
 /* ---------------------------------------------------------------- body-part VAEs + rotations
  * Softmax multi-head attention core of torch.nn.MultiheadAttention for short sequences

@@ -227,33 +227,59 @@ __device__ __forceinline__ double wave_max_f64(double v) {
   return v;
 }
 
-// 10 rounds of "largest remaining value" over the items each thread holds in v[]; tops[r] valid on thread 0
-__device__ __forceinline__ void block_top_rounds(double (&v)[SEL_IPT], double* red, double (&tops)[SEL_K]) {
-  __shared__ int owner;
+// The 10 largest values (with multiplicity) of the 256 x SEL_IPT items a workgroup holds in registers; tops[] is uniform
+// across the block on return.  Per wave: 10 rounds of "largest remaining value" on wave shuffles alone (the owner of a
+// round's maximum -- the lowest lane that holds it -- consumes ONE instance); the four waves' lists meet in LDS and wave 0
+// repeats the rounds over those 40 values.  One barrier pair per call (round 3 took two per round plus an atomic: the ten
+// rounds of a slice cost more than its whole sweep).
+__device__ __forceinline__ void wave_top_rounds(double (&v)[SEL_IPT], double (&tops)[SEL_K]) {
+  const int lane = threadIdx.x & 63;
   for (int r = 0; r < SEL_K; ++r) {
     double m = v[0];
 #pragma unroll
     for (int i = 1; i < SEL_IPT; ++i) m = v[i] > m ? v[i] : m;
     const double wm = wave_max_f64(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wm;
-    if (threadIdx.x == 0) owner = 0x7fffffff;
-    __syncthreads();
-    double bm = red[0];
-    for (int w = 1; w < 4; ++w) bm = red[w] > bm ? red[w] : bm;
-    if (m == bm) atomicMin(&owner, (int)threadIdx.x);
-    __syncthreads();
-    if ((int)threadIdx.x == owner) {   // consume ONE instance of the maximum
+    const unsigned long long holders = __ballot(m == wm);
+    if (lane == __ffsll((long long)holders) - 1) {   // consume ONE instance of the maximum
       bool done = false;
 #pragma unroll
       for (int i = 0; i < SEL_IPT; ++i)
-        if (!done && v[i] == bm) {
+        if (!done && v[i] == wm) {
           v[i] = -1.0;
           done = true;
         }
     }
-    tops[r] = bm;
-    __syncthreads();
+    tops[r] = wm;
   }
+}
+
+__device__ __forceinline__ void block_top_rounds(double (&v)[SEL_IPT], double* red, double (&tops)[SEL_K]) {
+  __shared__ double lists[4 * SEL_K + SEL_K];
+  (void)red;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  wave_top_rounds(v, tops);
+  if (lane < SEL_K) {
+    double t = -1.0;
+    for (int r = 0; r < SEL_K; ++r) t = (lane == r) ? tops[r] : t;
+    lists[wave * SEL_K + lane] = t;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double w[SEL_IPT];
+#pragma unroll
+    for (int i = 0; i < SEL_IPT; ++i) w[i] = -1.0;
+    if (lane < 4 * SEL_K) w[0] = lists[lane];
+    double t2[SEL_K];
+    wave_top_rounds(w, t2);
+    if (lane < SEL_K) {
+      double t = -1.0;
+      for (int r = 0; r < SEL_K; ++r) t = (lane == r) ? t2[r] : t;
+      lists[4 * SEL_K + lane] = t;
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < SEL_K; ++r) tops[r] = lists[4 * SEL_K + r];
+  __syncthreads();                                   // (the lists are rewritten by the caller's next pass)
 }
 
 // blockIdx.y = query of a batched selection (strides in elements; 0 for a single query)

@@ -117,7 +117,11 @@ __device__ __forceinline__ void zero(Acc& a) {
 
 }  // namespace
 
-__global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_args a) {
+struct rg_venc_group { rg_venc_args a[4]; };   // up to four stacks (the four body parts) in one launch: blockIdx.y picks
+
+__global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_group grp) {
+  const rg_venc_args& a = grp.a[blockIdx.y];
+  if ((int)blockIdx.x >= (a.nseq + 1) / 2) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const P0 = smem + OFF_P0;
   unsigned char* const P1 = smem + OFF_P1;
@@ -593,13 +597,25 @@ __global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_args a) {
   wait_vmcnt<0>();
 }
 
-extern "C" int rg_venc_forward(rg_handle* h, const rg_venc_args* args_host, void* stream) {
-  RG_REQUIRE(h, args_host, "null args");
-  const rg_venc_args& a = *args_host;
+static int venc_check(rg_handle* h, const rg_venc_args& a) {
   RG_REQUIRE(h, a.wstream && a.pstream && a.x && a.out && a.xbuf, "null pointer");
   RG_REQUIRE(h, a.nseq >= 1 && a.S >= 1 && a.S <= SQ, "unsupported shape (1 <= S <= 24 tokens per sequence)");
   RG_REQUIRE(h, a.nb >= 1 && 8 * (2 * a.nb + 1) + 2 * a.nb <= MAX_UNITS, "unsupported depth (1 <= blocks per side <= 8)");
   RG_REQUIRE(h, a.dump_block < 0 || a.dump, "dump_block needs a dump buffer");
+  return RG_OK;
+}
+
+extern "C" int rg_venc_forward_grouped(rg_handle* h, const rg_venc_args* args_host, int n, void* stream) {
+  RG_REQUIRE(h, args_host && n >= 1 && n <= 4, "1..4 argument blocks");
+  rg_venc_group g;
+  int wgs = 0;
+  for (int i = 0; i < 4; ++i) {
+    g.a[i] = args_host[i < n ? i : 0];
+    if (i < n) {
+      if (int rc = venc_check(h, g.a[i])) return rc;
+      wgs = max(wgs, (g.a[i].nseq + 1) / 2);
+    }
+  }
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)rg_venc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
@@ -608,7 +624,12 @@ extern "C" int rg_venc_forward(rg_handle* h, const rg_venc_args* args_host, void
     }
     attr = true;
   }
-  hipLaunchKernelGGL(rg_venc_kernel, dim3((a.nseq + 1) / 2), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
+  hipLaunchKernelGGL(rg_venc_kernel, dim3(wgs, n), dim3(NTH), LDS_BYTES, rg_stream(stream), g);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
+}
+
+extern "C" int rg_venc_forward(rg_handle* h, const rg_venc_args* args_host, void* stream) {
+  RG_REQUIRE(h, args_host, "null args");
+  return rg_venc_forward_grouped(h, args_host, 1, stream);
 }

@@ -143,48 +143,48 @@ class DiscourseIndex:
             raise capi.RgError("rg_discourse_scores failed: %s" % lib.rg_last_error(self.h._h).decode())
         return self._score.cpu().numpy(), self._top.cpu().numpy()
 
-    def sweep_async(self, queries):
-        """Launch sweep + device-side candidate selection for a list of (sense, conn, speaker_id, q_prom)
-        without any host synchronisation; returns a ticket for collect()."""
-        lib, vp = self.h.lib, ctypes.c_void_p
+    def sweep_buffers(self, queries):
+        """Device buffers of one sweep over `queries` [(sense, conn, speaker_id, q_prom)]: the query parameters (uploaded
+        asynchronously from pinned memory), the selection workspace and the survivor lists."""
+        lib = self.h.lib
         Q, n = len(queries), self.n
         cap = n
-        nws = lib.rg_select_workspace_doubles(n)
-        if not self.fused_sweep:
-            score = torch.empty(Q, n, dtype=torch.float64, device=self.dev)
-            top = torch.empty(Q, n, dtype=torch.int32, device=self.dev)
-        ws = torch.empty(Q, nws, dtype=torch.float64, device=self.dev)
-        cursor = torch.zeros(Q, dtype=torch.int32, device=self.dev)
-        o_idx = torch.empty(Q, cap, dtype=torch.int32, device=self.dev)
-        o_top = torch.empty(Q, cap, dtype=torch.int32, device=self.dev)
-        o_score = torch.empty(Q, cap, dtype=torch.float64, device=self.dev)
-        s = torch.cuda.current_stream().cuda_stream
         nan = float("nan")
         params = to_device_async(torch.tensor([[float(self.sense_code.get(sense, -2)), float(self.conn_code.get(conn, -1)),
                                                 float(int(spk)), nan if q_prom is None else float(q_prom)]
                                                for sense, conn, spk, q_prom in queries], dtype=torch.float64), self.dev)
+        e = lambda *shape, dt=torch.int32: torch.empty(*shape, dtype=dt, device=self.dev)
+        bufs = dict(Q=Q, cap=cap, params=params, ws=e(Q, lib.rg_select_workspace_doubles(n), dt=torch.float64),
+                    cursor=e(Q), idx=e(Q, cap), top=e(Q, cap), score=e(Q, cap, dt=torch.float64))
+        if not self.fused_sweep:
+            bufs.update(all_score=e(Q, n, dt=torch.float64), all_top=e(Q, n))
+        return bufs
+
+    def sweep_launch(self, bufs):
+        """The launches of one sweep + device-side candidate selection on the current stream (no allocation, no copy, no
+        synchronisation): fused = rg_discourse_select_fused (two launches, scores in registers), else the sweep + the
+        three-launch selection over score arrays.  Returns the ticket for collect()."""
+        lib, vp = self.h.lib, ctypes.c_void_p
+        s = torch.cuda.current_stream().cuda_stream
+        p = lambda k: vp(bufs[k].data_ptr())
+        db = (vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()), vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
+              vp(self.rel_prom.data_ptr()), self.n)
         if self.fused_sweep:
-            # two launches: scores in registers, per-slice top lists -> thresholds, second pass appends the survivors
-            rc = lib.rg_discourse_select_fused(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
-                                               vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
-                                               vp(self.rel_prom.data_ptr()), n, vp(params.data_ptr()), Q, vp(ws.data_ptr()),
-                                               vp(cursor.data_ptr()), cap, vp(o_idx.data_ptr()), vp(o_top.data_ptr()),
-                                               vp(o_score.data_ptr()), vp(s))
-            if rc != 0:
-                raise capi.RgError("retrieval sweep failed: %s" % lib.rg_last_error(self.h._h).decode())
-            return dict(cursor=cursor, idx=o_idx, top=o_top, score=o_score, keep=(ws, params))
-        # one sweep launch and one three-launch selection for the whole batch of queries
-        rc = lib.rg_discourse_scores_batched(self.h._h, vp(self.spk.data_ptr()), vp(self.rel_off.data_ptr()),
-                                             vp(self.rel_sense.data_ptr()), vp(self.rel_conn.data_ptr()),
-                                             vp(self.rel_prom.data_ptr()), n, vp(params.data_ptr()), Q,
-                                             vp(score.data_ptr()), vp(top.data_ptr()), vp(s))
-        if rc == 0:
-            rc = lib.rg_select_top_scores_batched(self.h._h, vp(score.data_ptr()), vp(top.data_ptr()), n, Q,
-                                                  vp(ws.data_ptr()), vp(cursor.data_ptr()), cap, vp(o_idx.data_ptr()),
-                                                  vp(o_top.data_ptr()), vp(o_score.data_ptr()), vp(s))
+            rc = lib.rg_discourse_select_fused(self.h._h, *db, p("params"), bufs["Q"], p("ws"), p("cursor"), bufs["cap"], p("idx"),
+                                               p("top"), p("score"), vp(s))
+        else:
+            rc = lib.rg_discourse_scores_batched(self.h._h, *db, p("params"), bufs["Q"], p("all_score"), p("all_top"), vp(s))
+            if rc == 0:
+                rc = lib.rg_select_top_scores_batched(self.h._h, p("all_score"), p("all_top"), self.n, bufs["Q"], p("ws"), p("cursor"),
+                                                      bufs["cap"], p("idx"), p("top"), p("score"), vp(s))
         if rc != 0:
             raise capi.RgError("retrieval sweep failed: %s" % lib.rg_last_error(self.h._h).decode())
-        return dict(cursor=cursor, idx=o_idx, top=o_top, score=o_score, keep=(score, top, ws, params))
+        return dict(cursor=bufs["cursor"], idx=bufs["idx"], top=bufs["top"], score=bufs["score"], keep=bufs)
+
+    def sweep_async(self, queries):
+        """Launch sweep + device-side candidate selection for a list of (sense, conn, speaker_id, q_prom)
+        without any host synchronisation; returns a ticket for collect()."""
+        return self.sweep_launch(self.sweep_buffers(queries))
 
     @staticmethod
     def collect(ticket):
