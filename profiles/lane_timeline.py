@@ -28,6 +28,7 @@ if "SLOTS" in os.environ:
 if "LANES" in os.environ:
     model.lanes = int(os.environ["LANES"])
 model.async_results = bool(int(os.environ.get("PIPELINED", "0")))
+model.calibrate_lanes = os.environ.get("CALIBRATE", "1") == "1"
 if "SAMPLE_LANES" in os.environ:
     model.sample_lanes = int(os.environ["SAMPLE_LANES"])
 data = rg.synth.synth_batch(B, seed=1234, device=dev)

@@ -322,8 +322,10 @@ class MotionDiffusion(torch.nn.Module):
                         a front end never writes what the chain in flight still reads; at most `max_inflight` batches
                         are queued before forward() blocks on the oldest.
       lane_streams      the caller's own streams for the lanes / the search / the base lanes (max(lanes, base_lanes) + 1 of them)
-      calibrate_lanes   pick streams that were measured to run concurrently (distinct hardware queues) first; performance only:
-                        the NUMBER of lanes and the presence of the search stream never depend on a measurement
+      calibrate_lanes   (default) pick streams that were measured to run concurrently (distinct hardware queues) first --
+                        two lanes that share a hardware queue run their chains one after the other (61 instead of 41 ms per
+                        guided step, profiles/r04i_lane_timeline.txt); performance only: the NUMBER of lanes and the presence of
+                        the search stream never depend on a measurement.  False: the next streams of torch's pool, unmeasured
       session_options   keyword arguments of denoiser.DenoiserSession (engine, ln_mode, ...)
       vae_options       keyword arguments of vae.GestureRepEncoder (part_streams, chain)"""
 
@@ -332,7 +334,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=3,
-                 lane_streams=None, calibrate_lanes=False, **kwargs):
+                 lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -368,7 +370,12 @@ class MotionDiffusion(torch.nn.Module):
         self.cobatch_lanes = str(cobatch_lanes)
         capi.require(self.cobatch_lanes in ("batch", "split"),
                 "unsupported argument: requires self.cobatch_lanes in (\"batch\", \"split\")")
-        self._lane_streams, self._search_stream, self._lanes_calibrated = [], None, None
+        self._lane_streams, self._search_stream, self._decode_stream, self._lanes_calibrated = [], None, None, None
+        # decode_stream=True: asynchronous batches decode on a stream of their own instead of the lane's.  On the lane's stream the
+        # decode (4.9 ms alone, 8-15 ms beside the other lane's chain) sits between two chains of that lane
+        # (profiles/r04i_lane_timeline.txt); on its own stream it competes with BOTH chains for compute units and the step gets
+        # slower (43.1 vs 41.0 ms, profiles/r04j): off by default, as round 3 found for the same experiment
+        self.decode_on_own_stream = bool(decode_stream)
         self._given_streams = None if lane_streams is None else list(lane_streams)
         self.calibrate_lanes, self.lane_report = bool(calibrate_lanes), None
 
@@ -600,11 +607,11 @@ class MotionDiffusion(torch.nn.Module):
         `lane_streams=` constructor argument (the caller's own streams); `calibrate_lanes=True`: streams measured to be
         concurrent first, unmeasured ones to make up the count; otherwise fresh streams."""
         lanes = max(1, int(self.lanes))
-        need = max(lanes, self.base_lanes) + 1
+        need = max(lanes, self.base_lanes) + 2            # lanes (+ base lanes), the search stream, the decode stream
         report = dict(lanes=lanes, base_lanes=self.base_lanes, streams=need, source="fresh", measured_concurrent=None)
         if self._given_streams is not None:
             found = list(self._given_streams)
-            capi.require(len(found) >= need, "lane_streams: %d streams needed (max(lanes, base_lanes) + 1 for the search), got %d"
+            capi.require(len(found) >= need, "lane_streams: %d streams needed (max(lanes, base_lanes) + the search stream + the decode stream), got %d"
                          % (need, len(found)))
             report["source"] = "caller"
         elif self.calibrate_lanes:
@@ -614,8 +621,8 @@ class MotionDiffusion(torch.nn.Module):
         else:
             found = [torch.cuda.Stream(device=self.device) for _ in range(need)]
         found = found[:need]
-        self._search_stream = found[lanes]
-        self._lane_streams = found[:lanes] + found[lanes + 1:]
+        self._search_stream, self._decode_stream = found[lanes], found[lanes + 1]
+        self._lane_streams = found[:lanes] + found[lanes + 2:]
         self._lanes_calibrated = (lanes, self.base_lanes)
         self.lane_report = report
 
@@ -1128,6 +1135,8 @@ class MotionDiffusion(torch.nn.Module):
         gre, results, main, S, T, D, B = self.model.gesture_rep_encoder, st.results, st.main, st.S, st.T, st.D, st.B
         # (asynchronous: the lanes take turns, so that the decode does not always delay the same lane's next chain)
         tail_lane, tail = st.plan_s[self._tail_turn % len(st.plan_s)][:2] if st.run_async else (-1, main)
+        if st.run_async and self.decode_on_own_stream and self._decode_stream is not None:
+            tail_lane, tail = -2, self._decode_stream
         self._tail_turn += 1
         if self._jitter is not None:
             self._jitter(tail, "tail")
