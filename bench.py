@@ -103,6 +103,8 @@ def launch_ranks(n, argv, dry=False):
 class Workload:
     """One benchmark configuration: model + resident synthetic inputs + step()."""
 
+    streams = None     # the measured stream set of the first model of the process; later models take it (same topology for all)
+
     def __init__(self, rg, kind, B, dev, rank, db_size, precision="bf16", database=None, clips=10, windows=3, pipelined=True, cobatch=True):
         import collections
         self.rg, self.kind, self.B, self.dev, self.precision = rg, kind, B, dev, precision
@@ -119,7 +121,10 @@ class Workload:
         if self.guided and database is None:
             self.database = rg.synth.SyntheticDataset(db_size, seed=2025, device=dev, feat_device=dev)
         self.model = rg.build_architecture(rg.synth.reference_style_model_cfg(self.cfg, self.vae_cfgs, with_retrieval=self.guided),
-                                           database=self.database if self.guided else None, device=dev, precision=precision)
+                                           database=self.database if self.guided else None, device=dev, precision=precision,
+                                           lane_streams=Workload.streams)
+        if Workload.streams is None:
+            Workload.streams = self.model.stream_set()
         self.model.load_state_dict(rg.synth.synth_full_state(0, self.cfg, self.vae_cfgs))
         self.model.eval()
         self.model.async_results = bool(pipelined)     # (long-form: run_many then pipelines the windows through submit())
@@ -609,6 +614,7 @@ def main():
                 r = {"value": round(w.frames_per_step * steps / d, 1), "unit": "frames/s", "ms_per_step": round(d / steps * 1e3, 2),
                      "steps": steps, "warmup": warmup, "dtype": "bf16" if w.precision == "bf16" else "bf16x3 (fp32-equivalent)"}
                 r["verified"] = w.verify()
+                r["stream_topology"] = w.model.lane_report
                 if w.kind != "longform" and roof:
                     r["roofline"] = w.gemm_roofline(local_rank)
                 return r

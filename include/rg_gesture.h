@@ -380,6 +380,39 @@ int rg_venc_forward(rg_handle* h, const rg_venc_args* args_host, void* stream);
  * in ONE launch: args_host[n], gridDim.y = n. */
 int rg_venc_forward_grouped(rg_handle* h, const rg_venc_args* args_host, int n, void* stream);
 
+/* Block-fused body-part VAE decoder of the "all_encoder" architecture (mogen/models/transformers/gesture_vae.py:195-239
+ * `decode`: the skip-transformer ENCODER stack over cat(z [10], zero queries [150]) = 160 tokens with pos = query_pos, i.e.
+ * q = k = x + pos, v = x (detr_utils.py:335-393), num_heads * 8 = 32 heads of 16): one launch per block instead of nine,
+ * a sequence cut into four tiles of 40 rows (one workgroup each), the tiles' keys / values exchanged through L2 between the
+ * launches.  Launch `step` (0 .. 2 nb + 1) runs [attention, out_proj + norm1, FFN + norm2 of block step - 1] -> [skip push or
+ * skip linear of block step] -> [Q, K, V of block step]; launch 0 only projects, the last one ends with the stack's final norm.
+ * Same weight / parameter streams as rg_venc_forward (Q pre-scaled by 1/sqrt(16)); specialised for latent_dim 512, 4 x 8
+ * heads, ff_size 1024, GELU, post-norm, 160 tokens, bf16 operands with fp32 accumulation.
+ *   x    fp32 [nseq][160][512]   residual stream: the stack's input before step 0, its output (behind the final norm) after the
+ *                                last step, updated in place by every launch
+ *   pos  fp32 [nseq][160][512]   query_pos (constant over the blocks)
+ *   qimg bf16 [4 nseq][48 KiB]   a tile's Q operand panel as it lies in LDS (handed from launch to launch)
+ *   kbuf bf16 [2][nseq][160][512]   keys, row-major;   vt bf16 [2][nseq][512][160]   values, feature-major; both double-buffered
+ *                                by launch parity (a launch's faster tiles write block `step`'s while slower ones still read
+ *                                block step - 1's)
+ *   xbuf fp32 [4 nseq][nb][8][12][64][4]   the skip stack;   dump: diagnostics (fp32 [4 nseq][48][512]: the state a launch starts
+ *                                its projection part from) or NULL */
+typedef struct rg_vdec_args {
+  const void* wstream;
+  const void* pstream;
+  float* x;
+  const float* pos;
+  void* qimg;
+  void* kbuf;
+  void* vt;
+  float* xbuf;
+  float* dump;
+  int nseq, nb, step, pad_;
+} rg_vdec_args;
+
+int rg_vdec_step(rg_handle* h, const rg_vdec_args* args_host, void* stream);
+int rg_vdec_step_grouped(rg_handle* h, const rg_vdec_args* args_host, int n, void* stream);
+
 /* ---------------------------------------------------------------- body-part VAEs + rotations
  * Softmax multi-head attention core of torch.nn.MultiheadAttention for short sequences
  * (detr_utils.py:364-366, 427-433): o[b,i,h,:] = softmax_j(q[b,i,h,:].k[b,j,h,:]/sqrt(hd)) v[b,j,h,:].

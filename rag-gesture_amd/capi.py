@@ -227,11 +227,11 @@ class OpRecorder:
                     if rc != 0:
                         raise RgError("rg_gemm_grouped failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
                     done = True
-                elif kind == "call" and ops[0][1] == "venc_forward":
-                    # the parts' fused encoder stacks: one launch, gridDim.y = part (argument blocks by value)
+                elif kind == "call" and ops[0][1] in ("venc_forward", "vdec_step"):
+                    # the parts' fused encoder stacks / decoder steps: one launch, gridDim.y = part (argument blocks by value)
                     blocks = [op[2][0]._obj for op in ops]
                     arr_t = type(blocks[0]) * n
-                    h.call("venc_forward_grouped", ctypes.byref(arr_t(*blocks)), n, stream=s)
+                    h.call(ops[0][1] + "_grouped", ctypes.byref(arr_t(*blocks)), n, stream=s)
                     done = True
                 elif kind == "call" and ops[0][1] in self.GROUPED:
                     pidx, entry, order = self.GROUPED[ops[0][1]]

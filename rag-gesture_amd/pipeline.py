@@ -626,6 +626,14 @@ class MotionDiffusion(torch.nn.Module):
         self._lanes_calibrated = (lanes, self.base_lanes)
         self.lane_report = report
 
+    def stream_set(self):
+        """The streams of this model in the order the `lane_streams=` constructor argument takes them: several models of one
+        process (bench.py builds six) can share one measured set instead of each measuring its own."""
+        lanes = max(1, int(self.lanes))
+        if self._lanes_calibrated != (lanes, self.base_lanes):
+            self._make_streams()
+        return self._lane_streams[:lanes] + [self._search_stream, self._decode_stream] + self._lane_streams[lanes:]
+
     def _lane_plan(self, B, n_lanes=None):
         """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips (n_lanes of them, default self.lanes)."""
         lanes = max(1, int(self.lanes))

@@ -68,11 +68,13 @@ class TransformerVAE:
     decoder_arch, position_embedding, nfeats, num_frames, frame_chunk_size,
     transformer_activation, transformer_normalize_before, vae_dist)."""
 
-    def __init__(self, state, vcfg, device="cuda", precision="bf16", chain=True, fused_encoder=True):
+    def __init__(self, state, vcfg, device="cuda", precision="bf16", chain=True, fused_encoder=True, fused_decoder=True):
         """chain: bf16 path only -- producers hand bf16 copies to the GEMMs that consume them (False: every GEMM converts
         its fp32 operand tiles itself; a measurement knob).
         fused_encoder: run the encoder stack as ONE launch (rg_venc_forward: two chunk sequences per workgroup, activations
-        resident on chip, weights streamed) where the shape supports it (vencfwd.supported); False: the per-op launch chain."""
+        resident on chip, weights streamed) where the shape supports it (vencfwd.supported); False: the per-op launch chain.
+        fused_decoder: the all_encoder decoder stack as one launch per block (rg_vdec_step: four 40-row tiles per 160-token
+        sequence, keys / values exchanged through L2 between the launches) where vencfwd.decoder_supported; False: the chain."""
         capi.require(vcfg.get("vae_dist", "normal") == "normal", "only the Normal posterior is supported")
         self.cfg = vcfg
         self.dev = torch.device(device)
@@ -98,9 +100,12 @@ class TransformerVAE:
         self.venc = None
         if fused_encoder and vencfwd.supported(vcfg, precision):
             self.venc = vencfwd.VencForward(self.h, vencfwd.VencStreams(state, "encoder", vcfg["num_layers"], self.heads, dev))
+        self.vdec, self._fused_decoder = None, bool(fused_decoder)
         if self.arch == "all_encoder":
             self.decoder = _Stack(state, "decoder", dev, split, vcfg["num_layers"], cross=False)
             self.dec_heads = self.heads * 8
+            if fused_decoder and vencfwd.decoder_supported(vcfg, precision, vcfg["num_frames"] // vcfg["frame_chunk_size"]):
+                self.vdec = vencfwd.VdecForward(self.h, vencfwd.VencStreams(state, "decoder", vcfg["num_layers"], self.dec_heads, dev))
         elif self.arch == "encoder_decoder":
             self.decoder = _Stack(state, "decoder", dev, split, (vcfg["num_layers"] - 1) * 4 + 1, cross=True)
             self.dec_heads = self.heads * 4
@@ -261,8 +266,11 @@ class TransformerVAE:
             self.h.call("copy_rows", latent, xseq, B, n_chunks, D, T, row_off, S, 0)
             pos = torch.empty_like(xseq)
             self.h.call("add_rows", xseq, self.pe_dec[:S].contiguous(), pos, capi.I64(xseq.numel()), capi.I64(S * D))
-            out = self._skip_stack(self.decoder, xseq,
-                                   lambda blk, t: self._enc_layer(blk, t, B, S, self.dec_heads, pos=pos))
+            if self.vdec is not None and S == 160:
+                out = self.vdec.run(xseq, pos, B)
+            else:
+                out = self._skip_stack(self.decoder, xseq,
+                                       lambda blk, t: self._enc_layer(blk, t, B, S, self.dec_heads, pos=pos))
             fr = torch.empty(B * F_, D, device=self.dev)
             self.h.call("copy_rows", out, fr, B, F_, D, S, n_chunks, F_, 0)
         else:
@@ -281,7 +289,7 @@ class GestureRepEncoder:
     """diffusion_transformer.py:131-330: four VAEs, 6D rotation packing, separator tokens."""
 
     def __init__(self, state, vae_cfgs, device="cuda", precision="bf16", prefix="gesture_rep_encoder.", part_streams=True,
-                 chain=True, grouped=True, fused_encoder=True):
+                 chain=True, grouped=True, fused_encoder=True, fused_decoder=True):
         """part_streams: run the four body-part VAEs as concurrent launch chains (False: one chain); chain: see
         TransformerVAE; grouped: where the parts run as ONE chain (asynchronous submission), layer i of all four parts goes out
         as one grouped launch (capi.OpRecorder): a quarter of the dependent launches, same bits."""
@@ -292,7 +300,7 @@ class GestureRepEncoder:
         for part in PARTS:
             p = "%s%s_vae." % (prefix, part)
             sd = {k[len(p):]: v for k, v in state.items() if k.startswith(p)}
-            self.vaes[part] = TransformerVAE(sd, vae_cfgs[part], device, precision, chain=chain, fused_encoder=fused_encoder)
+            self.vaes[part] = TransformerVAE(sd, vae_cfgs[part], device, precision, chain=chain, fused_encoder=fused_encoder, fused_decoder=fused_decoder)
         self.vae_latent_dim = vae_cfgs["upper"]["latent_dim"]
         self.frame_chunk_size = vae_cfgs["upper"]["frame_chunk_size"]
         self.uj = self.lj = self.fj = self.hj = self.tj = None

@@ -81,6 +81,51 @@ class VencStreams:
         self.pstream = P.view(NU + 1, 4, 8, 64).permute(0, 2, 1, 3).contiguous()       # per wave: [4 vectors][64 features]
 
 
+class VdecArgs(ctypes.Structure):
+    _fields_ = [("wstream", _vp), ("pstream", _vp), ("x", _vp), ("pos", _vp), ("qimg", _vp), ("kbuf", _vp), ("vt", _vp),
+                ("xbuf", _vp), ("dump", _vp), ("nseq", ctypes.c_int), ("nb", ctypes.c_int), ("step", ctypes.c_int),
+                ("pad_", ctypes.c_int)]
+
+
+def decoder_supported(vcfg, precision, n_chunks):
+    """Shapes rg_vdec_step is specialised for: the all_encoder decoder over n_chunks + num_frames = 160 tokens."""
+    return (precision == "bf16" and vcfg["decoder_arch"] == "all_encoder" and vcfg["latent_dim"] == 512 and vcfg["num_heads"] == 4
+            and vcfg["ff_size"] == 1024 and vcfg["transformer_activation"] == "gelu" and not vcfg["transformer_normalize_before"]
+            and n_chunks + vcfg["num_frames"] == 160 and 1 <= num_blocks(vcfg["num_layers"]) <= 8)
+
+
+class VdecForward:
+    """The block-fused decoder stack (include/rg_gesture.h: rg_vdec_step): 2 nb + 2 launches per decode."""
+
+    def __init__(self, h, streams):
+        self.h, self.st = h, streams
+
+    def run(self, xseq, pos, nseq, dumps=None):
+        """xseq fp32 [nseq * 160, 512] (contiguous; updated IN PLACE to the stack's output behind its final norm), pos fp32
+        [nseq * 160, 512] = xseq + positional table (gesture_vae.py:221-224).  dumps: optional list that receives the state
+        every launch starts its projection part from (diagnostics)."""
+        for t in (xseq, pos):
+            if not (t.is_contiguous() and t.dtype == torch.float32 and t.numel() == nseq * 160 * 512):
+                raise capi.RgError("rg_vdec_step: x / pos must be contiguous fp32 [nseq * 160, 512] tensors")
+        dev, nb = xseq.device, self.st.nb
+        qimg = torch.empty(4 * nseq * 48 * 1024, device=dev, dtype=torch.uint8)
+        kbuf = torch.empty(2 * nseq * 160 * 512, device=dev, dtype=torch.bfloat16)     # double-buffered by launch parity
+        vt = torch.empty(2 * nseq * 512 * 160, device=dev, dtype=torch.bfloat16)
+        xbuf = torch.empty(4 * nseq * nb * 8 * 12 * 64 * 4, device=dev)
+        for step in range(2 * nb + 2):
+            a = VdecArgs()
+            a.wstream, a.pstream = self.st.wstream.data_ptr(), self.st.pstream.data_ptr()
+            a.x, a.pos, a.qimg, a.kbuf, a.vt, a.xbuf = (t.data_ptr() for t in (xseq, pos, qimg, kbuf, vt, xbuf))
+            d = None
+            if dumps is not None:
+                d = torch.zeros(4 * nseq, 48, 512, device=dev)
+                dumps.append(d)
+            a.dump = d.data_ptr() if d is not None else None
+            a.nseq, a.nb, a.step = int(nseq), int(nb), step
+            self.h.call("vdec_step", ctypes.byref(a), keep=(a, xseq, pos, qimg, kbuf, vt, xbuf, d))
+        return xseq
+
+
 class VencForward:
     """Launches of one stack."""
 

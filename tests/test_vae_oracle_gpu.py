@@ -5,8 +5,10 @@ test_oracle_golden.py), through every launch path the product uses:
   * grouped       -- one chain, layer i of all four parts as ONE grouped launch (capi.OpRecorder: rg_gemm_grouped,
                      rg_layernorm_grouped, rg_mha_bf16_grouped, ...; the asynchronous pipeline),
   * single chain  -- one chain, launches one by one,
-  * fused encoder -- the whole encoder stack of a part as ONE launch (rg_venc_forward, csrc/rg_venc.hip: two chunk sequences
-                     per workgroup) -- the default where the shape supports it; `*_unfused` = the per-op chains instead,
+  * fused stacks  -- the whole encoder stack of a part as ONE launch (rg_venc_forward, csrc/rg_venc.hip: two chunk sequences
+                     per workgroup) and the all_encoder decoder stack as one launch per block (rg_vdec_step, csrc/rg_vdec.hip:
+                     four 40-row tiles per 160-token sequence) -- the defaults where the shape supports them; `*_unfused` = the
+                     per-op chains instead,
 
 at the sizes of BASELINE config 3: 16 clips (encode + decode) and 48 exemplars (encode), 8 layers, both decoder
 architectures (gesture_vae.py:124-239, detr_utils.py:101-210).  Until this file the grouped launches were only compared
@@ -41,8 +43,8 @@ def _state(rg, vae_cfgs):
 PATHS = {"part_streams": dict(part_streams=True), "grouped": dict(part_streams=False, grouped=True),
          "single_chain": dict(part_streams=False, grouped=False),
          # the encoder stacks as per-op launch chains instead of the fused one-launch encoder (rg_venc_forward)
-         "part_streams_unfused": dict(part_streams=True, fused_encoder=False),
-         "grouped_unfused": dict(part_streams=False, grouped=True, fused_encoder=False)}
+         "part_streams_unfused": dict(part_streams=True, fused_encoder=False, fused_decoder=False),
+         "grouped_unfused": dict(part_streams=False, grouped=True, fused_encoder=False, fused_decoder=False)}
 
 
 @pytest.fixture(scope="module")
@@ -111,5 +113,6 @@ def test_launch_paths_agree_bit_for_bit(rg, oracle_results, arch):
         for i, (a, b) in enumerate(zip(outs[path], outs[base])):
             assert torch.equal(a, b), (path, i, (a - b).abs().max().item())
     # fused and unfused encoders: the same arithmetic class (bf16 operands, fp32 accumulation), another order of operations
-    a, b = outs["grouped"][0], outs["grouped_unfused"][0]
-    assert ((a - b).norm() / b.norm()).item() <= 1e-2
+    for i, (a, b) in enumerate(zip(outs["grouped"], outs["grouped_unfused"])):
+        if i in (0, 5, 6, 7):        # latent, transl, exps, contact (the rotations are compared through matrices above)
+            assert ((a - b).norm() / b.norm()).item() <= 1.5e-2, i
