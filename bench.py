@@ -595,7 +595,7 @@ def main():
                 # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 gfx950
                 # correction + WRITE_SIZE; profiles/pmc_seq.py, pmc_seq_summarize.py; round 1-2: the rg_gemm shapes)
                 if roofline.get("workgroups_per_launch") is not None:
-                    with open(os.path.join(ROOT, "profiles", "r03_pmc_seq.json")) as f:
+                    with open(os.path.join(ROOT, "profiles", "r04_pmc_seq.json")) as f:
                         pm = json.load(f)
                     roofline["traffic"] = round(pm["fetch_bytes"] + pm["write_bytes"])
                     roofline["traffic_algorithmic"] = round(pm["algorithmic_hbm_bytes"])
