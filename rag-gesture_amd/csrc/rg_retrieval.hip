@@ -375,52 +375,11 @@ __global__ void __launch_bounds__(256) compact_kernel(const double* __restrict__
 //                   values: one block_top_rounds pass per 1014 of them), then scores its 4 entries AGAIN (the integer-coded
 //                   CSR is 1.2 MB: it stays in L2) and appends the survivors.
 // Same arithmetic, same comparisons: identical survivors (order arbitrary as before; the host sorts them by index).
-// The workgroup's slice of the integer-coded DB (1024 entries: speaker, relation offsets, and the relations they index) staged
-// in LDS with coalesced loads: the per-thread CSR walks then run at LDS instead of L2 latency.  Slices with more relations than
-// SLICE_REL (3072: 48 KiB) keep reading global memory.  The pointers handed back are rebased so that the absolute entry /
-// relation indices of discourse_score_value work on them unchanged.
-constexpr int SLICE_E = 256 * SEL_IPT;     // entries per workgroup
-constexpr int SLICE_REL = 3072;
-struct SliceView {
-  const int* spk;
-  const int* rel_off;
-  const int* rel_sense;
-  const int* rel_conn;
-  const double* rel_prom;
-};
-__device__ __forceinline__ SliceView stage_slice(unsigned char* lds, const int* __restrict__ spk, const int* __restrict__ rel_off,
-                                                 const int* __restrict__ rel_sense, const int* __restrict__ rel_conn,
-                                                 const double* __restrict__ rel_prom, int n_entries) {
-  const int e0 = blockIdx.x * SLICE_E, e1 = min(e0 + SLICE_E, n_entries);
-  const int r0 = rel_off[e0], r1 = rel_off[e1];
-  SliceView v{spk, rel_off, rel_sense, rel_conn, rel_prom};
-  if (r1 - r0 <= SLICE_REL) {      // (workgroup-uniform)
-    double* s_prom = reinterpret_cast<double*>(lds);                         // [SLICE_REL]
-    int* s_sense = reinterpret_cast<int*>(lds + SLICE_REL * 8);             // [SLICE_REL]
-    int* s_conn = s_sense + SLICE_REL;                                       // [SLICE_REL]
-    int* s_off = s_conn + SLICE_REL;                                         // [SLICE_E + 1]
-    int* s_spk = s_off + SLICE_E + 1;                                        // [SLICE_E]
-    for (int i = threadIdx.x; i < e1 - e0 + 1; i += 256) s_off[i] = rel_off[e0 + i];
-    for (int i = threadIdx.x; i < e1 - e0; i += 256) s_spk[i] = spk[e0 + i];
-    for (int i = threadIdx.x; i < r1 - r0; i += 256) {
-      s_sense[i] = rel_sense[r0 + i];
-      s_conn[i] = rel_conn[r0 + i];
-      s_prom[i] = rel_prom[r0 + i];
-    }
-    __syncthreads();
-    v = SliceView{s_spk - e0, s_off - e0, s_sense - r0, s_conn - r0, s_prom - r0};
-  }
-  return v;
-}
-constexpr int SLICE_LDS = SLICE_REL * 16 + (2 * SLICE_E + 1) * 4 + 12;
-
 __global__ void __launch_bounds__(256) sweep_tops_kernel(
     const int* __restrict__ spk, const int* __restrict__ rel_off, const int* __restrict__ rel_sense,
     const int* __restrict__ rel_conn, const double* __restrict__ rel_prom, int n_entries,
     const double* __restrict__ params, double* __restrict__ block_tops, int* __restrict__ cursor, size_t ws_stride) {
   __shared__ double red[4];
-  __shared__ __attribute__((aligned(16))) unsigned char slice[SLICE_LDS];
-  const SliceView db = stage_slice(slice, spk, rel_off, rel_sense, rel_conn, rel_prom, n_entries);
   const double* qp = params + 4 * blockIdx.y;
   const int q_sense = (int)qp[0], q_conn = (int)qp[1], q_spk = (int)qp[2];
   const double q_prom = qp[3];
@@ -431,7 +390,7 @@ __global__ void __launch_bounds__(256) sweep_tops_kernel(
     v[i] = -1.0;
     if (e < n_entries) {
       int tp;
-      discourse_score_value(e, db.spk, db.rel_off, db.rel_sense, db.rel_conn, db.rel_prom, q_sense, q_conn, q_spk, q_prom, v[i], tp);
+      discourse_score_value(e, spk, rel_off, rel_sense, rel_conn, rel_prom, q_sense, q_conn, q_spk, q_prom, v[i], tp);
     }
   }
   block_top_rounds(v, red, tops);
@@ -448,8 +407,6 @@ __global__ void __launch_bounds__(256) sweep_compact_kernel(
     const double* __restrict__ params, const double* __restrict__ block_tops, int n_lists, int* __restrict__ cursor,
     int cap, int* __restrict__ out_idx, int* __restrict__ out_top, double* __restrict__ out_score, size_t ws_stride) {
   __shared__ double red[4];
-  __shared__ __attribute__((aligned(16))) unsigned char slice[SLICE_LDS];
-  const SliceView db = stage_slice(slice, spk, rel_off, rel_sense, rel_conn, rel_prom, n_entries);
   block_tops += blockIdx.y * ws_stride;
   // threshold = 10th largest of the query's per-slice lists (as topk_merge_kernel)
   double carry[SEL_K];
@@ -487,7 +444,7 @@ __global__ void __launch_bounds__(256) sweep_compact_kernel(
     if (e >= n_entries) continue;
     double sc;
     int tp;
-    discourse_score_value(e, db.spk, db.rel_off, db.rel_sense, db.rel_conn, db.rel_prom, q_sense, q_conn, q_spk, q_prom, sc, tp);
+    discourse_score_value(e, spk, rel_off, rel_sense, rel_conn, rel_prom, q_sense, q_conn, q_spk, q_prom, sc, tp);
     if (sc >= thr && sc > 0.0) {
       const int pos = atomicAdd(cursor, 1);
       if (pos < cap) {

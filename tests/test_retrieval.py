@@ -123,12 +123,12 @@ def test_hip_sweep_matches_oracle_large_db(rg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_entries,dense", [(50, False), (4096, False), (32768, False), (4096, True)])
-def test_fused_sweep_selects_exactly_what_the_two_step_form_selects(rg, n_entries, dense):
+def test_fused_sweep_selects_exactly_what_the_two_step_form_selects(rg, n_entries, dense):  # (dense: three times the relations per entry)
     """rg_discourse_select_fused (scores in registers, two launches) against rg_discourse_scores_batched +
     rg_select_top_scores_batched (scores through memory, four launches) and against the full score rows: the same survivors
     with bit-identical float64 scores and the same relation indices for every query relation of a batch (BASELINE DB size
     included; 50 entries: the `fewer than 64 entries: keep every positive score` branch; dense: every entry's relations three
-    times over, so that a 1024-entry slice holds more relations than the kernels stage in LDS and they read global memory)."""
+    times over)."""
     import numpy as np
     smp = rg.synth.synth_retrieval_samples(n_entries, seed=2025)
     if dense:
