@@ -378,9 +378,8 @@ __global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_group grp) {
     if (blk > nb) {
       Acc xs;
       skip_io(xs, 2 * nb - blk, false);          // output block i pops the state saved behind input block nb - 1 - i
-      // re-fill the ring behind the register-destination loads above (their vmcnt(0) drained it: nothing is lost, the
-      // fragments were waited for, but the counted waits below assume RD - 1 in flight) -- nothing to do: consume() waits
-      // for the OLDEST fragment only and every slot was re-issued by release() / gemm_unit before
+      // (the vmcnt(0) behind these register-destination loads also lands every ring fragment in flight: harmless, consume()
+      //  only ever waits for the OLDEST one and every slot is re-issued as it is read)
       bar();                                      // P1's last readers (FF2 of the previous block) are done
       write_raw(P1, xs);
       bar();
