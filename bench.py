@@ -112,7 +112,7 @@ class Workload:
         # every random draw of a batch comes from this generator, inside submit(): the state in front of a submission is all
         # it takes to repeat that batch later (verify(): the last timed batches against synchronous forwards)
         self.noise = rg.pipeline.DeviceNoise(dev, seed=4242 + rank)
-        self._done = collections.deque(maxlen=max(1, int(os.environ.get("RG_BENCH_VERIFY_BATCHES", "2"))))
+        self._done = collections.deque(maxlen=max(1, int(os.environ.get("RG_BENCH_VERIFY_BATCHES", "4"))))   # (one per batch lane)
         self.cfg = rg.synth.default_model_cfg(num_layers=8)
         self.vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
         self.guided = kind in ("guided", "longform")
@@ -191,7 +191,7 @@ class Workload:
                           out["pred_transl"], out["pred_exps"]], dim=-1)
 
     def verify(self):
-        """OUTSIDE the timed region: the last batches the timed loop produced (two: one per batch lane) against ONE
+        """OUTSIDE the timed region: the last batches the timed loop produced (four: one per batch lane) against ONE
         SYNCHRONOUS forward each of the same inputs and the same noise (the generator state saved in front of their
         submission) -- `torch.equal`, bit for bit.  What is timed is therefore a throughput of verified results: a race
         between lanes, a stale graph buffer or a mis-ordered hand-out shows up here (every batch has its own noise, so no
@@ -269,12 +269,16 @@ class Workload:
             # every (phase, slot) pair of the pipeline has a graph of its own (inversion alone while the pipeline fills,
             # co-batched chain, sampling alone at the drain; slots alternate call by call): fill-and-drain sequences of odd
             # and even length until no call captures anything new
-            seen, quiet, n = -1, 0, 2
+            # (whole batches rotate over the lanes: a lane sees its second batch -- the co-batched chain -- only in a
+            #  sequence longer than the number of lanes)
+            lanes = self.rotation() if self.kind == "guided" else 2
+            short, long_ = (2, 3) if lanes <= 2 else (lanes, 2 * lanes + 1)
+            seen, quiet, n = -1, 0, short
             while quiet < 2 and self.kind != "longform":
                 for _ in range(n if self.model.async_results else 1):
                     self.step()
                 self.drain()
-                n = 5 - n
+                n = short + long_ - n
                 quiet = quiet + 1 if len(self.model._graphs) == seen else 0
                 seen = len(self.model._graphs)
             while quiet < 2 and self.kind == "longform" and self.model.async_results and n < 12:
@@ -284,6 +288,13 @@ class Workload:
                 quiet = quiet + 1 if len(self.model._graphs) == seen else 0
                 seen = len(self.model._graphs)
             self.primed = True
+
+    def rotation(self):
+        """Lanes that whole batches of this workload rotate over (submit())."""
+        m = self.model
+        if not self.cobatch or m.cobatch_lanes != "batch":
+            return 1
+        return m.batch_lanes if self.guided else m.base_lanes
 
     def timed(self, steps, warmup, fence):
         self.prime()
@@ -301,7 +312,7 @@ class Workload:
     def gemm_roofline(self, local_rank):
         """HIP events around every launch of the dominant kernel in eager steps of the SAME submission mode as the timed run
         (graph replays cannot hold events; the launches are the same), taken in the steady state: the pipeline is primed with
-        4 eager steps before the events start, 2 steps (one per batch lane) are recorded.
+        two eager steps per batch lane before the events start, one step per batch lane is recorded.
         bf16 mode: rg_seq_kernel (the whole denoiser forward of up to 256 sequences in one launch; variant 3), or the bf16-A
         rg_gemm kernels when the launch chain is selected (variant 1); fp32 mode: the bf16x3 GEMMs of the launch chain
         (variant 2, 3 MFMAs per product: priced at a third of the bf16 peak)."""
@@ -311,7 +322,9 @@ class Workload:
         variant = 2 if self.precision != "bf16" else (3 if seq else 1)
         peak = MFMA_BF16_PEAK if variant != 2 else MFMA_BF16_PEAK / 3
 
-        def events(nprime=4, nprof=2):
+        rot = max(2, self.rotation())
+
+        def events(nprime=2 * rot, nprof=rot):
             self.drain()
             model.use_graphs = False
             for _ in range(nprime):
@@ -335,14 +348,25 @@ class Workload:
         r = {"bound": "mfma", "kernel": kernel,
              "achieved": round(ach / 1e12, 3), "peak": round(peak / 1e12, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 5),
              "launches": n, "avg_launch_us": round(ms * 1e3 / max(1, n), 2), "flops_per_launch_avg": round(fl / max(1, n)),
-             "lanes": model.lanes, "flops_per_step": round(fl / 2)}      # (2 recorded steps)
+             "lanes": self.rotation(), "flops_per_step": round(fl / rot)}      # (`rot` recorded steps)
         if seq:
             # a launch holds one workgroup per sequence and a workgroup owns a CU (155 KiB of LDS): a lane of 2 x (16 + 48)
             # sequences runs on 128 of the 256 CUs and the other lane's launch on the rest, at the same time
             per_clip = 2.0 * 43 * 512 * 512 * (130 + 82) + 8 * 7 * 2.0 * 43 * 32 * 32 * 16   # one conditional + one classifier-free sequence
-            r["workgroups_per_launch"] = 2 * round(fl / max(1, n) / per_clip)
-            r["note"] = ("per launch; a launch occupies one CU per sequence, so %d concurrent lanes share the chip: the chip-level "
-                         "rate is the sum over the lanes' concurrent launches" % model.lanes)
+            pairs = [s.sq.args.pairs for k, s in model._sessions.items() if s.sq is not None and k[1] == "cobatch"]
+            paired = bool(pairs) and all(pairs) and self.cobatch
+            seqs = 2 * round(fl / max(1, n) / per_clip)
+            cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+            r["sequences_per_launch"] = seqs
+            r["workgroups_per_launch"] = seqs // 2 if paired else seqs
+            # a workgroup owns a compute unit for the whole launch (155 KiB of LDS): the share of the chip a launch can use
+            r["cu_share"] = round(min(1.0, r["workgroups_per_launch"] / cus), 4)
+            r["frac_of_occupied_cus"] = round(ach / (peak * r["cu_share"]), 5) if r["cu_share"] else None
+            r["note"] = ("per launch; a launch occupies one CU per workgroup (%s), so %d concurrent lanes share the chip: `frac` prices "
+                         "one lane's launch against the WHOLE chip's peak, `frac_of_occupied_cus` against the peak of the CUs it "
+                         "holds; the chip-level rate is the sum over the lanes' concurrent launches (`whole_step`)"
+                         % ("one workgroup per clip: conditional sequence, then its classifier-free twin" if paired
+                            else "one workgroup per sequence", self.rotation()))
         return r
 
 
@@ -570,7 +594,7 @@ def main():
         # Informational, never `value`: the same K submissions with the pipeline already full when the clock starts and
         # still full when it stops (K results come out, the two pending batches are drained after the clock) -- `value`
         # above pays the pipeline's fill and drain inside its K steps.
-        for _ in range(4):
+        for _ in range(2 * wl.rotation()):
             wl.step()
         torch.cuda.synchronize()
         ts = time.perf_counter()
@@ -634,7 +658,7 @@ def main():
                 # the same pipeline with 32 clips per step on ONE lane: every rg_seq launch then holds 2 x (32 + 96) = 256
                 # sequences = one per CU, which is what `roofline.frac` means for a launch that fills the chip
                 w32 = Workload(rg, "guided", 32, dev, rank, args.db_size, database=wl.database)
-                w32.model.lanes = 1
+                w32.model.lanes = w32.model.batch_lanes = 1
                 also["guided_B32_one_lane"] = dict(record(w32, steps=8, warmup=2),
                                                    workload="the headline workload with 32 clips per step on one lane: 256 sequences per launch")
                 del w32
@@ -676,8 +700,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2),
             "batch_latency_ms": {"median": lat_med, "max": lat_max,
                                  "note": "device time from a batch's submission to its packed result; the co-batched pipeline "
-                                         "hands a batch out two submissions later (its sampling shares launches with a later "
-                                         "batch's inversion), so latency > 2 x ms_per_step while throughput = 1 / ms_per_step"},
+                                         "hands a batch out one rotation of the batch lanes later (its sampling shares launches with "
+                                         "the next batch's inversion on its lane), so latency > lanes x ms_per_step while "
+                                         "throughput = 1 / ms_per_step"},
             "steady_state_ms_per_step": steady,   # informational (pipeline full at both ends of the clock); never `value`
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -688,10 +713,11 @@ def main():
                        "submission": (("asynchronous, submit(): whole batches alternate between %d lanes (one 50-launch chain "
                                        "each); every batch completes inside the timed region" % wl.model.base_lanes)
                                       if wl.cobatch and kind == "base" else
-                                      ("asynchronous, co-batched: the sampling loop of batch n and the exemplar inversion of batch "
-                                       "n+2 advance in the same denoiser launches (sampler.cobatched_loop), the front end of "
-                                       "batch n+1 runs beside them; the pipeline fills and drains inside the timed region, "
-                                       "which holds exactly `steps` complete batches") if wl.cobatch else
+                                      ("asynchronous, co-batched: whole batches rotate over %d lanes; the sampling loop of batch n and the "
+                                       "exemplar inversion of batch n+%d advance in the same denoiser launches (sampler.cobatched_loop), "
+                                       "the front ends of the batches between them run beside the lanes' chains; the pipeline fills and "
+                                       "drains inside the timed region, which holds exactly `steps` complete batches"
+                                       % (wl.rotation(), wl.rotation())) if wl.cobatch else
                                       ("asynchronous, %d slots: the front end (conditions, VAE encodes, retrieval) of batch n+1 and "
                                        "the decode of batch n run beside the inversion -> sampling chain; every batch completes "
                                        "inside the timed region" % wl.model.slots)) if wl.model.async_results

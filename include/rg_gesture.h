@@ -343,7 +343,9 @@ typedef struct rg_seq_args {
   int l0, l1;              /* this launch runs layers [l0, l1): + the embedding when l0 == 0, + the head when l1 == L.  A forward
                               cut into several launches frees every compute unit between them (a workgroup holds its CU for the
                               whole launch), which lets OTHER streams' kernels in between them (measured without gain on the step: NOTEBOOK 8.4) */
-  int pad_;
+  int pairs;               /* 0: one workgroup per sequence (2 B workgroups); 1: one workgroup per clip runs the conditional
+                              sequence, then its classifier-free twin (B workgroups, 1.7x as long: less CU time per forward,
+                              for callers that run several narrow launches side by side) -- same results bit for bit */
 } rg_seq_args;
 
 int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);

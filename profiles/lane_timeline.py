@@ -21,6 +21,8 @@ model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
 model.eval()
 if "SEQ_LAUNCHES" in os.environ:
     model.session_options["seq_launches"] = int(os.environ["SEQ_LAUNCHES"])
+if "SEQ_PAIRS" in os.environ:
+    model.session_options["seq_pairs"] = bool(int(os.environ["SEQ_PAIRS"]))
 if "MAX_INFLIGHT" in os.environ:
     model.max_inflight = int(os.environ["MAX_INFLIGHT"])
 if "SLOTS" in os.environ:
@@ -74,11 +76,11 @@ def one_step(trace=False, sync=True):
     return t_host, (time.perf_counter() - t_step[0]) * 1e3
 
 
-for _ in range(3 if not os.environ.get("COBATCH") else 9):     # (the co-batched pipeline has graphs per phase, lane and slot)
+for _ in range(int(os.environ.get("WARM", "3" if not os.environ.get("COBATCH") else "9"))):     # (the co-batched pipeline has graphs per phase, lane and slot)
     one_step()
 if os.environ.get("COBATCH"):
     model.flush()
-    for _ in range(5):
+    for _ in range(int(os.environ.get("WARM2", "5"))):
         one_step()
 model._graph_run = traced
 model.model.gesture_rep_encoder.graph_runner = traced

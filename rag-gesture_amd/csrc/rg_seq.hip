@@ -170,12 +170,16 @@ __device__ __forceinline__ void zero(Acc& a) {
 
 }  // namespace
 
-__global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// One forward of one sequence (a whole workgroup): the body of rg_seq_kernel.
+__device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq, unsigned char* const smem) {
   unsigned char* const P0 = smem + OFF_P0;
   unsigned char* const P1 = smem + OFF_P1;
   float* const sStat = reinterpret_cast<float*>(smem + OFF_STAT);
-  const int tid = threadIdx.x, lane0 = tid & 63;
+  // (an opaque copy: nothing derived from the thread id is an invariant of the caller's pass loop, where it would stay live
+  //  -- spilled -- across the whole forward)
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane0 = tid & 63;
   // Lane-derived values are re-derived from an opaque copy of the lane id wherever they are used: as loop invariants of
   // the layer loop the address arithmetic of every unrolled LDS access would otherwise be hoisted in front of the loop
   // and live (spilled) across it.
@@ -187,15 +191,6 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   unsigned char* const ring = smem + OFF_RING + wave * (RD * 1024);
   const int T = a.T, B = a.B, L = a.L, R = 2 * a.B;
-  // Workgroup -> sequence.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, speed only,
-  // never correctness): the conditional sequences go to four of the eight groups and the classifier-free ones (which skip
-  // a third of the weight stream and run ahead) to the other four, so the workgroups that share an L2 walk the stream
-  // together and each L2 pulls one copy of it instead of two.
-  int seq = blockIdx.x;
-  if ((B & 3) == 0) {
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    seq = x < 4 ? 4 * q + x : B + 4 * q + (x - 4);
-  }
   const bool cond = seq < B;
   const int clip = cond ? seq : seq - B;
   const int st = clip >= a.split ? a.step_b : a.step;
@@ -818,6 +813,31 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
 #endif
 }
 
+__global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int B = a.B;
+  // Workgroup -> sequence(s).
+  // pairs == 0: one workgroup per sequence.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one,
+  // speed only, never correctness): the conditional sequences go to four of the eight groups and the classifier-free ones
+  // (which skip a third of the weight stream and run ahead) to the other four, so the workgroups that share an L2 walk the
+  // stream together and each L2 pulls one copy of it instead of two.
+  // pairs == 1: one workgroup per clip: its conditional sequence, then its classifier-free twin (0.7 of the time).  A launch
+  // of B workgroups then holds B compute units for 1.7 units of time instead of 2 B for 1.0, of which the classifier-free
+  // half idles the last 0.3: 15 % less CU time per forward, for callers whose launches are narrow enough to run side by
+  // side.  Every workgroup of the launch walks the same part of the stream at the same time.
+  int seq0 = blockIdx.x;
+  if (!a.pairs && (B & 3) == 0) {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    seq0 = x < 4 ? 4 * q + x : B + 4 * q + (x - 4);
+  }
+  const int npass = a.pairs ? 2 : 1;
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+    run_sequence(a, seq0 + pass * B, smem);
+    __syncthreads();     // descriptors, panels and statistics of the pass are dead in every wave
+  }
+}
+
 extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream) {
   RG_REQUIRE(h, args_host, "null args");
   const rg_seq_args& a = *args_host;
@@ -827,6 +847,7 @@ extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* 
   RG_REQUIRE(h, a.dump_stage == 0 || a.dump, "dump_stage needs a dump buffer");
   RG_REQUIRE(h, 0 <= a.l0 && a.l0 < a.l1 && a.l1 <= a.L, "layer range [l0, l1) must be a non-empty part of [0, L)");
   RG_REQUIRE(h, (a.l0 == 0 && a.l1 == a.L) || a.xbuf, "a partial layer range needs the hand-over buffer xbuf");
+  RG_REQUIRE(h, a.pairs == 0 || a.pairs == 1, "pairs must be 0 or 1");
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)rg_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
@@ -850,7 +871,7 @@ extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* 
     rec.flops = a.B * (cond + unc);
     (void)hipEventRecord(rec.start, rg_stream(stream));
   }
-  hipLaunchKernelGGL(rg_seq_kernel, dim3(2 * a.B), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
+  hipLaunchKernelGGL(rg_seq_kernel, dim3(a.pairs ? a.B : 2 * a.B), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
   if (h->profiling) {
     (void)hipEventRecord(rec.stop, rg_stream(stream));

@@ -246,7 +246,7 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False, xcd_affine=True, engine=None,
-                 styl_in_gemm=False, seq_launches=1, kv_grouped=True):
+                 styl_in_gemm=False, seq_launches=1, kv_grouped=True, seq_pairs=False):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
@@ -255,6 +255,9 @@ class DenoiserSession:
         through a 96 KiB-per-sequence buffer).  A workgroup holds its compute unit for a whole launch; cutting the forward
         frees every CU a few times per millisecond, which lets the kernels of other streams (the next batch's front end) in
         promptly.  Same bits for every value.
+        seq_pairs (engine "seq"): one workgroup per CLIP runs the conditional sequence and then its classifier-free twin (B
+        workgroups for ~1.7x the time instead of 2 B of which the classifier-free half idles the last 0.3): less CU time per
+        forward for pipelines that run enough narrow chains side by side to fill the chip.  Same bits.
         The remaining options belong to the launch chain:
         ln_mode: "folded" = LayerNorm folded into the consuming GEMM's epilogue (two passes per
         layer fewer; its bf16 operand is the UN-normalised row, so the error grows with |row mean| / std),
@@ -293,7 +296,7 @@ class DenoiserSession:
         self.sq = None
         if self.engine == "seq":           # activations never leave the CU: no per-op buffers
             self.ln_mode = "exact"
-            self.sq = SQ.SeqForward(self, launches=seq_launches)
+            self.sq = SQ.SeqForward(self, launches=seq_launches, pairs=seq_pairs)
             return
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
         # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide, or 64 wide

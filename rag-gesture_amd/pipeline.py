@@ -321,7 +321,15 @@ class MotionDiffusion(torch.nn.Module):
                         front of / behind it.  Batches alternate between `slots` sets of sessions and graph buffers so that
                         a front end never writes what the chain in flight still reads; at most `max_inflight` batches
                         are queued before forward() blocks on the oldest.
-      lane_streams      the caller's own streams for the lanes / the search / the base lanes (max(lanes, base_lanes) + 1 of them)
+      batch_lanes       submit() of batches WITH exemplar inversion (the co-batched pipeline): whole batches rotate over this
+                        many lanes, each running [sampling of its pending batch || inversion of the new one] as one chain of 50
+                        launches.  2 lanes x 128 workgroups (one per sequence) fill the chip but leave the classifier-free half
+                        idle for the last 0.3 of every launch; 4 lanes x 64 workgroups (one per CLIP: conditional sequence, then
+                        its twin -- DenoiserSession seq_pairs, chosen automatically where the lanes' launches would not fit the
+                        chip side by side) keep every compute unit busy: 36.2 vs 38.7 ms per guided step of 16 clips over 24
+                        steps, 34.8 vs 37.8 over 48 (profiles/r04s_pairs_lanes.txt); latency per batch 320 vs 190 ms
+      lane_streams      the caller's own streams for the lanes / the search / the base and batch lanes
+                        (max(lanes, base_lanes, batch_lanes) + 2 of them)
       calibrate_lanes   (default) pick streams that were measured to run concurrently (distinct hardware queues) first --
                         two lanes that share a hardware queue run their chains one after the other (61 instead of 41 ms per
                         guided step, profiles/r04i_lane_timeline.txt); performance only: the NUMBER of lanes and the presence of
@@ -334,7 +342,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=3,
-                 lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
+                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -359,6 +367,7 @@ class MotionDiffusion(torch.nn.Module):
         # submit() of batches WITHOUT exemplar inversion (base diffusion: 2 B sequences per launch, 64 at B = 32) lets whole
         # batches alternate between this many lanes -- a launch holds one CU per sequence, so three or four such chains fit the chip (3 measured as good as 4: profiles/r03g)
         self.base_lanes = max(1, int(base_lanes))
+        self.batch_lanes = max(1, int(batch_lanes))
         self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
         # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
@@ -366,7 +375,7 @@ class MotionDiffusion(torch.nn.Module):
         # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
         # (one pipeline per lane when whole batches alternate between the lanes, cobatch_lanes="batch"; else one, key None)
         self._pend, self._cob, self._ready, self._tail_turn = {}, None, collections.deque(), 0
-        self._slots, self._submitted = {}, 0
+        self._slots, self._submitted, self._last_out_seq = {}, 0, -1
         self.cobatch_lanes = str(cobatch_lanes)
         capi.require(self.cobatch_lanes in ("batch", "split"),
                 "unsupported argument: requires self.cobatch_lanes in (\"batch\", \"split\")")
@@ -539,10 +548,24 @@ class MotionDiffusion(torch.nn.Module):
                 for gk in [g for g, o in self._graph_owner.items() if o == old]:
                     self._graphs.pop(gk, None)
                     del self._graph_owner[gk]
-            self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B, **self.session_options)
+            opts = dict(self.session_options)
+            if opts.get("seq_pairs", "auto") == "auto":
+                opts["seq_pairs"] = self._seq_pairs_auto(B)
+            self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B, **opts)
         else:
             self._sessions[key] = self._sessions.pop(key)        # most recently used goes last
         return self._sessions[key]
+
+    def _seq_pairs_auto(self, B):
+        """One workgroup per clip instead of one per sequence (DenoiserSession seq_pairs; same bits) for the sessions of a
+        batch lane whose launches would not fit the chip beside the other lanes' otherwise: 2 B workgroups x the lanes in
+        rotation > compute units.  Narrow launches (the sampling of a last batch, synchronous forwards, the base workload) keep
+        one workgroup per sequence: 1.0 instead of 1.65 ms per launch."""
+        cob = self._cob
+        if not (self.async_results and cob is not None and cob.get("lane") is not None):
+            return False
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        return 2 * B * self.batch_lanes > cus
 
     def _set_conditions(self, B, role, lane, word, audio, speaker_ids, motion_mask, query_masks):
         """DenoiserSession.set_conditions through the graph cache: its ~55 launches (pre-projections, per-layer K/V
@@ -602,16 +625,17 @@ class MotionDiffusion(torch.nn.Module):
 
     def _make_streams(self):
         """The stream topology: `lanes` lane streams, one search stream, then the additional lanes of the base workload --
-        max(lanes, base_lanes) + 1 streams, ALWAYS that many, whatever the machine, the load on the host or the number of
+        max(lanes, base_lanes, batch_lanes) + 2 streams, ALWAYS that many, whatever the machine, the load on the host or the number of
         ranks starting at once (the schedule a test pins is the schedule every box runs).  Sources, in order: the
         `lane_streams=` constructor argument (the caller's own streams); `calibrate_lanes=True`: streams measured to be
         concurrent first, unmeasured ones to make up the count; otherwise fresh streams."""
         lanes = max(1, int(self.lanes))
-        need = max(lanes, self.base_lanes) + 2            # lanes (+ base lanes), the search stream, the decode stream
-        report = dict(lanes=lanes, base_lanes=self.base_lanes, streams=need, source="fresh", measured_concurrent=None)
+        need = max(lanes, self.base_lanes, self.batch_lanes) + 2     # lanes (+ base / batch lanes), the search stream, the decode stream
+        report = dict(lanes=lanes, base_lanes=self.base_lanes, batch_lanes=self.batch_lanes, streams=need, source="fresh",
+                      measured_concurrent=None)
         if self._given_streams is not None:
             found = list(self._given_streams)
-            capi.require(len(found) >= need, "lane_streams: %d streams needed (max(lanes, base_lanes) + the search stream + the decode stream), got %d"
+            capi.require(len(found) >= need, "lane_streams: %d streams needed (max(lanes, base_lanes, batch_lanes) + the search stream + the decode stream), got %d"
                          % (need, len(found)))
             report["source"] = "caller"
         elif self.calibrate_lanes:
@@ -623,23 +647,23 @@ class MotionDiffusion(torch.nn.Module):
         found = found[:need]
         self._search_stream, self._decode_stream = found[lanes], found[lanes + 1]
         self._lane_streams = found[:lanes] + found[lanes + 2:]
-        self._lanes_calibrated = (lanes, self.base_lanes)
+        self._lanes_calibrated = (lanes, self.base_lanes, self.batch_lanes)
         self.lane_report = report
 
     def stream_set(self):
         """The streams of this model in the order the `lane_streams=` constructor argument takes them: several models of one
         process (bench.py builds six) can share one measured set instead of each measuring its own."""
         lanes = max(1, int(self.lanes))
-        if self._lanes_calibrated != (lanes, self.base_lanes):
+        if self._lanes_calibrated != (lanes, self.base_lanes, self.batch_lanes):
             self._make_streams()
         return self._lane_streams[:lanes] + [self._search_stream, self._decode_stream] + self._lane_streams[lanes:]
 
     def _lane_plan(self, B, n_lanes=None):
         """[(lane index, stream, b0, b1)]: contiguous, near-equal groups of clips (n_lanes of them, default self.lanes)."""
         lanes = max(1, int(self.lanes))
-        if self._lanes_calibrated != (lanes, self.base_lanes):
+        if self._lanes_calibrated != (lanes, self.base_lanes, self.batch_lanes):
             self._make_streams()
-        want = max(lanes, self.base_lanes if self.async_results else 1)
+        want = max(lanes, max(self.base_lanes, self.batch_lanes) if self.async_results else 1)
         n = max(1, min(lanes if n_lanes is None else int(n_lanes), want, B, len(self._lane_streams)))
         cuts = [(B * i) // n for i in range(n + 1)]
         return [(i, self._lane_streams[i], cuts[i], cuts[i + 1]) for i in range(n)]
@@ -707,8 +731,8 @@ class MotionDiffusion(torch.nn.Module):
         if cob is not None and cob.get("lane") is not None:
             # whole batches alternate between the lanes: this one runs (inversion now, sampling two calls later) on one
             # lane's stream, the batch submitted before it is still busy on the other
-            if not use_inversion:
-                plan = self._lane_plan(B, self.base_lanes)   # nothing to share launches with: more, smaller chains
+            # (base: nothing to share launches with, more and smaller chains; with inversion: the co-batched chains)
+            plan = self._lane_plan(B, self.batch_lanes if use_inversion else self.base_lanes)
             pid = cob["lane"] % len(plan)
             plan = plan_s = [(pid, plan[pid][1], 0, B)]
         if run_async:
@@ -915,7 +939,7 @@ class MotionDiffusion(torch.nn.Module):
         be co-batched (no inversion, a lane without exemplars, another batch size) are completed on their own."""
         if not self.async_results or self.slots < 2:
             raise capi.RgError("submit() needs MotionDiffusion(async_results=True, slots >= 2)")
-        self._cob = dict(lane=self._submitted if (self.cobatch_lanes == "batch" and self.lanes > 1) else None)
+        self._cob = dict(lane=self._submitted if (self.cobatch_lanes == "batch" and self.batch_lanes > 1) else None)
         self._submitted += 1
         try:
             self.forward(**kwargs)
@@ -974,7 +998,11 @@ class MotionDiffusion(torch.nn.Module):
         same = pend is not None and can_defer and (pend.B, pend.T) == (st.B, st.T) and \
             [(b0, b1) for _, _, b0, b1 in pend.plan] == [(b0, b1) for _, _, b0, b1 in st.plan]
         if pend is not None and not same:
-            self._ready.append(self._finish_alone(self._pend.pop(st.pid)))   # finishes alone (in the other slot's sessions)
+            # finishes alone (in the other slot's sessions) -- behind everything submitted before it: results are handed out
+            # in submission order, and this lane's pending batch is the oldest only while the rotation is undisturbed (a
+            # batch without inversion picks its lane among `base_lanes`, not `batch_lanes`)
+            for p in sorted((p for p in self._pend if self._pend[p].seq <= pend.seq), key=lambda p: self._pend[p].seq):
+                self._ready.append(self._finish_alone(self._pend.pop(p)))
             self._slot = self._slots[st.pid] = st.slot
             pend = None
         if not can_defer:                              # nothing to share launches with later: complete it now,
@@ -1146,6 +1174,9 @@ class MotionDiffusion(torch.nn.Module):
         if st.run_async and self.decode_on_own_stream and self._decode_stream is not None:
             tail_lane, tail = -2, self._decode_stream
         self._tail_turn += 1
+        if st.run_async:     # (submission order is the contract of submit() / flush(): a scheduling bug must not pass as a result)
+            capi.require(st.seq >= self._last_out_seq, "internal: results handed out against the submission order")
+            self._last_out_seq = st.seq
         if self._jitter is not None:
             self._jitter(tail, "tail")
         for _, stream, _, _ in st.plan + st.plan_s:
@@ -1190,7 +1221,10 @@ class MotionDiffusion(torch.nn.Module):
             for lane in self._lanes_of(st.plan, st.plan_s):
                 self._slot_done[(lane, st.slot)] = [done]
             self._inflight.append(done)
-            while len(self._inflight) > (self.max_inflight if st.use_inversion else max(self.max_inflight, self.base_lanes)):
+            # (whole batches in rotation: every lane's next chain is queued behind its running one before the host waits)
+            #  measured: 4 lanes 38.4 ms per step with 4 in flight, 36.2 with 6; 2 lanes 38.7 with 2, 43.7 with 4)
+            rot = self.base_lanes if not st.use_inversion else (2 * self.batch_lanes - 2 if st.pid is not None else 0)
+            while len(self._inflight) > max(self.max_inflight, rot):
                 self._inflight.popleft().synchronize()
         elif tail is not main:
             main.wait_event(done)

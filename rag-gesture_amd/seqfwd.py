@@ -29,7 +29,7 @@ class SeqArgs(ctypes.Structure):
                 ("L", ctypes.c_int), ("B", ctypes.c_int), ("T", ctypes.c_int), ("S", ctypes.c_int),
                 ("step", ctypes.c_int), ("step_b", ctypes.c_int), ("split", ctypes.c_int),
                 ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("l0", ctypes.c_int), ("l1", ctypes.c_int),
-                ("pad_", ctypes.c_int)]
+                ("pairs", ctypes.c_int)]
 
 
 def supported(cfg, T, precision):
@@ -153,8 +153,9 @@ class SeqStreams:
 class SeqForward:
     """Buffers of one DenoiserSession for rg_seq_forward."""
 
-    def __init__(self, sess, launches=1):
-        """launches: kernel launches per forward (the L layers cut into near-equal ranges; 1 = the whole forward in one)."""
+    def __init__(self, sess, launches=1, pairs=False):
+        """launches: kernel launches per forward (the L layers cut into near-equal ranges; 1 = the whole forward in one);
+        pairs: one workgroup per clip (conditional sequence, then its classifier-free twin) instead of one per sequence."""
         w = sess.w
         self.sess, self.h, self.st = sess, sess.h, w.seq_streams
         B, dev = sess.B, w.dev
@@ -168,6 +169,7 @@ class SeqForward:
         a.wstream, a.pstream, a.ustream, a.afrag = p(self.st.wstream), p(self.st.pstream), p(self.st.ustream), p(self.afrag)
         a.tbias, a.src_mask, a.qmask, a.head = p(w.tbias), p(sess.src_mask), p(sess.qmask), p(sess.head)
         a.L, a.B, a.T, a.S = w.L, B, w.T, self.st.S
+        a.pairs = int(bool(pairs))
         a.dump, a.dump_stage, a.dump_layer = None, 0, 0
         a.xbuf = p(self.xbuf) if self.xbuf is not None else None
 

@@ -527,6 +527,10 @@ def synth_query(seed, n_rel=3, n_speakers=25, feat_dim=768):
     t = 0.3
     for r in range(n_rel):
         conn = conns[int(g.integers(0, len(conns)))] if r else "because"
+        if r == 2 and conn == disc[1][0]:
+            # relation 1 carries no prominence entry (the None path): the same connective again would hand relation 2's entry
+            # to relation 1 and leave the map short, where the reference drops into a debugger (rag/utils.py:171-228)
+            conn = conns[(conns.index(conn) + 1) % len(conns)]
         sense = SENSES[int(g.integers(0, len(SENSES)))] if r else SENSES[0]
         cs = t + float(g.uniform(0.2, 2.0))
         ce = cs + float(g.uniform(0.15, 0.6))

@@ -126,7 +126,7 @@ def test_async_pipeline_equals_synchronous_forwards(rg, guided):
     assert torch.equal(out["pred_upper"], ref[0]["pred_upper"])
 
 
-@pytest.mark.parametrize("mode", ["batch", "split", "one-lane"])
+@pytest.mark.parametrize("mode", ["batch", "batch4-pairs", "split", "one-lane"])
 def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
     """submit() / flush(): the sampling loop of batch n advances in the same denoiser launches as the exemplar inversion
     of batch n + 1 (shared sessions, two step groups per forward); a batch without exemplars in a lane or of another size
@@ -141,6 +141,12 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
     B, N = 4, 6
     batches = _batches(rg, B, N, dev) + _batches(rg, 2, 1, dev)      # the last one has another batch size
     kinds = ["guided", "guided", "guided", "inv", "guided", "base", "guided"]
+    if mode == "batch4-pairs":
+        # the default rotation over four batch lanes, one workgroup per clip forced (the pipeline picks it by itself only for
+        # launches that would not fit the chip side by side: 16 clips + exemplars): batch n shares its lane -- and, where
+        # both invert exemplars at the same size, its launches -- with batch n + 4
+        batches = _batches(rg, B, 12, dev) + _batches(rg, 2, 1, dev)
+        kinds = ["guided"] * 5 + ["inv", "guided", "base", "guided", "guided", "inv", "guided", "guided"]
 
     def ikw(i):
         k = dict(guided=dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1),
@@ -159,10 +165,16 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
         ref.append({k: out[k].clone() for k in KEYS})
     model.async_results = True
     if mode == "one-lane":
-        model.lanes = 1              # a single pipeline on a single lane stream
+        model.lanes = model.batch_lanes = 1    # a single pipeline on a single lane stream
+    elif mode == "batch4-pairs":
+        assert model.batch_lanes == 4 and model.cobatch_lanes == "batch"
+        torch.cuda.synchronize()     # (the references above ran one workgroup per sequence: new sessions from here on)
+        model._sessions.clear(), model._graphs.clear(), model._graph_owner.clear()
+        model.session_options["seq_pairs"] = True
     else:
         model.cobatch_lanes = mode   # "batch": whole batches alternate between the lanes (results two calls later); "split":
-    for rep in range(2):             # every batch is cut over the lanes (results one call later)
+        model.batch_lanes = 2        # every batch is cut over the lanes (results one call later)
+    for rep in range(2):
         got = []
         for i in range(len(batches)):
             out = model.submit(**args(i))
@@ -176,6 +188,9 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
         torch.cuda.synchronize()
         _same(got, ref, model, "submit()/flush() mode %s pass %d kinds %s" % (mode, rep, kinds))
     assert model.flush() == []
+    if mode == "batch4-pairs":
+        assert any(k[0] == "cobatch" for k in model._graphs), "no launch was shared: the test lost its subject"
+        assert all(s.sq.args.pairs == 1 for s in model._sessions.values() if s.sq is not None)
     # the pipeline is an asynchronous-mode feature
     model.async_results = False
     with pytest.raises(rg.capi.RgError):
@@ -237,8 +252,9 @@ def test_unchanged_tool_loop_and_three_line_pipelined_loop(rg):
         got.append(_tool_body(rg, output))
     got += [_tool_body(rg, output) for output in model.flush()]
     _same(got, want, model, "submit()/flush() loop")
-    # the schedule is fixed by the constructor arguments alone: two lanes + search + decode + the third base lane
-    assert (len(model._lane_streams), model._search_stream is not None, model._decode_stream is not None) == (3, True, True), _where(model)
+    # the schedule is fixed by the constructor arguments alone: four batch lanes (two of them the lanes of a synchronous forward,
+    # three the base lanes) + search + decode
+    assert (len(model._lane_streams), model._search_stream is not None, model._decode_stream is not None) == (4, True, True), _where(model)
 
 
 def test_base_batches_alternate_between_base_lanes(rg):
@@ -276,8 +292,8 @@ def test_base_batches_alternate_between_base_lanes(rg):
     _same(got, ref, model, "base lanes")
 
 
-@pytest.mark.parametrize("use_graphs,calibrate", [(True, False), (True, True), (False, False)])
-def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate):
+@pytest.mark.parametrize("use_graphs,calibrate,batch_lanes", [(True, False, 4), (True, True, 4), (False, False, 4), (True, False, 2)])
+def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate, batch_lanes):
     """The regression test of the round-3 race (two tails on two lanes shared ONE decode graph): guided batches through
     submit() / flush() without any host synchronisation between them -- so tails, chains and front ends of neighbouring
     batches really overlap -- with random delays injected on every stream, repeatedly; then base batches over three lanes.
@@ -288,11 +304,11 @@ def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
     db = rg.synth.SyntheticDataset(512, seed=11, device=dev, feat_device=dev)
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=db, device=dev,
-                                  calibrate_lanes=calibrate)
+                                  calibrate_lanes=calibrate, batch_lanes=batch_lanes)
     model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
     model.eval()
     model.use_graphs = use_graphs
-    batches = _batches(rg, 4, 6, dev)
+    batches = _batches(rg, 4, 2 * batch_lanes + 2, dev)
     guided = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
 
     def args(i, flags):
@@ -321,6 +337,7 @@ def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate)
             torch.cuda.synchronize()
             _same(got, want[name], model, "jitter pass %d %s" % (rep, name))
         assert model._jitter.calls > 0
-    assert model.lane_report["streams"] == 5 and len(model._lane_streams) == 3 and model._search_stream is not None
+    n_lanes = max(2, 3, batch_lanes)      # lanes of a synchronous forward, base lanes, batch lanes
+    assert model.lane_report["streams"] == n_lanes + 2 and len(model._lane_streams) == n_lanes and model._search_stream is not None
     if use_graphs:
         assert any(k[0] == "dec" and k[-1] >= 0 for k in model._graphs), "decode graphs are per tail lane"

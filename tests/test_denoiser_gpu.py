@@ -278,6 +278,31 @@ def test_seq_forward_cut_into_several_launches_is_bit_identical(rg, setup):
     assert all(torch.equal(o, outs[0]) for o in outs[1:])
 
 
+@pytest.mark.parametrize("B", [1, 5, 16, 64])
+def test_seq_forward_one_workgroup_per_clip_is_bit_identical(rg, setup, B):
+    """DenoiserSession(seq_pairs=True): B workgroups, each running a clip's conditional sequence and then its classifier-free
+    twin, instead of 2 B workgroups (what the pipeline picks for launches that would not fit the chip beside the other batch
+    lanes').  Same bits: with two step groups, real masks, cut into several launches (the hand-over buffer is per sequence),
+    and over consecutive forwards of one session (nothing of a pass survives into the next)."""
+    cfg, P, W = setup[8]
+    data = rg.synth.synth_batch(B, seed=80)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(8)).standard_normal((B, 43, 512)).astype(np.float32)).cuda()
+    mm = torch.ones(B, 43)
+    mm[:, [10, 21, 32]] = 0
+    mm[0, 30:] = 0
+    outs = {}
+    for pairs, n in ((False, 1), (True, 1), (True, 3)):
+        sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=pairs, seq_launches=n)
+        assert sess.sq.args.pairs == int(pairs)
+        sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
+        outs[pairs, n] = [sess.forward(x, st, sb, sp).clone() for st, sb, sp in ((49, None, None), (23, 40, max(1, B // 3)), (0, None, None))]
+        torch.cuda.synchronize()
+    for key in ((True, 1), (True, 3)):
+        for i, (a, b) in enumerate(zip(outs[key], outs[False, 1])):
+            assert torch.isfinite(a).all() and torch.equal(a, b), (B, key, i, (a - b).abs().max().item())
+    assert not torch.equal(outs[False, 1][0], outs[False, 1][2])
+
+
 @pytest.mark.parametrize("grouped", [True, False])
 def test_condition_side_attention_matrices_vs_oracle(rg, parity, setup, grouped):
     """DenoiserSession.set_conditions: A[layer][condition][clip][head] = softmax_N(K)^T V (efficient_attention.py:74-90) of the

@@ -138,17 +138,20 @@ def test_config3_guided_b16_full_db_vs_oracle(rg, parity):
 
 
 def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity):
-    """What bench.py times: asynchronous submission, co-batched pipeline, whole batches alternating between the lanes.  The
-    middle one of three different batches has its sampling loop co-batched with a later batch's exemplar inversion and its
-    own inversion with an earlier batch's sampling: every step-group code path and the real exemplar counts meet the
-    independent reference here."""
+    """What bench.py times: asynchronous submission, co-batched pipeline, whole batches rotating over the batch lanes (four,
+    one workgroup per clip: DenoiserSession seq_pairs, picked by the pipeline for launches of this width).  Batch n shares a
+    lane with batches n - 4 and n + 4: of nine different batches the fifth has its exemplar inversion co-batched with an
+    earlier batch's sampling loop and its own sampling with a later batch's inversion: every step-group code path and the
+    real exemplar counts meet the independent reference here."""
     dev = torch.device("cuda", 0)
     B, N_DB = 16, 32768
     cfg, vae_cfgs, database, model, P, cpu_db = _guided_setup(rg, dev, B, N_DB)
     model.async_results = True
+    L = model.batch_lanes
+    assert L == 4
     ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
     outs, keeps, tapes, exs = [], [], [], []
-    for n in range(3):
+    for n in range(2 * L + 1):
         data = _guided_batch(rg, dev, B, 1234 + 17 * n, 100 * n)
         keeps.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()})
         tapes.append(RecordingTape(rg.synth.NoiseTape(90 + n)))
@@ -157,14 +160,18 @@ def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity):
         if r is not None:
             outs.append(r)
     outs += model.flush()
-    assert len(outs) == 3
+    assert len(outs) == 2 * L + 1
     for r in outs:
         model.wait_results(r)
     torch.cuda.synchronize()
-    assert len(exs[1]) >= B
-    assert not torch.equal(outs[0]["prev_latentout"], outs[1]["prev_latentout"])
-    _check_clips(rg, parity, "config 3 as benchmarked (submit / flush, middle batch)", (0, 7, 15), B, P, cfg, vae_cfgs, cpu_db,
-                 keeps[1], tapes[1], exs[1], outs[1], ikw)
+    paired = {k[:2]: s.sq.args.pairs for k, s in model._sessions.items() if s.sq is not None}
+    assert [v for k, v in paired.items() if k[1] == "cobatch"] and all(v == 1 for k, v in paired.items() if k[1] == "cobatch"), paired
+    # (16 clips + their exemplars in a launch, four lanes: one workgroup per clip)
+    assert any(k[0] == "cobatch" for k in model._graphs)
+    assert len(exs[L]) >= B
+    assert not torch.equal(outs[0]["prev_latentout"], outs[L]["prev_latentout"])
+    _check_clips(rg, parity, "config 3 as benchmarked (submit / flush, batch %d of %d)" % (L, 2 * L + 1), (0, 7, 15), B, P, cfg,
+                 vae_cfgs, cpu_db, keeps[L], tapes[L], exs[L], outs[L], ikw)
 
 
 def test_config2_base_b32_vs_oracle(rg, parity):

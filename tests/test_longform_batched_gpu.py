@@ -45,18 +45,21 @@ def test_run_many_equals_per_clip_runs(rg, precision):
         assert np.abs(one["poses"] - many[ci]["poses"]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("guided", [True, False])
-def test_pipelined_windows_equal_the_sequential_loop(rg, guided, tmp_path):
+@pytest.mark.parametrize("guided,batch_lanes", [(True, 2), (True, 4), (False, 4)])
+def test_pipelined_windows_equal_the_sequential_loop(rg, guided, batch_lanes, tmp_path):
     """run_many(pipelined=True): the windows go through submit() / flush() with the previous window's latent still pending
     (pipeline.PendingLatent) -- retrieval + exemplar inversion of window k + 1 beside the sampling loop of window k.  Same
     noise tape, clips of different lengths (the batch shrinks: the pending latent is row-selected), BASELINE config 5's
     flags (llm retrieval on cached answers, inversion + insertion guidance + prev-latent): every latent and every output
-    must equal the sequential loop's, bit for bit."""
+    must equal the sequential loop's, bit for bit.  Window batches rotate over `batch_lanes` lanes: with two, window k + 2 shares
+    its launches with window k (co-batched chains); with four (the default) the inversions of the next windows run as chains
+    of their own on the other lanes."""
     dev = torch.device("cuda", 0)
     cfg = rg.synth.default_model_cfg(num_layers=2)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder", num_layers=2)
     ds = rg.synth.SyntheticDataset(300, seed=31, device=dev, feat_device=dev)
-    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds, device=dev)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=ds, device=dev,
+                                  batch_lanes=batch_lanes)
     model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
     model.eval()
     cache = rg.retrieval.LLMResponseCache(str(tmp_path / "llm_cache.json"), call=rg.synth.synth_llm_answer)
@@ -78,7 +81,7 @@ def test_pipelined_windows_equal_the_sequential_loop(rg, guided, tmp_path):
     model.async_results = True
     pip = synth.run_many([copy(c) for c in clips], features, noise_tape=rg.synth.NoiseTape(71), retrieval_method="llm", **flags)
     torch.cuda.synchronize()
-    if guided:
+    if guided and batch_lanes == 2:
         assert any(k[0] == "cobatch" for k in model._graphs), "the pipelined run should have gone through co-batched chains"
     assert not model._pend and not model._ready
     for ci in range(len(clips)):
