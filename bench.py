@@ -341,8 +341,9 @@ class Workload:
 
         n, ms, fl = events()
         ach = fl / (ms * 1e-3) if ms > 0 else 0.0
-        kernel = {3: "rg_seq_kernel (one workgroup per sequence: embedding, 8 decoder layers, head; bf16 MFMA, fp32 accumulate; "
-                     "weights streamed by LDS-DMA)",
+        kernel = {3: "rg_seq_kernel (a whole denoiser forward per workgroup -- embedding, 8 decoder layers, head -- of one sequence, or of "
+                     "a clip's conditional sequence and then its classifier-free twin; bf16 MFMA, fp32 accumulate; weights streamed by "
+                     "LDS-DMA)",
                   1: "rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)",
                   2: "rg_gemm bf16x3 kernels (fp32-equivalent products: hi*hi + hi*lo + lo*hi)"}[variant]
         r = {"bound": "mfma", "kernel": kernel,
@@ -619,11 +620,16 @@ def main():
                 # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 gfx950
                 # correction + WRITE_SIZE; profiles/pmc_seq.py, pmc_seq_summarize.py; round 1-2: the rg_gemm shapes)
                 if roofline.get("workgroups_per_launch") is not None:
-                    with open(os.path.join(ROOT, "profiles", "r04_pmc_seq.json")) as f:
+                    # (r04_pmc_seq: 128 workgroups, one per sequence; r04s_pmc_seq_pairs: 64 workgroups, one per clip -- the twin's
+                    #  pass streams the shared weights through every L2 a second time)
+                    paired = roofline["workgroups_per_launch"] < roofline["sequences_per_launch"]
+                    with open(os.path.join(ROOT, "profiles", "r04s_pmc_seq_pairs.json" if paired else "r04_pmc_seq.json")) as f:
                         pm = json.load(f)
                     roofline["traffic"] = round(pm["fetch_bytes"] + pm["write_bytes"])
                     roofline["traffic_algorithmic"] = round(pm["algorithmic_hbm_bytes"])
-                    roofline["mfma_utilisation_pmc"] = round(pm["mfma_utilisation"], 4)
+                    roofline["mfma_utilisation_pmc"] = round(pm["mfma_utilisation"], 4)      # (of the whole chip's MFMA cycles, one launch alone)
+                    if roofline.get("cu_share"):
+                        roofline["mfma_utilisation_pmc_of_occupied_cus"] = round(pm["mfma_utilisation"] / roofline["cu_share"], 4)
                 else:
                     with open(os.path.join(ROOT, "profiles", "r02m_pmc_gemm_traffic.json")) as f:
                         rows = json.load(f)

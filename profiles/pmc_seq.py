@@ -15,7 +15,8 @@ rg = importlib.import_module("rag-gesture_amd")
 B, REPS, L, T = int(os.environ.get("SEQ_B", "64")), int(os.environ.get("SEQ_REPS", "10")), 8, 43
 cfg = rg.synth.default_model_cfg(num_layers=L)
 W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, rg.schedule.Schedule(), "cuda")
-sess = rg.denoiser.DenoiserSession(W, B, engine="seq")
+PAIRS = os.environ.get("SEQ_PAIRS", "0") == "1"     # one workgroup per clip (conditional sequence, then its twin): B workgroups
+sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=PAIRS)
 d = rg.synth.synth_batch(B, seed=1)
 mask = torch.ones(B, 43); mask[:, [10, 21, 32]] = 0
 sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, {c: mask.clone() for c in rg.denoiser.CONDS})
@@ -37,5 +38,5 @@ alg = (st.wstream.numel() * 2 + 2 * (st.pstream[0].numel() * 4 + st.ustream[0].n
 # bytes the workgroups pull through their LDS rings (what the per-CU intake sees): every sequence streams its own copy
 per_cond = (16 * L + 2) * 520 * 1024 + L * 3 * 64 * 1024
 per_unc = (10 * L + 2) * 520 * 1024 + L * 16 * 1024
-print(json.dumps(dict(kernel="rg_seq_kernel", sequences=2 * B, launches=REPS, flops_per_launch=flops, algorithmic_hbm_bytes=alg,
+print(json.dumps(dict(kernel="rg_seq_kernel", sequences=2 * B, workgroups=B if PAIRS else 2 * B, launches=REPS, flops_per_launch=flops, algorithmic_hbm_bytes=alg,
                       lds_ring_bytes=B * (per_cond + per_unc))))
