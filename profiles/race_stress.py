@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--batches", type=int, default=5)
     ap.add_argument("--B", type=int, default=4)
     ap.add_argument("--tag", default=None)
+    ap.add_argument("--pairs", action="store_true", help="one workgroup per clip in every rg_seq launch of the asynchronous passes")
+    ap.add_argument("--batch-lanes", type=int, default=None)
     a = ap.parse_args()
     rg = importlib.import_module("rag-gesture_amd")
     if a.old:
@@ -78,7 +80,7 @@ def main():
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
     db = rg.synth.SyntheticDataset(512, seed=11, device=dev, feat_device=dev)
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=db, device=dev,
-                                  calibrate_lanes=a.calibrate)
+                                  calibrate_lanes=a.calibrate, **({} if a.batch_lanes is None else dict(batch_lanes=a.batch_lanes)))
     model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
     model.eval()
     model.use_graphs = not a.no_graphs
@@ -105,6 +107,10 @@ def main():
         torch.cuda.synchronize()
         want.append({k: out[k].cpu().numpy() for k in KEYS})
     model.async_results = True
+    if a.pairs:              # (the synchronous references above ran one workgroup per sequence)
+        torch.cuda.synchronize()
+        model._sessions.clear(), model._graphs.clear(), model._graph_owner.clear()
+        model.session_options["seq_pairs"] = True
     rng = random.Random(7)
 
     def jitter(stream, tag):
@@ -134,7 +140,8 @@ def main():
         bad += not row["ok"]
         rows.append(row)
         print(json.dumps(row), flush=True)
-    summary = dict(reps=a.reps, failed=bad, old_graph_run=a.old, graphs=model.use_graphs, jitter=not a.no_jitter, read=a.read,
+    summary = dict(reps=a.reps, failed=bad, batches=a.batches, pairs=a.pairs, batch_lanes=model.batch_lanes,
+                   cobatch_graphs=sum(1 for k in model._graphs if k[0] == "cobatch"), old_graph_run=a.old, graphs=model.use_graphs, jitter=not a.no_jitter, read=a.read,
                    topology=model.lane_report, lane_streams=len(model._lane_streams), search_stream=model._search_stream is not None,
                    cross_stream_waits=model.graph_cross_stream_waits, hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"))
     print(json.dumps(dict(summary=summary)), flush=True)
