@@ -734,9 +734,16 @@ def main():
         }
         all_ok = all_ok and all(v.get("verified", {}).get("verified", True) for v in (also or {}).values())
         line["verified"] = all_ok
-        print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio on stdout: everything it has to say is flushed out first, so that the
+        # JSON is the LAST line of stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
     if not all_ok:
         sys.stderr.write("bench.py: a timed batch does not equal its synchronous forward -- the figure above is not a result\n")
         sys.exit(3)
