@@ -729,8 +729,8 @@ class MotionDiffusion(torch.nn.Module):
         cob = self._cob if run_async else None      # submit(): this batch's sampling is deferred to a later call
         pid = None
         if cob is not None and cob.get("lane") is not None:
-            # whole batches alternate between the lanes: this one runs (inversion now, sampling two calls later) on one
-            # lane's stream, the batch submitted before it is still busy on the other
+            # whole batches rotate over the lanes: this one runs (inversion now, sampling one rotation later) on one
+            # lane's stream while the batches submitted before it are busy on the others
             # (base: nothing to share launches with, more and smaller chains; with inversion: the co-batched chains)
             plan = self._lane_plan(B, self.batch_lanes if use_inversion else self.base_lanes)
             pid = cob["lane"] % len(plan)
@@ -931,11 +931,11 @@ class MotionDiffusion(torch.nn.Module):
 
     # ------------------------------------------------------------------ co-batched pipeline
     def submit(self, **kwargs):
-        """Queue a batch whose sampling is DEFERRED to the next call: its exemplars are inverted now, in the same denoiser
-        launches that run the sampling loop of the batch submitted before (sampler.cobatched_loop: a forward over the 8 clips
-        + 24 exemplars of a lane costs ~1.1x the forward over the exemplars alone).  Returns the results of the previous
-        batch (asynchronous: `done_event` / `done_stream`, see `wait_results`), or None while the pipeline fills;
-        `flush()` finishes what is pending.  Same arguments as forward(); needs async_results=True.  Batches that cannot
+        """Queue a batch whose sampling is DEFERRED to a later call: its exemplars are inverted now, in the same denoiser
+        launches that run the sampling loop of the batch submitted one rotation of the `batch_lanes` earlier
+        (sampler.cobatched_loop: one forward per step for the 16 clips of one batch and the 48 exemplars of the other).
+        Returns the results of that earlier batch (asynchronous: `done_event` / `done_stream`, see `wait_results`), or None
+        while the pipeline fills; results come out in submission order; `flush()` finishes what is pending.  Same arguments as forward(); needs async_results=True.  Batches that cannot
         be co-batched (no inversion, a lane without exemplars, another batch size) are completed on their own."""
         if not self.async_results or self.slots < 2:
             raise capi.RgError("submit() needs MotionDiffusion(async_results=True, slots >= 2)")
