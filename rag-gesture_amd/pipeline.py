@@ -556,7 +556,7 @@ class MotionDiffusion(torch.nn.Module):
             self._sessions[key] = self._sessions.pop(key)        # most recently used goes last
         return self._sessions[key]
 
-    def _seq_pairs_auto(self, B):
+    def _seq_pairs_auto(self, B, cus=None):
         """One workgroup per clip instead of one per sequence (DenoiserSession seq_pairs; same bits) for the sessions of a
         batch lane whose launches would not fit the chip beside the other lanes' otherwise: 2 B workgroups x the lanes in
         rotation > compute units.  Narrow launches (the sampling of a last batch, synchronous forwards, the base workload) keep
@@ -564,7 +564,8 @@ class MotionDiffusion(torch.nn.Module):
         cob = self._cob
         if not (self.async_results and cob is not None and cob.get("lane") is not None):
             return False
-        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if cus is None:
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         return 2 * B * self.batch_lanes > cus
 
     def _set_conditions(self, B, role, lane, word, audio, speaker_ids, motion_mask, query_masks):
@@ -966,6 +967,10 @@ class MotionDiffusion(torch.nn.Module):
         self._sampling_pass(st)
         return self._tail(st)
 
+    def _pending_upto(self, seq):
+        """Pipeline ids of the pending batches submitted no later than submission `seq`, oldest first."""
+        return sorted((p for p in self._pend if self._pend[p].seq <= seq), key=lambda p: self._pend[p].seq)
+
     def _set_conditions_pair(self, sess, key, own, a, b, n_a):
         """Conditions of a session that holds two batches side by side (clips [0, n_a): a, the rest: b), one graph."""
         dev = self.model.weights.dev
@@ -1001,7 +1006,7 @@ class MotionDiffusion(torch.nn.Module):
             # finishes alone (in the other slot's sessions) -- behind everything submitted before it: results are handed out
             # in submission order, and this lane's pending batch is the oldest only while the rotation is undisturbed (a
             # batch without inversion picks its lane among `base_lanes`, not `batch_lanes`)
-            for p in sorted((p for p in self._pend if self._pend[p].seq <= pend.seq), key=lambda p: self._pend[p].seq):
+            for p in self._pending_upto(pend.seq):
                 self._ready.append(self._finish_alone(self._pend.pop(p)))
             self._slot = self._slots[st.pid] = st.slot
             pend = None

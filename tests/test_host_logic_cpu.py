@@ -233,3 +233,27 @@ def test_slot_bookkeeping_is_per_lane(rg):
     assert m._take_slot(0, main, [0]) == 1 and main.waited == ["a"]      # pipeline 0 meets what pipeline None left on lane 0
     main = _Main()
     assert m._take_slot(0, main, [0]) == 0 and main.waited == ["c"]
+
+
+def test_batch_lane_rules_results_in_submission_order_and_paired_launches(rg):
+    """Two host-side rules of the four-lane pipeline.  (i) Wherever a pending batch has to finish on its own, everything
+    submitted before it finishes first: a batch without inversion picks its lane among `base_lanes`, so the pending batch it meets
+    there need not be the oldest one (found on the GPU as results out of order, NOTEBOOK 9.8).  (ii) One workgroup per clip is
+    chosen exactly where the batch lanes' launches would not fit the compute units side by side."""
+    import types
+    MD = rg.pipeline.MotionDiffusion
+    m = MD.__new__(MD)
+    m._pend = {3: types.SimpleNamespace(seq=3), 0: types.SimpleNamespace(seq=4), 1: types.SimpleNamespace(seq=5),
+               2: types.SimpleNamespace(seq=6)}
+    assert m._pending_upto(5) == [3, 0, 1]           # a base batch on lane 1 meets batch 5: 3 and 4 go first
+    assert m._pending_upto(3) == [3] and m._pending_upto(2) == [] and m._pending_upto(99) == [3, 0, 1, 2]
+    m.async_results, m.batch_lanes, m._cob = True, 4, dict(lane=7)
+    assert m._seq_pairs_auto(64, cus=256) and m._seq_pairs_auto(48, cus=256)       # co-batched chains, 48-exemplar inversions
+    assert not m._seq_pairs_auto(16, cus=256) and not m._seq_pairs_auto(32, cus=256)   # a draining batch's 16 clips; 2 x 32 x 4 = 256 fits
+    m.batch_lanes = 2
+    assert not m._seq_pairs_auto(64, cus=256)        # two lanes of 128 workgroups fit
+    m.batch_lanes, m._cob = 4, None
+    assert not m._seq_pairs_auto(64, cus=256)        # synchronous forwards: never
+    m._cob, m.async_results = dict(lane=None), True
+    assert not m._seq_pairs_auto(64, cus=256)        # lanes split a batch (cobatch_lanes="split"): one workgroup per sequence
+
