@@ -112,9 +112,28 @@ __device__ __forceinline__ void zero(Acc& a) {
 
 struct rg_vdec_group { rg_vdec_args a[4]; };   // up to four stacks (the four body parts) in one launch: blockIdx.y picks
 
+// Diagnostic build only (build.py RG_DIAG=1): wall-clock (100 MHz) stamps at the phase boundaries of a launch, written per wave
+// to a.dump[(tile * 8 + wave) * 16 + i] (ticks since stamp 0) when pad_ == 99 (profiles/dbg/vdec_stamps.py).  Stamps: 0 start,
+// 1 descriptors + Q image in LDS, 2 attention, 3 x rows loaded, 4 out_proj + norm1, 5 FFN + norm2 (+ skip push), 6 skip linear +
+// x rows stored, 7 Q / K / V projections, 8 K / V / Q image stored (launch 0: 1 -> 3 -> 6 ...; last launch: ... 5 -> 8).
+#ifdef RG_STAMPS
+#define VSTAMP(i) ts_[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define VSTAMP(i)
+#endif
+
 __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
   const rg_vdec_args& a = grp.a[blockIdx.y];
   if ((int)blockIdx.x >= 4 * a.nseq) return;
+#ifdef RG_STAMPS
+  unsigned long long ts_[9];
+  const bool stamps = a.pad_ == 99 && a.dump;
+  VSTAMP(0);
+#pragma unroll
+  for (int i = 1; i < 9; ++i) ts_[i] = 0;
+#else
+  constexpr bool stamps = false;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const P0 = smem + OFF_P0;
   unsigned char* const P1 = smem + OFF_P1;
@@ -162,6 +181,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     for (int i = 0; i < (TP * 64) / NTH; ++i) reinterpret_cast<u32x4*>(P1)[tid + NTH * i] = src[tid + NTH * i];
   }
   __syncthreads();
+  VSTAMP(1);
 
   auto panel_store = [&](unsigned char* panel, int l15, int g4, int j, int tb, float v0, float v1, float v2, float v3) {
     const int s = 2 * wave + (j >> 1), gq = 2 * (j & 1) + (g4 >> 1);
@@ -395,10 +415,12 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
         }
       }
     }
+    VSTAMP(2);
     bar();                                        // everyone is done with the Q panel
     write_raw(P1, oo);
     bar();
     rows_io(xr, a.x, false);
+    VSTAMP(3);
     // ======================================================= x = LayerNorm1(x + out_proj(attention))
     {
       const unsigned char* ps = consume();
@@ -424,6 +446,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
         }
       bar();
     }
+    VSTAMP(4);
     // ======================================================= x = LayerNorm2(x + linear2(gelu(linear1(x))))
     {
       f32x4 ga[4], be[4];
@@ -462,10 +485,20 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
           for (int r = 0; r < 4; ++r) xr[j][tb][r] = fmaf((xr[j][tb][r] - mean[tb]) * rstd[tb], ga[j][r], be[j][r]);
     }
     if (step - 1 < nb) skip_io(xr, step - 1, true);
+    VSTAMP(5);
   } else {
     rows_io(xr, a.x, false);
+    VSTAMP(3);
   }
-  if (a.dump) {      // diagnostics: the state behind block step - 1 (launch 0: the input)
+#ifdef RG_STAMPS
+  auto stamps_out = [&]() {
+    if (stamps && lane0 == 0) {
+      VSTAMP(8);
+      for (int i = 0; i < 9; ++i) a.dump[((size_t)tile * 8 + wave) * 16 + i] = ts_[i] ? (float)(ts_[i] - ts_[0]) : 0.f;
+    }
+  };
+#endif
+  if (a.dump && !stamps) {      // diagnostics: the state behind block step - 1 (launch 0: the input)
     LANE_LOCAL();
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -492,6 +525,9 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     }
     release();
     rows_io(xr, a.x, true);
+#ifdef RG_STAMPS
+    stamps_out();
+#endif
     return;
   }
   // ======================================================= skip concatenation + Linear(2 D -> D) in front of output block `step`
@@ -514,6 +550,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     write_raw(P0, xr);
   }
   rows_io(xr, a.x, true);                         // the residual stream of the next launch
+  VSTAMP(6);
   // ======================================================= Q, K (from x + pos) and V (from x) of block `step`
   {
     Acc xp;
@@ -542,6 +579,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     release();
   }
   gemm_unit(vv, P0, STDL);
+  VSTAMP(7);
   {
     LANE_LOCAL();
     // K rows (T layout: row 16 tb + l15, 4 consecutive features) and V transposed (standard layout: feature 16 j + l15,
@@ -570,6 +608,9 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     for (int i = 0; i < (TP * 64) / NTH; ++i) dst[tid + NTH * i] = reinterpret_cast<const u32x4*>(P1)[tid + NTH * i];
   }
   wait_vmcnt<0>();
+#ifdef RG_STAMPS
+  stamps_out();
+#endif
 }
 
 static int vdec_check(rg_handle* h, const rg_vdec_args& a) {
