@@ -38,22 +38,25 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(rg, tmp_path):
     if cc is None:
         pytest.skip("no C compiler")
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
-    G = rg.gemm
-    fields = [name for name, _ in G.GemmDesc._fields_]
+    structs = [("rg_gemm_desc", rg.gemm.GemmDesc), ("rg_seq_args", rg.seqfwd.SeqArgs), ("rg_venc_args", rg.vencfwd.VencArgs),
+               ("rg_vdec_args", rg.vencfwd.VdecArgs)]
     src = tmp_path / "abi.c"
-    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rg_gesture.h"', 'int main(void) {',
-             '  printf("size %zu\\n", sizeof(rg_gemm_desc));']
-    for f in fields:
-        lines.append('  printf("%s %%zu\\n", offsetof(rg_gemm_desc, %s));' % (f, f))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rg_gesture.h"', 'int main(void) {']
+    for cname, cls in structs:
+        lines.append('  printf("%s.size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
     lines += ['  return 0;', '}']
     src.write_text("\n".join(lines))
     exe = tmp_path / "abi"
     r = subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe)], capture_output=True, text=True)
-    assert r.returncode == 0, "the header is not plain C:\n" + r.stderr
+    assert r.returncode == 0, "the header is not plain C (or a ctypes field has no C counterpart):\n" + r.stderr
     out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
-    assert int(out["size"]) == ctypes.sizeof(G.GemmDesc)
-    for f in fields:
-        assert int(out[f]) == getattr(G.GemmDesc, f).offset, "field %s: C offset %s, ctypes %d" % (f, out[f], getattr(G.GemmDesc, f).offset)
+    for cname, cls in structs:
+        assert int(out[cname + ".size"]) == ctypes.sizeof(cls), (cname, out[cname + ".size"], ctypes.sizeof(cls))
+        for f, _ in cls._fields_:
+            assert int(out["%s.%s" % (cname, f)]) == getattr(cls, f).offset, \
+                "%s.%s: C offset %s, ctypes %d" % (cname, f, out["%s.%s" % (cname, f)], getattr(cls, f).offset)
 
 
 def test_device_code_has_no_packed_fp32_instructions(tmp_path):
