@@ -873,7 +873,7 @@ class MotionDiffusion(torch.nn.Module):
             use_insertion_guidance=use_insertion_guidance, guidance_iters=guidance_iters, guidance_lr=guidance_lr,
             visualize_inversion=visualize_inversion, inversion_start_time=inversion_start_time, vis_inv=[], vis_pairs=[],
             word=word, audio=audio, spk=spk, motion_mask=motion_mask, qmask=qmask, early_cond=early_cond,
-            use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot, pid=pid, seq=self._submitted,
+            use_prev_latent=use_prev_latent, prev_latent=prev_latent, idx_groups=(up_i, ha_i, fa_i, lt_i), slot=self._slot, pid=pid, seq=self._submitted, via_submit=cob is not None,
             prev_future=prev_future if in_seq is not None else None, latent_ready=None)
         # what a later batch's pending prev_latent needs of this one (not the whole state: invl alone is 140 MB at B = 32)
         st.handle = self._last_state = types.SimpleNamespace(B=B, x_out=st.x_out, latent_ready=None)
@@ -1179,7 +1179,8 @@ class MotionDiffusion(torch.nn.Module):
         if st.run_async and self.decode_on_own_stream and self._decode_stream is not None:
             tail_lane, tail = -2, self._decode_stream
         self._tail_turn += 1
-        if st.run_async:     # (submission order is the contract of submit() / flush(): a scheduling bug must not pass as a result)
+        if st.run_async and st.via_submit:   # (submission order is the contract of submit() / flush(): a scheduling bug must
+            #                                    not pass as a result; a plain forward() between them is the caller's own order)
             capi.require(st.seq >= self._last_out_seq, "internal: results handed out against the submission order")
             self._last_out_seq = st.seq
         if self._jitter is not None:
