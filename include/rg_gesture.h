@@ -337,6 +337,7 @@ typedef struct rg_seq_args {
   float* head;             /* fp32 [2B][T][512] result */
   float* dump;
   float* xbuf;             /* fp32 [2B][8][12][64][4] hand-over of the residual stream between the launches of one forward, or NULL */
+  void* gbuf;              /* rg_seq2_forward: bf16 [workgroups][2][48 KiB] panel images; its xbuf is fp32 [workgroups][2][8][12][64][4] */
   int L, B, T, S;          /* layers, clips, tokens, steps in pstream / ustream */
   int step, step_b, split; /* clips [0, split) at step, clips [split, B) at step_b */
   int dump_stage, dump_layer;
@@ -349,6 +350,7 @@ typedef struct rg_seq_args {
 } rg_seq_args;
 
 int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);
+int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);
 
 /* Sequence-stationary body-part VAE encoder: the whole skip-transformer stack of `TransformerVAE.encode_to_dist`
  * (mogen/models/transformers/gesture_vae.py:111-193: chunk sequences of frame_chunk_size frames + the two distribution

@@ -21,7 +21,7 @@ constexpr int UNIT_BYTES = 512 * 512 * 2;
 
 // NS sequences per workgroup; NJ 16-feature blocks per wave (4: 8 waves x 64 features, 8: 4 waves x 128 features, one per
 // SIMD with 512 registers); RD ring slots per wave; RT: 0 accumulators stay in registers, 1 load + add + store per unit
-template <int NS, int NJ, int RD, int RT>
+template <int NS, int NJ, int RD, int RT, int PF = 0>
 __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __restrict__ wstream, float* __restrict__ R, int nunits,
                                                        int stream_units, float* out, unsigned long long* clk) {
   constexpr int NW = 32 / NJ, NB = NS * 3, FPU = 16 * NJ;     // waves, token blocks, fragments per unit and wave
@@ -55,32 +55,65 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
   f32x4* Rw = reinterpret_cast<f32x4*>(R) + ((size_t)(blockIdx.x * NW + wave) * (NJ * NB)) * 64 + lane;
 #pragma unroll 1
   for (int u = 0; u < nunits; ++u) {
+    if constexpr (PF == 0) {
     bf16x8 w[2], pf[2][NB];
-    wait_vmcnt<RD - 1>();
-    w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
+      wait_vmcnt<RD - 1>();
+      w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
+  #pragma unroll
+      for (int b = 0; b < NB; ++b) pf[0][b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16) << 10));
+  #pragma unroll 1
+      for (int s2 = 0; s2 < 16; s2 += 2) {
+  #pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+  #pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const bool last = ss == 1 && j == NJ - 1 && s2 == 14;
+            wait_lds();
+            issue(head);
+            head = head + 1 == RD ? 0 : head + 1;
+            if (!last) {
+              wait_vmcnt<RD - 1>();
+              w[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
+            }
+            if (j == NJ - 1 && !last) {
+  #pragma unroll
+              for (int b = 0; b < NB; ++b) pf[ss ^ 1][b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16 + s2 + ss + 1) << 10));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+            for (int b = 0; b < NB; ++b) acc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[ss][b], acc[j][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+  }
+    if constexpr (PF == 1) {     // one set of panel fragments, each re-read for the next k-step behind its last MFMA (rg_seq2.hip)
+      bf16x8 w[2], pf[NB];
+      wait_vmcnt<RD - 1>();
+      w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) pf[0][b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16) << 10));
+      for (int b = 0; b < NB; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16) << 10));
 #pragma unroll 1
-    for (int s2 = 0; s2 < 16; s2 += 2) {
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
+      for (int s = 0; s < 16; ++s) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const bool last = ss == 1 && j == NJ - 1 && s2 == 14;
-          wait_lds();
+          if (j == 0) __builtin_amdgcn_s_waitcnt(0xc07f | (NB << 8)); else __builtin_amdgcn_s_waitcnt(0xc07f);
+          asm volatile("" ::: "memory");
           issue(head);
           head = head + 1 == RD ? 0 : head + 1;
-          if (!last) {
+          if (j < NJ - 1 || s != 15) {
             wait_vmcnt<RD - 1>();
             w[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
           }
-          if (j == NJ - 1 && !last) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) pf[ss ^ 1][b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16 + s2 + ss + 1) << 10));
-          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int b = 0; b < NB; ++b) acc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[ss][b], acc[j][b], 0, 0, 0);
+          for (int b = 0; b < NB; ++b) {
+            acc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[b], acc[j][b], 0, 0, 0);
+            if (j == NJ - 1) {
+              pf[b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16 + s + 1) << 10));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -114,12 +147,12 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
   out[blockIdx.x * 512 + tid] = s;
 }
 
-template <int NS, int NJ, int RD, int RT>
+template <int NS, int NJ, int RD, int RT, int PF = 0>
 void run(const unsigned char* stream, int stream_units, float* R, int grid, float* out, unsigned long long* clk) {
   constexpr int NW = 32 / NJ;
   const int nunits = 260;
   const size_t lds = NS * 49152 + NW * RD * 1024;
-  auto k = probe<NS, NJ, RD, RT>;
+  auto k = probe<NS, NJ, RD, RT, PF>;
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -135,8 +168,8 @@ void run(const unsigned char* stream, int stream_units, float* R, int grid, floa
   unsigned long long c[2]; CK(hipMemcpy(c, clk, sizeof(c), hipMemcpyDeviceToHost));
   const double us_unit = best * 1e3 / nunits, mhz = (double)c[0] / ((double)c[1] / 100.0);
   const double flop = 2.0 * 512 * 512 * 48 * NS;
-  printf("NS=%d waves=%d RD=%2d RT=%d grid=%3d | %6.2f us/unit | rows x units / us / CU: %5.2f (48-row) %5.2f (43-row) | %5.1f GB/s/CU | "
-         "MFMA %5.1f TF/CU-set = %.3f of peak(grid CUs) | clk %4.0f MHz\n", NS, NW, RD, RT, grid, us_unit, 48.0 * NS / us_unit, 43.0 * NS / us_unit,
+  printf("NS=%d waves=%d RD=%2d RT=%d PF=%d grid=%3d | %6.2f us/unit | rows x units / us / CU: %5.2f (48-row) %5.2f (43-row) | %5.1f GB/s/CU | "
+         "MFMA %5.1f TF/CU-set = %.3f of peak(grid CUs) | clk %4.0f MHz\n", NS, NW, RD, RT, PF, grid, us_unit, 48.0 * NS / us_unit, 43.0 * NS / us_unit,
          UNIT_BYTES / us_unit / 1e3, flop * grid / us_unit / 1e6, flop * grid / us_unit / 1e6 / (2500.0 * grid / 256), mhz);
 }
 
@@ -156,9 +189,8 @@ int main() {
   for (int grid : {64, 128, 256}) {
     run<1, 4, 7, 0>(stream, stream_units, R, grid, out, clk);    // today's loop
     run<2, 4, 6, 0>(stream, stream_units, R, grid, out, clk);    // two sequences per fragment, accumulators resident
+    run<2, 4, 6, 0, 1>(stream, stream_units, R, grid, out, clk); // ... one set of panel-fragment registers, refreshed in place
     run<2, 4, 6, 1>(stream, stream_units, R, grid, out, clk);    // + fp32 round trip through L2 per unit
-    run<2, 8, 12, 0>(stream, stream_units, R, grid, out, clk);   // four waves x 512 registers
-    run<2, 8, 12, 1>(stream, stream_units, R, grid, out, clk);
   }
   return 0;
 }

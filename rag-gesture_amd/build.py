@@ -12,8 +12,9 @@ import sys
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 DIAG = os.environ.get("RG_DIAG") == "1"   # diagnostic build with in-kernel phase stamps (never the product)
-LIB_PATH = os.path.join(PKG_DIR, "librg_gesture_diag.so" if DIAG else "librg_gesture.so")
-OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj_diag" if DIAG else "_obj")
+TAG = "diag" if DIAG else os.environ.get("RG_LIB_TAG", "")   # RG_LIB_TAG=x: an experiment build (RG_EXTRA_FLAGS) beside the product library
+LIB_PATH = os.path.join(PKG_DIR, "librg_gesture%s.so" % ("_" + TAG if TAG else ""))
+OBJ_DIR = os.path.join(PKG_DIR, "csrc", "_obj" + ("_" + TAG if TAG else ""))
 ARCH = "gfx950"
 # NO_PACKED_FP32: the device code is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 /
 # v_pk_fma_f32, which the compiler forms from pairs of independent fp32 operations on gfx90a and later).

@@ -12,7 +12,8 @@ import re
 import torch
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "librg_gesture_diag.so" if os.environ.get("RG_DIAG") == "1" else "librg_gesture.so")
+_TAG = "diag" if os.environ.get("RG_DIAG") == "1" else os.environ.get("RG_LIB_TAG", "")    # (see build.py: diagnostic / experiment builds)
+LIB_PATH = os.path.join(PKG_DIR, "librg_gesture%s.so" % ("_" + _TAG if _TAG else ""))
 HEADER_PATH = os.path.join(os.path.dirname(PKG_DIR), "include", "rg_gesture.h")
 
 _lib = None
