@@ -82,7 +82,7 @@ def launch_ranks(n, argv, dry=False):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.setdefault("GPU_MAX_HW_QUEUES", "8")     # read by the HIP runtime at its first call: in place before the rank starts
+        env.setdefault("GPU_MAX_HW_QUEUES", "16")     # read by the HIP runtime at its first call: in place before the rank starts
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE, stderr=None if r == 0 else subprocess.PIPE, text=True))
     rc, outs = 0, []
@@ -122,7 +122,7 @@ class Workload:
             self.database = rg.synth.SyntheticDataset(db_size, seed=2025, device=dev, feat_device=dev)
         self.model = rg.build_architecture(rg.synth.reference_style_model_cfg(self.cfg, self.vae_cfgs, with_retrieval=self.guided),
                                            database=self.database if self.guided else None, device=dev, precision=precision,
-                                           lane_streams=Workload.streams)
+                                           lane_streams=Workload.streams, **json.loads(os.environ.get("RG_BENCH_MODEL_KWARGS", "{}")))
         if Workload.streams is None:
             Workload.streams = self.model.stream_set()
         self.model.load_state_dict(rg.synth.synth_full_state(0, self.cfg, self.vae_cfgs))
@@ -510,7 +510,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or unset WORLD_SIZE "
                          "to let bench.py start the ranks itself)" % (args.gpus, world, args.gpus))
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # (torchrun-started ranks: still before torch is imported)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # (torchrun-started ranks: still before torch is imported)
     if args.dry_launch:
         print(json.dumps(dict(rank=rank, local_rank=local_rank, world=world, master_addr=os.environ.get("MASTER_ADDR"),
                               master_port=os.environ.get("MASTER_PORT"), pid=os.getpid(),

@@ -21,7 +21,7 @@ constexpr int UNIT_BYTES = 512 * 512 * 2;
 
 // NS sequences per workgroup; NJ 16-feature blocks per wave (4: 8 waves x 64 features, 8: 4 waves x 128 features, one per
 // SIMD with 512 registers); RD ring slots per wave; RT: 0 accumulators stay in registers, 1 load + add + store per unit
-template <int NS, int NJ, int RD, int RT, int PF = 0>
+template <int NS, int NJ, int RD, int RT, int PF = 0, int BAR = 0, int PRIO = 0>
 __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __restrict__ wstream, float* __restrict__ R, int nunits,
                                                        int stream_units, float* out, unsigned long long* clk) {
   constexpr int NW = 32 / NJ, NB = NS * 3, FPU = 16 * NJ;     // waves, token blocks, fragments per unit and wave
@@ -43,8 +43,10 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
       if (++iu == stream_units) { iu = 0; soff = wave * (FPU * 1024); }
     }
   };
+  if constexpr (PF != 2) {
 #pragma unroll
-  for (int s = 0; s < RD; ++s) issue(s);
+    for (int s = 0; s < RD; ++s) issue(s);
+  }
   f32x4 acc[NJ][NB];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
@@ -53,8 +55,18 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
   const unsigned char* pl = smem + lane * 16;
   const unsigned char* rl = ring + lane * 16;
   f32x4* Rw = reinterpret_cast<f32x4*>(R) + ((size_t)(blockIdx.x * NW + wave) * (NJ * NB)) * 64 + lane;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x4 wr[8];
+  const u32x4* wsrc = reinterpret_cast<const u32x4*>(wstream) + lane;
+  auto frag_ptr = [&](int unit, int f) { return wsrc + ((size_t)((unit % stream_units) * NW + wave) * FPU + f) * 64; };
+  if constexpr (PF == 2) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) wr[f] = *frag_ptr(0, f);
+  }
+  unsigned long long tg = 0;
 #pragma unroll 1
   for (int u = 0; u < nunits; ++u) {
+    const unsigned long long tu0 = __builtin_amdgcn_s_memrealtime();
     if constexpr (PF == 0) {
     bf16x8 w[2], pf[2][NB];
       wait_vmcnt<RD - 1>();
@@ -95,6 +107,8 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
       for (int b = 0; b < NB; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16) << 10));
 #pragma unroll 1
       for (int s = 0; s < 16; ++s) {
+        if (PRIO == 1 && s == 0 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+        if (PRIO >= 2 && wave >= NW / 2) { if ((s >> (PRIO - 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           if (j == 0) __builtin_amdgcn_s_waitcnt(0xc07f | (NB << 8)); else __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -118,6 +132,39 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
         }
       }
     }
+    if constexpr (PF == 2) {     // weights straight into registers (no LDS ring): 8 fragments (two k-steps) in flight per wave
+      static_assert(NJ == 4, "register ring: 8 fragments = 2 k-steps");
+      bf16x8 pf[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16) << 10));
+#pragma unroll 1
+      for (int s2 = 0; s2 < 16; s2 += 2) {
+        if (PRIO == 1 && s2 == 0 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+        if (PRIO >= 2 && wave >= NW / 2) { if ((s2 >> (PRIO - 1)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          const int j = f & 3;
+          const bf16x8 wv = __builtin_bit_cast(bf16x8, wr[f]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            acc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, pf[b], acc[j][b], 0, 0, 0);
+            if (j == NJ - 1) {
+              pf[b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16 + s2 + (f >> 2) + 1) << 10));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          wr[f] = *frag_ptr(u + (s2 == 14), ((s2 + 2) & 15) * 4 + f);      // the same fragment slot, two k-steps on
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    tg += __builtin_amdgcn_s_memrealtime() - tu0;
+    if (BAR) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     if (RT) {      // residual round trip: 12 KiB per sequence and wave each way, lane-linear 1-KiB wave instructions
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -138,6 +185,7 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
     }
   }
   wait_vmcnt<0>();
+  if (lane == 0) clk[512 + blockIdx.x * 8 + wave] = tg;
   if (tid == 0) { clk[2 * blockIdx.x] = __builtin_readcyclecounter() - c0; clk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
   float s = 0.f;
 #pragma unroll
@@ -147,12 +195,12 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
   out[blockIdx.x * 512 + tid] = s;
 }
 
-template <int NS, int NJ, int RD, int RT, int PF = 0>
+template <int NS, int NJ, int RD, int RT, int PF = 0, int BAR = 0, int PRIO = 0>
 void run(const unsigned char* stream, int stream_units, float* R, int grid, float* out, unsigned long long* clk) {
   constexpr int NW = 32 / NJ;
   const int nunits = 260;
   const size_t lds = NS * 49152 + NW * RD * 1024;
-  auto k = probe<NS, NJ, RD, RT, PF>;
+  auto k = probe<NS, NJ, RD, RT, PF, BAR, PRIO>;
   CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -166,10 +214,13 @@ void run(const unsigned char* stream, int stream_units, float* R, int grid, floa
     if (ms < best) best = ms;
   }
   unsigned long long c[2]; CK(hipMemcpy(c, clk, sizeof(c), hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> wt(grid * 8); CK(hipMemcpy(wt.data(), clk + 512, wt.size() * 8, hipMemcpyDeviceToHost));
+  double told = 0, tyoung = 0;
+  for (int g = 0; g < grid; ++g) for (int w = 0; w < NW; ++w) (w < NW / 2 ? told : tyoung) += (double)wt[g * 8 + w] / 100.0 / nunits / (grid * NW / 2);
   const double us_unit = best * 1e3 / nunits, mhz = (double)c[0] / ((double)c[1] / 100.0);
   const double flop = 2.0 * 512 * 512 * 48 * NS;
-  printf("NS=%d waves=%d RD=%2d RT=%d PF=%d grid=%3d | %6.2f us/unit | rows x units / us / CU: %5.2f (48-row) %5.2f (43-row) | %5.1f GB/s/CU | "
-         "MFMA %5.1f TF/CU-set = %.3f of peak(grid CUs) | clk %4.0f MHz\n", NS, NW, RD, RT, PF, grid, us_unit, 48.0 * NS / us_unit, 43.0 * NS / us_unit,
+  printf("NS=%d waves=%d RD=%2d RT=%d PF=%d BAR=%d PRIO=%d grid=%3d | %6.2f us/unit (in-loop: first half of the waves %5.2f, second half %5.2f) | rows x units / us / CU: %5.2f (48-row) %5.2f (43-row) | %5.1f GB/s/CU | "
+         "MFMA %5.1f TF/CU-set = %.3f of peak(grid CUs) | clk %4.0f MHz\n", NS, NW, RD, RT, PF, BAR, PRIO, grid, us_unit, told, tyoung, 48.0 * NS / us_unit, 43.0 * NS / us_unit,
          UNIT_BYTES / us_unit / 1e3, flop * grid / us_unit / 1e6, flop * grid / us_unit / 1e6 / (2500.0 * grid / 256), mhz);
 }
 
@@ -183,14 +234,19 @@ int main() {
   CK(hipMalloc(&out, 256 * 512 * sizeof(float)));
   CK(hipMalloc(&R, (size_t)256 * 2 * 48 * 512 * sizeof(float)));
   CK(hipMemset(R, 0, (size_t)256 * 2 * 48 * 512 * sizeof(float)));
-  CK(hipMalloc(&clk, 256 * 2 * sizeof(unsigned long long)));
+  CK(hipMalloc(&clk, (512 + 256 * 8) * sizeof(unsigned long long)));
   CK(hipMemcpy(stream, h.data(), h.size() * 2, hipMemcpyHostToDevice));
   printf("today's rg_seq GEMM phases: 130 units x 43 rows / 720 us = 7.76 rows x units / us / CU; go >= 11.6 (43-row)\n");
-  for (int grid : {64, 128, 256}) {
-    run<1, 4, 7, 0>(stream, stream_units, R, grid, out, clk);    // today's loop
-    run<2, 4, 6, 0>(stream, stream_units, R, grid, out, clk);    // two sequences per fragment, accumulators resident
-    run<2, 4, 6, 0, 1>(stream, stream_units, R, grid, out, clk); // ... one set of panel-fragment registers, refreshed in place
-    run<2, 4, 6, 1>(stream, stream_units, R, grid, out, clk);    // + fp32 round trip through L2 per unit
+  for (int grid : {64, 256}) {
+    run<2, 4, 6, 0, 1, 1>(stream, stream_units, R, grid, out, clk);       // LDS ring, barrier per unit
+    run<2, 4, 6, 0, 1, 1, 1>(stream, stream_units, R, grid, out, clk);    // second half of the waves at priority 1
+    run<2, 4, 6, 0, 1, 1, 2>(stream, stream_units, R, grid, out, clk);    // ... on every other k-step
+    run<2, 4, 6, 0, 1, 1, 3>(stream, stream_units, R, grid, out, clk);    // ... on every other pair of k-steps
+    run<2, 4, 6, 0, 1, 1, 4>(stream, stream_units, R, grid, out, clk);    // ... four
+    run<2, 4, 6, 0, 2, 1>(stream, stream_units, R, grid, out, clk);       // register ring
+    run<2, 4, 6, 0, 2, 1, 1>(stream, stream_units, R, grid, out, clk);
+    run<2, 4, 6, 0, 2, 1, 2>(stream, stream_units, R, grid, out, clk);
+    run<2, 4, 6, 0, 2, 1, 3>(stream, stream_units, R, grid, out, clk);
   }
   return 0;
 }

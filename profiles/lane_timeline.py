@@ -29,6 +29,8 @@ if "SLOTS" in os.environ:
     model.slots = int(os.environ["SLOTS"])
 if "LANES" in os.environ:
     model.lanes = int(os.environ["LANES"])
+if "BATCH_LANES" in os.environ:
+    model.batch_lanes = int(os.environ["BATCH_LANES"])
 model.async_results = bool(int(os.environ.get("PIPELINED", "0")))
 model.calibrate_lanes = os.environ.get("CALIBRATE", "1") == "1"
 if "SAMPLE_LANES" in os.environ:

@@ -1,7 +1,8 @@
 """MI355X-native RAG-Gesture inference hot path."""
 import os as _os
 
-# The asynchronous pipeline keeps up to six streams busy at once (the caller's, up to four lanes, the retrieval search);
+# The asynchronous pipeline keeps up to eleven streams busy at once (the caller's, eight batch lanes, the retrieval search,
+# the decode stream);
 # the HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that
 # share a queue serialise.  Read when the runtime initialises (the first HIP call); a value the user has set wins.
 # The package must therefore be imported BEFORE the host application's first HIP call (bench.py and `bench.py --gpus N`
@@ -16,7 +17,7 @@ if "GPU_MAX_HW_QUEUES" not in _os.environ:
         _warnings.warn("rag-gesture_amd imported after the HIP runtime was initialised: GPU_MAX_HW_QUEUES keeps the runtime's "
                        "default (4 hardware queues); lanes that share a queue serialise (slower, never incorrect)")
     else:
-        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        _os.environ["GPU_MAX_HW_QUEUES"] = "16"
 from . import synth, schedule, capi, gemm, denoiser, sampler, vae, pipeline, retrieval, dist, packing, longform, features  # noqa: F401
 from .pipeline import MotionDiffusion, ReGestureTransformer, build_architecture, register_with_mmcv  # noqa: F401
 

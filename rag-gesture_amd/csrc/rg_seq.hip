@@ -684,7 +684,11 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
       for (int tb = 0; tb < 3; ++tb) {
         const float sd = 1.0f / rstd[tb];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xr[j][tb] *= sd;
+        for (int j = 0; j < 4; ++j) {
+          xr[j][tb] *= sd;
+          // (rounded here in both forward kernels: no contraction with the additions of the classifier-free tables behind it)
+          asm volatile("" : "+v"(xr[j][tb]));
+        }
       }
     }
     if (!cond) {

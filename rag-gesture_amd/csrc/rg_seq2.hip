@@ -816,7 +816,11 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         for (int tb = 0; tb < 3; ++tb) {
           const float sd = 1.0f / rstd[q][tb];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) X[q][j][tb] *= sd;
+          for (int j = 0; j < 4; ++j) {
+            X[q][j][tb] *= sd;
+            // (rounded here in both forward kernels: no contraction with the additions of the classifier-free tables behind it)
+            asm volatile("" : "+v"(X[q][j][tb]));
+          }
         }
     };
     if (!cond) {

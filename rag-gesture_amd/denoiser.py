@@ -246,7 +246,7 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False, xcd_affine=True, engine=None,
-                 styl_in_gemm=False, seq_launches=1, kv_grouped=True, seq_pairs=False, seq_duo=True):
+                 styl_in_gemm=False, seq_launches=1, kv_grouped=True, seq_pairs=False, seq_duo=None):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
@@ -296,7 +296,11 @@ class DenoiserSession:
         self.sq = None
         if self.engine == "seq":           # activations never leave the CU: no per-op buffers
             self.ln_mode = "exact"
-            self.sq = SQ.SeqForward(self, launches=seq_launches, pairs=seq_pairs, duo=seq_duo and seq_launches == 1)
+            # seq_duo: two same-kind sequences per workgroup (rg_seq2_forward: half the weight bytes per token row, 0.8 of the CU
+            # time per forward with seq_pairs) -- for the wide launches of a pipeline that fills the chip with them; None: with
+            # seq_pairs.  Narrow launches are faster (in latency) with one workgroup per sequence.  Same bits either way.
+            duo = bool(seq_pairs) if seq_duo is None else bool(seq_duo)
+            self.sq = SQ.SeqForward(self, launches=seq_launches, pairs=seq_pairs, duo=duo and seq_launches == 1)
             return
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
         # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide, or 64 wide

@@ -105,6 +105,11 @@ class LongformSynthesizer:
                          "long-form synthesis (pipelined): the model's submit() pipeline must be empty (call flush() first)")
         state = dict(so_far=None, gt_so_far=None, n=0)
         prev_latent, latents = None, []
+        # the windows of ONE clip are a dependent chain (window k + 1 samples from window k's latent): they stay on one lane,
+        # where window k + 1's exemplar inversion shares the denoiser launches of window k's sampling, instead of rotating
+        rot_before = getattr(self.model, "rotation_lanes", None)
+        if pipelined:
+            self.model.rotation_lanes = 1
 
         def take(out):
             cidx = state["n"]
@@ -150,6 +155,7 @@ class LongformSynthesizer:
         if pipelined:
             for out in self.model.flush():
                 take(out)
+            self.model.rotation_lanes = rot_before
         capi.require(state["n"] == len(starts), "long-form synthesis: windows left in the pipeline")
         so_far, gt_so_far = state["so_far"], state["gt_so_far"]
         motion, facial, trans = so_far

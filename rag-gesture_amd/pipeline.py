@@ -342,7 +342,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=3,
-                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
+                 batch_lanes=8, lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -371,6 +371,7 @@ class MotionDiffusion(torch.nn.Module):
         self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
         # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
+        self.rotation_lanes = None     # submit(): lanes in the rotation of whole batches (None: batch_lanes / base_lanes); longform.py pins 1
         self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
         # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
         # (one pipeline per lane when whole batches alternate between the lanes, cobatch_lanes="batch"; else one, key None)
@@ -733,9 +734,13 @@ class MotionDiffusion(torch.nn.Module):
             # whole batches rotate over the lanes: this one runs (inversion now, sampling one rotation later) on one
             # lane's stream while the batches submitted before it are busy on the others
             # (base: nothing to share launches with, more and smaller chains; with inversion: the co-batched chains)
-            plan = self._lane_plan(B, self.batch_lanes if use_inversion else self.base_lanes)
-            pid = cob["lane"] % len(plan)
-            plan = plan_s = [(pid, plan[pid][1], 0, B)]
+            # (the lane is a function of the submission count and the lane count ONLY: a batch of fewer clips than lanes must
+            #  not change the modulus, or it lands on a lane whose pending batch is not the oldest)
+            self._lane_plan(B)                                   # (makes the streams on first use)
+            n_rot = getattr(self, "rotation_lanes", None) or (self.batch_lanes if use_inversion else self.base_lanes)
+            n_rot = max(1, min(int(n_rot), len(self._lane_streams)))
+            pid = cob["lane"] % n_rot
+            plan = plan_s = [(pid, self._lane_streams[pid], 0, B)]
         if run_async:
             self._slot = self._take_slot(pid, main, self._lanes_of(plan, plan_s))
         else:
@@ -1229,7 +1234,7 @@ class MotionDiffusion(torch.nn.Module):
             self._inflight.append(done)
             # (whole batches in rotation: every lane's next chain is queued behind its running one before the host waits)
             #  measured: 4 lanes 38.4 ms per step with 4 in flight, 36.2 with 6; 2 lanes 38.7 with 2, 43.7 with 4)
-            rot = self.base_lanes if not st.use_inversion else (2 * self.batch_lanes - 2 if st.pid is not None else 0)
+            rot = self.base_lanes if not st.use_inversion else (2 * self.batch_lanes + 4 if st.pid is not None else 0)
             while len(self._inflight) > max(self.max_inflight, rot):
                 self._inflight.popleft().synchronize()
         elif tail is not main:

@@ -126,7 +126,7 @@ def test_async_pipeline_equals_synchronous_forwards(rg, guided):
     assert torch.equal(out["pred_upper"], ref[0]["pred_upper"])
 
 
-@pytest.mark.parametrize("mode", ["batch", "batch4-pairs", "split", "one-lane"])
+@pytest.mark.parametrize("mode", ["batch", "batch4-pairs", "batch4-small", "split", "one-lane"])
 def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
     """submit() / flush(): the sampling loop of batch n advances in the same denoiser launches as the exemplar inversion
     of batch n + 1 (shared sessions, two step groups per forward); a batch without exemplars in a lane or of another size
@@ -148,6 +148,12 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
         batches = _batches(rg, B, 12, dev) + _batches(rg, 2, 1, dev)
         kinds = ["guided"] * 5 + ["inv", "guided", "base", "guided", "guided", "inv", "guided", "guided"]
 
+    if mode == "batch4-small":
+        # batches of FEWER clips than lanes behind full ones (4, 4, 4, 4, 4, 2, 1, 1, 3, 4): the lane of a batch must not depend
+        # on its size, or a small batch samples a lane's pending batch while an older one is still pending elsewhere
+        batches = _batches(rg, B, 5, dev) + _batches(rg, 2, 1, dev) + _batches(rg, 1, 2, dev) + _batches(rg, 3, 1, dev) + _batches(rg, B, 1, dev)
+        kinds = ["guided"] * 10
+
     def ikw(i):
         k = dict(guided=dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1),
                  inv=dict(use_inversion=True), base={})[kinds[i]]
@@ -166,8 +172,11 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
     model.async_results = True
     if mode == "one-lane":
         model.lanes = model.batch_lanes = 1    # a single pipeline on a single lane stream
+    elif mode == "batch4-small":
+        model.batch_lanes = 4
     elif mode == "batch4-pairs":
-        assert model.batch_lanes == 4 and model.cobatch_lanes == "batch"
+        assert model.batch_lanes == 8 and model.cobatch_lanes == "batch"
+        model.batch_lanes = 4
         torch.cuda.synchronize()     # (the references above ran one workgroup per sequence: new sessions from here on)
         model._sessions.clear(), model._graphs.clear(), model._graph_owner.clear()
         model.session_options["seq_pairs"] = True
@@ -252,9 +261,9 @@ def test_unchanged_tool_loop_and_three_line_pipelined_loop(rg):
         got.append(_tool_body(rg, output))
     got += [_tool_body(rg, output) for output in model.flush()]
     _same(got, want, model, "submit()/flush() loop")
-    # the schedule is fixed by the constructor arguments alone: four batch lanes (two of them the lanes of a synchronous forward,
+    # the schedule is fixed by the constructor arguments alone: eight batch lanes (two of them the lanes of a synchronous forward,
     # three the base lanes) + search + decode
-    assert (len(model._lane_streams), model._search_stream is not None, model._decode_stream is not None) == (4, True, True), _where(model)
+    assert (len(model._lane_streams), model._search_stream is not None, model._decode_stream is not None) == (8, True, True), _where(model)
 
 
 def test_base_batches_alternate_between_base_lanes(rg):

@@ -193,11 +193,11 @@ def test_stylization_inside_gemm_matches_separate_pass(rg, B):
     assert e <= 5e-3
 
 
-@pytest.mark.parametrize("B", [1, 3, 11])
-def test_seq_forward_matches_launch_chain_and_oracle(rg, parity, setup, B):
-    """The sequence-stationary forward (rg_seq_forward: one workgroup per sequence, one launch) against the per-op launch
-    chain on the same weights / conditions / masks (both bf16 MFMA operands: they differ by where bf16 roundings fall)
-    and against the fp32 oracle; every sequence of the batch is checked."""
+@pytest.mark.parametrize("B,duo", [(1, False), (3, False), (11, False), (1, True), (3, True), (11, True)])
+def test_seq_forward_matches_launch_chain_and_oracle(rg, parity, setup, B, duo):
+    """The sequence-stationary forward (rg_seq_forward: one workgroup per sequence, one launch; duo: rg_seq2_forward, two
+    sequences of a kind per workgroup) against the per-op launch chain on the same weights / conditions / masks (both bf16
+    MFMA operands: they differ by where bf16 roundings fall) and against the fp32 oracle; every sequence of the batch is checked."""
     cfg, P, W = setup[8]
     data = rg.synth.synth_batch(B, seed=77)
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal((B, 43, 512)).astype(np.float32))
@@ -208,8 +208,8 @@ def test_seq_forward_matches_launch_chain_and_oracle(rg, parity, setup, B):
     qm = od.make_query_masks(mm)
     outs = {}
     for engine in ("seq", "chain"):
-        sess = rg.denoiser.DenoiserSession(W, B, engine=engine)
-        assert (sess.sq is not None) == (engine == "seq")
+        sess = rg.denoiser.DenoiserSession(W, B, engine=engine, seq_duo=duo)
+        assert (sess.sq is not None) == (engine == "seq") and (engine != "seq" or sess.sq.duo == duo)
         sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
         for step in (49, 7):
             outs[engine, step] = sess.forward(x.cuda(), step).clone()
@@ -227,7 +227,7 @@ def test_seq_forward_matches_launch_chain_and_oracle(rg, parity, setup, B):
             assert e <= 1.5e-2, (B, step, r, e)
         print("B=%d step=%d seq vs launch chain: rel err %.3e" % (B, step, relerr(a, b)))
     # against the fp32 oracle (CFG-mixed x0, exact LayerNorm on the -1e6 rows like the kernels), all 43 rows
-    sess = rg.denoiser.DenoiserSession(W, B, engine="seq")
+    sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_duo=duo)
     sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, qm)
     x0 = _hip_x0(rg, W, sess, x, 7)
     od.OPTS.update(masked_ln="exact")
@@ -237,20 +237,23 @@ def test_seq_forward_matches_launch_chain_and_oracle(rg, parity, setup, B):
         od.OPTS.update(masked_ln="torch")
     e = relerr(x0, ref)
     emax = ((x0 - ref).norm(dim=-1) / ref.norm(dim=-1)).max().item()
-    parity.check("seq forward B=%d (bf16): x0 vs fp32 oracle, all rows" % B, e, 1e-2)
-    parity.check("seq forward B=%d (bf16): x0 vs fp32 oracle, worst token row" % B, emax, 3e-2)
+    tag = "two sequences per workgroup" if duo else "one sequence per workgroup"
+    parity.check("seq forward B=%d, %s (bf16): x0 vs fp32 oracle, all rows" % (B, tag), e, 1e-2)
+    parity.check("seq forward B=%d, %s (bf16): x0 vs fp32 oracle, worst token row" % (B, tag), emax, 3e-2)
 
 
-def test_seq_forward_two_step_groups(rg, setup):
+@pytest.mark.parametrize("duo,split", [(False, 2), (True, 2), (True, 3), (True, 0), (True, 5)])
+def test_seq_forward_two_step_groups(rg, setup, duo, split):
     """Clips [split, B) at another diffusion step in the same launch (the co-batched pipeline) == two separate forwards,
-    bit for bit: a workgroup's arithmetic does not depend on its neighbours."""
+    bit for bit: a workgroup's arithmetic does not depend on its neighbours (duo: pairs are formed inside a step group; odd
+    groups end in a lone sequence)."""
     cfg, P, W = setup[8]
-    B, split = 5, 2
+    B = 5
     data = rg.synth.synth_batch(B, seed=78)
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(6)).standard_normal((B, 43, 512)).astype(np.float32)).cuda()
     mm = torch.ones(B, 43)
     mm[:, [10, 21, 32]] = 0
-    sess = rg.denoiser.DenoiserSession(W, B, engine="seq")
+    sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_duo=duo)
     sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
     both = sess.forward(x, 40, 9, split).clone().view(2, B, 43, 512)
     a = sess.forward(x, 40).clone().view(2, B, 43, 512)
@@ -280,7 +283,10 @@ def test_seq_forward_cut_into_several_launches_is_bit_identical(rg, setup):
 
 @pytest.mark.parametrize("B", [1, 5, 16, 64])
 def test_seq_forward_one_workgroup_per_clip_is_bit_identical(rg, setup, B):
-    """DenoiserSession(seq_pairs=True): B workgroups, each running a clip's conditional sequence and then its classifier-free
+    """All launch forms of the sequence-stationary forward give the same bits: one workgroup per sequence (the reference
+    form here), per clip, cut into several launches, and rg_seq2_forward's two sequences of a kind per workgroup with the
+    classifier-free pairs in workgroups of their own or behind the conditional ones.
+    DenoiserSession(seq_pairs=True): B workgroups, each running a clip's conditional sequence and then its classifier-free
     twin, instead of 2 B workgroups (what the pipeline picks for launches that would not fit the chip beside the other batch
     lanes').  Same bits: with two step groups, real masks, cut into several launches (the hand-over buffer is per sequence),
     and over consecutive forwards of one session (nothing of a pass survives into the next)."""
@@ -291,13 +297,14 @@ def test_seq_forward_one_workgroup_per_clip_is_bit_identical(rg, setup, B):
     mm[:, [10, 21, 32]] = 0
     mm[0, 30:] = 0
     outs = {}
-    for pairs, n in ((False, 1), (True, 1), (True, 3)):
-        sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=pairs, seq_launches=n)
-        assert sess.sq.args.pairs == int(pairs)
+    for pairs, n in ((False, 1), (True, 1), (True, 3), (False, "duo"), (True, "duo")):
+        duo = n == "duo"
+        sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=pairs, seq_launches=1 if duo else n, seq_duo=duo)
+        assert sess.sq.args.pairs == int(pairs) and sess.sq.duo == duo
         sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
         outs[pairs, n] = [sess.forward(x, st, sb, sp).clone() for st, sb, sp in ((49, None, None), (23, 40, max(1, B // 3)), (0, None, None))]
         torch.cuda.synchronize()
-    for key in ((True, 1), (True, 3)):
+    for key in ((True, 1), (True, 3), (False, "duo"), (True, "duo")):
         for i, (a, b) in enumerate(zip(outs[key], outs[False, 1])):
             assert torch.isfinite(a).all() and torch.equal(a, b), (B, key, i, (a - b).abs().max().item())
     assert not torch.equal(outs[False, 1][0], outs[False, 1][2])

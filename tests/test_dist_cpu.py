@@ -90,7 +90,7 @@ def test_bench_launcher_starts_one_process_per_gpu():
     assert r.returncode == 0, r.stderr
     ranks = json.loads(r.stdout.strip().splitlines()[-1])
     assert sorted(x["local_rank"] for x in ranks) == list(range(8)) and len({x["pid"] for x in ranks}) == 8
-    assert all(x["hw_queues"] == "8" and x["torch_imported"] is False and x["ipc_legacy"] == "0" for x in ranks), ranks
+    assert all(x["hw_queues"] == "16" and x["torch_imported"] is False and x["ipc_legacy"] == "0" for x in ranks), ranks
     # a value the user has set wins
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
                        env=dict(env8, GPU_MAX_HW_QUEUES="6"), capture_output=True, text=True, timeout=120)

@@ -138,17 +138,17 @@ def test_config3_guided_b16_full_db_vs_oracle(rg, parity):
 
 
 def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity):
-    """What bench.py times: asynchronous submission, co-batched pipeline, whole batches rotating over the batch lanes (four,
-    one workgroup per clip: DenoiserSession seq_pairs, picked by the pipeline for launches of this width).  Batch n shares a
-    lane with batches n - 4 and n + 4: of nine different batches the fifth has its exemplar inversion co-batched with an
-    earlier batch's sampling loop and its own sampling with a later batch's inversion: every step-group code path and the
-    real exemplar counts meet the independent reference here."""
+    """What bench.py times: asynchronous submission, co-batched pipeline, whole batches rotating over the batch lanes (eight;
+    DenoiserSession seq_pairs + seq_duo, picked by the pipeline for launches of this width: a workgroup runs two conditional
+    sequences, then their classifier-free twins).  Batch n shares a lane with batches n - 8 and n + 8: of seventeen different
+    batches the ninth has its exemplar inversion co-batched with an earlier batch's sampling loop and its own sampling with a
+    later batch's inversion: every step-group code path and the real exemplar counts meet the independent reference here."""
     dev = torch.device("cuda", 0)
     B, N_DB = 16, 32768
     cfg, vae_cfgs, database, model, P, cpu_db = _guided_setup(rg, dev, B, N_DB)
     model.async_results = True
     L = model.batch_lanes
-    assert L == 4
+    assert L == 8
     ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
     outs, keeps, tapes, exs = [], [], [], []
     for n in range(2 * L + 1):
@@ -164,9 +164,9 @@ def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity):
     for r in outs:
         model.wait_results(r)
     torch.cuda.synchronize()
-    paired = {k[:2]: s.sq.args.pairs for k, s in model._sessions.items() if s.sq is not None}
-    assert [v for k, v in paired.items() if k[1] == "cobatch"] and all(v == 1 for k, v in paired.items() if k[1] == "cobatch"), paired
-    # (16 clips + their exemplars in a launch, four lanes: one workgroup per clip)
+    paired = {k[:2]: (s.sq.args.pairs, int(s.sq.duo)) for k, s in model._sessions.items() if s.sq is not None}
+    assert [v for k, v in paired.items() if k[1] == "cobatch"] and all(v == (1, 1) for k, v in paired.items() if k[1] == "cobatch"), paired
+    # (16 clips + their exemplars in a launch, eight lanes: 32 workgroups of two clips each)
     assert any(k[0] == "cobatch" for k in model._graphs)
     assert len(exs[L]) >= B
     assert not torch.equal(outs[0]["prev_latentout"], outs[L]["prev_latentout"])

@@ -247,9 +247,11 @@ def test_batch_lane_rules_results_in_submission_order_and_paired_launches(rg):
                2: types.SimpleNamespace(seq=6)}
     assert m._pending_upto(5) == [3, 0, 1]           # a base batch on lane 1 meets batch 5: 3 and 4 go first
     assert m._pending_upto(3) == [3] and m._pending_upto(2) == [] and m._pending_upto(99) == [3, 0, 1, 2]
-    m.async_results, m.batch_lanes, m._cob = True, 4, dict(lane=7)
+    m.async_results, m.batch_lanes, m._cob = True, 8, dict(lane=7)
     assert m._seq_pairs_auto(64, cus=256) and m._seq_pairs_auto(48, cus=256)       # co-batched chains, 48-exemplar inversions
-    assert not m._seq_pairs_auto(16, cus=256) and not m._seq_pairs_auto(32, cus=256)   # a draining batch's 16 clips; 2 x 32 x 4 = 256 fits
+    assert not m._seq_pairs_auto(16, cus=256) and m._seq_pairs_auto(32, cus=256)   # a draining batch's 16 clips: 2 x 16 x 8 = 256 fits
+    m.batch_lanes = 4
+    assert m._seq_pairs_auto(64, cus=256) and not m._seq_pairs_auto(32, cus=256)   # 2 x 32 x 4 = 256 fits
     m.batch_lanes = 2
     assert not m._seq_pairs_auto(64, cus=256)        # two lanes of 128 workgroups fit
     m.batch_lanes, m._cob = 4, None
