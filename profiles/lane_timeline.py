@@ -117,6 +117,27 @@ if os.environ.get("HOSTBLOCK"):
         for nm in names:
             wrap(owner, nm)
 
+if os.environ.get("TIMED_REGION"):
+    # what bench.py times: K submissions into an EMPTY pipeline + flush(), no synchronisation in between
+    K = int(os.environ["TIMED_REGION"])
+    model.flush()
+    torch.cuda.synchronize()
+    for _ in range(K):            # (a first, untraced region: its fill and drain capture the graphs they need)
+        one_step(sync=False)
+    model.flush()
+    torch.cuda.synchronize()
+    one_step(trace=True, sync=False)
+    for _ in range(K - 1):
+        one_step(sync=False)
+    model.flush()
+    torch.cuda.synchronize()
+    print("timed region: %d batches + flush done at %.1f ms" % (K, (time.perf_counter() - t_step[0]) * 1e3))
+    for i, (key, h0, h1, e0, e1) in enumerate(log):
+        if key[0] in ("cobatch", "dec", "invert", "sample", "inv", "loop") or "cob" in str(key[0]) or True:
+            print("   %-44s host call %6.1f -> %6.1f ms | device %6.1f -> %6.1f ms (%.1f)" % (
+                str(key)[:44], h0, h1, ev_step[0].elapsed_time(e0), ev_step[0].elapsed_time(e1), e0.elapsed_time(e1)))
+    sys.exit(0)
+
 if os.environ.get("BACK_TO_BACK"):
     # three steps without a synchronisation in between: where does step n + 1 start relative to step n's end?
     one_step(trace=True, sync=False)

@@ -16,7 +16,8 @@ B, REPS, L, T = int(os.environ.get("SEQ_B", "64")), int(os.environ.get("SEQ_REPS
 cfg = rg.synth.default_model_cfg(num_layers=L)
 W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, rg.schedule.Schedule(), "cuda")
 PAIRS = os.environ.get("SEQ_PAIRS", "0") == "1"     # one workgroup per clip (conditional sequence, then its twin): B workgroups
-sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=PAIRS)
+DUO = os.environ.get("SEQ_DUO", "0") == "1"         # rg_seq2_forward: two sequences of a kind per workgroup (with PAIRS: B / 2 workgroups)
+sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=PAIRS, seq_duo=DUO)
 d = rg.synth.synth_batch(B, seed=1)
 mask = torch.ones(B, 43); mask[:, [10, 21, 32]] = 0
 sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, {c: mask.clone() for c in rg.denoiser.CONDS})
@@ -38,5 +39,10 @@ alg = (st.wstream.numel() * 2 + 2 * (st.pstream[0].numel() * 4 + st.ustream[0].n
 # bytes the workgroups pull through their LDS rings (what the per-CU intake sees): every sequence streams its own copy
 per_cond = (16 * L + 2) * 520 * 1024 + L * 3 * 64 * 1024
 per_unc = (10 * L + 2) * 520 * 1024 + L * 16 * 1024
-print(json.dumps(dict(kernel="rg_seq_kernel", sequences=2 * B, workgroups=B if PAIRS else 2 * B, launches=REPS, flops_per_launch=flops, algorithmic_hbm_bytes=alg,
-                      lds_ring_bytes=B * (per_cond + per_unc))))
+if DUO:   # + the fp32 tile round trips (3 per layer) and bf16 panel images (4 per layer for conditional pairs) through xbuf / gbuf: L2-resident scratch
+    scratch = (B // 2) * L * ((3 + 3) * 2 * 96 * 1024 + (2 + 2) * 2 * 96 * 1024 + 4 * 2 * 2 * 48 * 1024)
+else:
+    scratch = 0
+wgs = (B // 2 if PAIRS else B) if DUO else (B if PAIRS else 2 * B)
+print(json.dumps(dict(kernel="rg_seq2_kernel" if DUO else "rg_seq_kernel", sequences=2 * B, workgroups=wgs, launches=REPS, flops_per_launch=flops, algorithmic_hbm_bytes=alg,
+                      lds_ring_bytes=B * (per_cond + per_unc) // (2 if DUO else 1), scratch_round_trip_bytes=scratch)))

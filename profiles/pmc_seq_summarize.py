@@ -12,7 +12,7 @@ def find(root, sub, pat):
 
 
 def rows(path, name=None):
-    out = [r for r in csv.DictReader(open(path)) if "rg_seq_kernel" in r.get("Kernel_Name", "") and (name is None or r.get("Counter_Name") == name)]
+    out = [r for r in csv.DictReader(open(path)) if ("rg_seq_kernel" in r.get("Kernel_Name", "") or "rg_seq2_kernel" in r.get("Kernel_Name", "")) and (name is None or r.get("Counter_Name") == name)]
     out.sort(key=lambda r: int(r["Dispatch_Id"]))
     return out
 

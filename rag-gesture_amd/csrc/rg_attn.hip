@@ -1324,11 +1324,8 @@ extern "C" int rg_ca_stylize_groups(rg_handle* h, const float* q3, const void* A
   const int Tp = (T + 7) & ~7;
   const size_t lds = ((size_t)CS_WAVES * 2 * Tp + 2 * Tp + Tp + (size_t)(D / HD) * Tp * HD) * sizeof(float);
   RG_REQUIRE(h, lds <= 160 * 1024, "row group does not fit LDS (D <= 768)");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)ca_stylize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (ca_stylize_kernel), 160 * 1024);
   CaStylizeArgs a;
   a.q3 = q3; a.At = reinterpret_cast<const unsigned short*>(At_bf16); a.qmask = qmask; a.gamma = gamma; a.beta = beta; a.scale_shift = scale_shift;
   a.unc_tab = reinterpret_cast<const unsigned short*>(unc_tab_bf16);
@@ -1358,11 +1355,8 @@ extern "C" int rg_sa_stylize(rg_handle* h, const float* qk, int ldqk, const void
   const int Tp = (T + 15) & ~15;
   const size_t lds = (size_t)SS_WAVES * (Tp * HD * 6) + ((size_t)SS_WAVES * 2 * Tp + 2 * Tp + Tp) * sizeof(float);
   RG_REQUIRE(h, lds <= 160 * 1024, "row group does not fit LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sa_stylize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (sa_stylize_kernel), 160 * 1024);
   SaStylizeArgs a;
   a.qk = qk; a.v = reinterpret_cast<const unsigned short*>(v_bf16); a.src_mask = src_mask; a.gamma = gamma; a.beta = beta;
   a.scale_shift = scale_shift; a.out = reinterpret_cast<unsigned short*>(out_bf16); a.perm = perm;

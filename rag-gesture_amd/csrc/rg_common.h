@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/rg_gesture.h"
+#include "rg_once.h"
 
 #include <vector>
 
@@ -44,6 +45,20 @@ struct rg_handle {
   } while (0)
 
 static inline hipStream_t rg_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// the device the calling thread launches on (the handle's device for every entry point that has one)
+static inline int rg_current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
+// LDS reservation of a kernel, once per device (rg_once.h)
+template <class K>
+static inline bool rg_reserve_lds(rg_attr_once& once, K kernel, size_t bytes) {
+  return once(rg_current_device(), [&]() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+  });
+}
 
 // grid for a grid-stride memory-bound kernel: enough blocks to fill 256 CUs x 8, no more.
 static inline int rg_grid_1d(int64_t work_items, int block) {

@@ -380,13 +380,9 @@ size_t lds_bytes(int nseg) {
 
 template <bool A_BF16, bool SPLIT, bool FAST>
 void launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
-  static bool attr = false;
+  static rg_attr_once lds_once;
   const size_t lds = lds_bytes<A_BF16, SPLIT>(d->nseg);
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<A_BF16, SPLIT, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_bytes<A_BF16, SPLIT>(RG_MAX_SEG));
-    attr = true;
-  }
+  (void)rg_reserve_lds(lds_once, (gemm_kernel<A_BF16, SPLIT, FAST>), (int)lds_bytes<A_BF16, SPLIT>(RG_MAX_SEG));
   hipLaunchKernelGGL((gemm_kernel<A_BF16, SPLIT, FAST>), rg_group_grid(grid), dim3(NT), lds, s, rg_group_of(d));
 }
 

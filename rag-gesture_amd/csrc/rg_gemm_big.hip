@@ -136,12 +136,8 @@ __global__ void __launch_bounds__(512, MINW) gemm_bf16_big_kernel(const rg_gemm_
 
 template <int BNT, int NS = 3, int MINW = 1>
 void big_launch(const rg_gemm_desc* d, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<BNT, NS, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
-    attr = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (gemm_bf16_big_kernel<BNT, NS, MINW>), 160 * 1024);
   const int mt = (d->M + BBM - 1) / BBM, nt = (d->N + BNT - 1) / BNT;
   size_t lds = (size_t)NS * (BBM + BNT) * ROW_BYTES;
   const size_t epi = (size_t)2 * (BNT / 128) * BM * SC_LD * sizeof(float);

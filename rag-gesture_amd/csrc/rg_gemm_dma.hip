@@ -440,12 +440,8 @@ size_t dma_lds_bytes(int nseg, int ns, size_t LN_ROWS) {
 
 template <bool A_BF16, bool SPLIT, int NS, int NW>
 void dma_launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<A_BF16, SPLIT, NS, NW>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    attr = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (gemm_dma_kernel<A_BF16, SPLIT, NS, NW>), (int)LDS_MAX);
   const size_t lds = dma_lds_bytes<A_BF16, SPLIT>(d->nseg, NS, stat_bytes(d));
   hipLaunchKernelGGL((gemm_dma_kernel<A_BF16, SPLIT, NS, NW>), rg_group_grid(grid), dim3(NW * 64), lds, s, rg_group_of(d));
 }
@@ -453,12 +449,8 @@ void dma_launch(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
 // 64x64 tiles, bf16 A, 4 waves (2x2, 32x32 each), 4-stage ring of 16 KiB; the epilogue tile keeps its 128-column stride
 template <int NS>
 void dma_launch_narrow_ns(const rg_gemm_desc* d, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, NS, 4, 64>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    attr = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (gemm_dma_kernel<true, false, NS, 4, 64>), (int)LDS_MAX);
   size_t lds = (size_t)NS * (A_TILE + 64 * ROW_BYTES) + stat_bytes(d);
   const size_t epi = (size_t)BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
@@ -477,12 +469,8 @@ void dma_launch_narrow(const rg_gemm_desc* d, hipStream_t s) { dma_launch_narrow
 // tile ahead, so one stage less is in flight than the ring is deep), 3 stages + tables = 76.5 KiB where two share it
 template <int NS, int NW>
 void dma_launch_styl(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, NS, NW, BN, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    attr = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (gemm_dma_kernel<true, false, NS, NW, BN, true>), (int)LDS_MAX);
   size_t lds = (size_t)NS * (A_TILE + W_TILE) + stat_bytes(d) + 2 * SEG_MAX * sizeof(float);
   const size_t epi = (size_t)BM * SC_LD * sizeof(float);
   if (epi > lds) lds = epi;
@@ -491,12 +479,8 @@ void dma_launch_styl(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
 
 // 8 waves, ring of 3 (76.5 KiB), at most 128 VGPRs (no residual prefetch): two workgroups per CU
 void dma_launch_pair(const rg_gemm_desc* d, dim3 grid, hipStream_t s) {
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_dma_kernel<true, false, 3, 8, BN, false, 4>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
-    attr = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (gemm_dma_kernel<true, false, 3, 8, BN, false, 4>), (int)LDS_MAX);
   const size_t lds = dma_lds_bytes<true, false>(0, 3, stat_bytes(d));
   hipLaunchKernelGGL((gemm_dma_kernel<true, false, 3, 8, BN, false, 4>), rg_group_grid(grid), dim3(512), lds, s, rg_group_of(d));
 }

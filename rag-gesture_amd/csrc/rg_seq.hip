@@ -468,13 +468,16 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb)
-        panel_store(panel, l15, g4, j, tb, (v[j][tb][0] - mean[tb]) * rstd[tb], (v[j][tb][1] - mean[tb]) * rstd[tb],
-                    (v[j][tb][2] - mean[tb]) * rstd[tb], (v[j][tb][3] - mean[tb]) * rstd[tb]);
+        {
+          const float r = rstd[tb], nm = -mean[tb] * r;      // (v - mean) rstd as ONE fused multiply-add per value (as rg_seq2.hip)
+          panel_store(panel, l15, g4, j, tb, fmaf(v[j][tb][0], r, nm), fmaf(v[j][tb][1], r, nm), fmaf(v[j][tb][2], r, nm), fmaf(v[j][tb][3], r, nm));
+        }
   };
   // StylizationBlock front half: SiLU(LN(y) * (1 + scale) + shift) with gain = gamma (1 + scale), off = beta (1 + scale)
   // + shift = vectors 1, 2 of the consuming unit's parameter fragment `ps`
   auto write_styl = [&](unsigned char* panel, const Acc& v, const float (&mean)[3], const float (&rstd)[3], const unsigned char* ps) {
     LANE_LOCAL();
+    const float nmr[3] = {-mean[0] * rstd[0], -mean[1] * rstd[1], -mean[2] * rstd[2]};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 gain = par_t(ps, 1, j, g4), off = par_t(ps, 2, j, g4);
@@ -482,7 +485,7 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
       for (int tb = 0; tb < 3; ++tb) {
         float o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf((v[j][tb][r] - mean[tb]) * rstd[tb], gain[r], off[r]));
+        for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf(fmaf(v[j][tb][r], rstd[tb], nmr[tb]), gain[r], off[r]));
         panel_store(panel, l15, g4, j, tb, o[0], o[1], o[2], o[3]);
       }
     }
@@ -852,13 +855,10 @@ extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* 
   RG_REQUIRE(h, 0 <= a.l0 && a.l0 < a.l1 && a.l1 <= a.L, "layer range [l0, l1) must be a non-empty part of [0, L)");
   RG_REQUIRE(h, (a.l0 == 0 && a.l1 == a.L) || a.xbuf, "a partial layer range needs the hand-over buffer xbuf");
   RG_REQUIRE(h, a.pairs == 0 || a.pairs == 1, "pairs must be 0 or 1");
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)rg_seq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      h->err = "rg_seq_forward: cannot reserve LDS";
-      return RG_ERR_HIP;
-    }
-    attr = true;
+  static rg_attr_once lds_once;
+  if (!rg_reserve_lds(lds_once, rg_seq_kernel, LDS_BYTES)) {
+    h->err = "rg_seq_forward: cannot reserve LDS";
+    return RG_ERR_HIP;
   }
   rg_prof_rec rec;
   if (h->profiling) {   // bench.py roofline: HIP events around the launch (variant 3), algorithmic FLOPs of the T token rows

@@ -9,14 +9,15 @@
 //   * the residual stream no longer lives in registers across a block: it takes the fp32 round trip through `xbuf` (L2, lane-
 //     linear 1-KiB wave instructions) three times per layer -- stored when a block starts, loaded back as the accumulator
 //     initialiser of the block's output projection while the stylization in front of it is being computed;
-//   * one bf16 panel per sequence (2 x 48 KiB) instead of two: operands that the old kernel parked in the second panel are
-//     HELD in registers as packed bf16 (48 VGPRs for both sequences) until the panel is free -- the stylized cross-attention
-//     rows of a condition, the two GELU halves of the FFN -- and the units were re-ordered so that at most one such operand is
-//     held beside a live accumulator (cross attention: Q3_0, MIXX, MIX_0 | Q3_1, Q3_2, MIX_1, MIX_2; FFN: FF1_0, FF1_1, FF2_0,
-//     FF2_1); the normalised x of the cross-attention block, needed again after MIX_0 used the panel, is kept as a bf16 image
-//     in `gbuf` (L2) and copied back;
+//   * one bf16 panel per sequence (2 x 48 KiB) instead of two.  Operands that the old kernel parked in the second panel either
+//     wait in registers as packed bf16 (48 VGPRs for both sequences: the two GELU halves of the FFN, units re-ordered FF1_0,
+//     FF1_1, FF2_0, FF2_1) or go through `gbuf` (L2) as bf16 panel images, every wave writing and later restoring its own
+//     fragments: the normalised x of the cross-attention block (the three query projections need it, the MIX units overwrite
+//     it) and the stylized rows of the three conditions (held in registers beside the queries' accumulator they spilled ~120
+//     registers each).  Cross-attention order: Q3_0, MIXX, MIX_0 | Q3_1, Q3_2, MIX_1, MIX_2, the accumulator in xbuf between;
+//   * the six panel fragments of a k-step live in one set of registers, re-read in place behind their last MFMA;
 //   * everything that touches memory besides the ring is issued at the START of an epilogue (statistics, barriers), never in
-//     front of a GEMM loop: the ring's counted vmcnt then never waits for it.
+//     front of a GEMM loop: the ring's counted vmcnt then rarely waits for it.  No scratch, 251 VGPRs.
 // Arithmetic per sequence is the old kernel's, operation for operation (same MFMA accumulation order, same epilogues): the two
 // kernels agree bit for bit (tests/test_denoiser_gpu.py), and a sequence's result does not depend on its partner.
 // Layouts, weight / parameter / table streams: rg_seq.hip and include/rg_gesture.h (rg_seq_args).
@@ -279,7 +280,10 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     cur_rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
   };
   auto issue = [&](int slot) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_rsrc, (lds_void*)(ring + slot * 1024), 16, lane16, ir << 10, 0, 0);
+    #ifndef RG2_RING_AUX
+#define RG2_RING_AUX 0
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_rsrc, (lds_void*)(ring + slot * 1024), 16, lane16, ir << 10, 0, RG2_RING_AUX);
     if (__builtin_expect(++ir == cur_cnt, 0)) {
       ir = 0;
       ++ie;
@@ -308,9 +312,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   float* const Rw = a.xbuf + ((size_t)blockIdx.x * 2 * NW + wave) * (12 * 64 * 4);      // + q * NW * 12 * 256 floats
   unsigned char* const Gw = reinterpret_cast<unsigned char*>(a.gbuf) + (size_t)blockIdx.x * (8 * PANEL);      // [slot 4][sequence 2][PANEL]
   auto store_R = [&](const Acc2& v) {
-#ifdef RG2_NO_RT         // (experiment, results invalid: what the xbuf / gbuf traffic costs)
-    return;
-#endif
     LANE_LOCAL();
     TSTART();
 #pragma unroll
@@ -323,9 +324,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     TSTOP(6);
   };
   auto load_R = [&](Acc2& v) {
-#ifdef RG2_NO_RT
-    return;
-#endif
     LANE_LOCAL();
     TSTART();
 #pragma unroll
@@ -354,9 +352,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     const unsigned char* pl = smem + lane * 16;
     const unsigned char* rl = ring + lane * 16;
     bf16x8 w[2], pf[6];
-#ifdef RG2_PRIO_YOUNG
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     ring_wait();
     w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
 #pragma unroll
@@ -366,9 +361,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         // w[j & 1] is in registers: the oldest LDS read outstanding (behind it at most the six panel re-reads)
-#ifdef RG2_PRIO_TOP
-        __builtin_amdgcn_s_setprio(1);
-#endif
         if (j == 0) __builtin_amdgcn_s_waitcnt(0xc67f); else __builtin_amdgcn_s_waitcnt(0xc07f);
         asm volatile("" ::: "memory");
         issue(head);                                              // refill the slot it came from
@@ -377,9 +369,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
           ring_wait();
           w[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
         }
-#ifdef RG2_PRIO_TOP
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -394,9 +383,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#ifdef RG2_PRIO_YOUNG
-    __builtin_amdgcn_s_setprio(0);
-#endif
     TSTOP(0);
     TLOG();
   };
@@ -425,6 +411,29 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   auto unit = [&](Acc2& acc) {
     const unsigned char* ps = consume();
     add_bias_t(acc, ps);
+    release();
+    gemm_unit(acc);
+  };
+  // ... acc = bias + W x panel (no zero-fill + add: 192 VALU instructions per unit)
+  auto unit_init = [&](Acc2& acc) {
+    {
+      LANE_LOCAL();
+      const unsigned char* ps = consume();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b = par_t(ps, 0, j, g4);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int tb = 0; tb < 3; ++tb) acc[q][j][tb] = b;
+      }
+      release();
+    }
+    gemm_unit(acc);
+  };
+  // ... acc += W x panel; the unit's parameter fragment (a zero bias: the second half of FFN linear2) is only taken off the ring
+  auto unit_more = [&](Acc2& acc) {
+    (void)consume();
     release();
     gemm_unit(acc);
   };
@@ -514,13 +523,12 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) {
-          const u32x2 p = u32x2{pack2((v[q][j][tb][0] - mean[q][tb]) * rstd[q][tb], (v[q][j][tb][1] - mean[q][tb]) * rstd[q][tb]),
-                                pack2((v[q][j][tb][2] - mean[q][tb]) * rstd[q][tb], (v[q][j][tb][3] - mean[q][tb]) * rstd[q][tb])};
+          const float r = rstd[q][tb], nm = -mean[q][tb] * r;      // (v - mean) rstd as ONE fused multiply-add per value
+          const u32x2 p = u32x2{pack2(fmaf(v[q][j][tb][0], r, nm), fmaf(v[q][j][tb][1], r, nm)),
+                                pack2(fmaf(v[q][j][tb][2], r, nm), fmaf(v[q][j][tb][3], r, nm))};
           const int off = q * PANEL + panel_off(l15, g4, j, tb);
           *reinterpret_cast<u32x2*>(smem + off) = p;
-#ifndef RG2_NO_RT
           if (KEEP) *reinterpret_cast<u32x2*>(Gw + off) = p;
-#endif
         }
   };
   // the wave's own fragments of both panels back from gbuf (16 bytes per lane and fragment)
@@ -550,26 +558,12 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     TSTOP(6);
   };
   // StylizationBlock front half: SiLU(LN(y) * (1 + scale) + shift) with gain = gamma (1 + scale), off = beta (1 + scale)
-  // + shift = vectors 1, 2 of the consuming unit's parameter fragment `ps`; as packed bf16 in registers
-  auto styl_held = [&](Held& hd, const Acc2& v, const float (&mean)[2][3], const float (&rstd)[2][3], const unsigned char* ps) {
-    LANE_LOCAL();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 gain = par_t(ps, 1, j, g4), off = par_t(ps, 2, j, g4);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int tb = 0; tb < 3; ++tb) {
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf((v[q][j][tb][r] - mean[q][tb]) * rstd[q][tb], gain[r], off[r]));
-          hd[q][j][tb] = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
-        }
-    }
-  };
-  // ... or to a slot of gbuf (the wave's own fragments of the panel image, as write_norm keeps xhat in slot 0)
+  // + shift = vectors 1, 2 of the consuming unit's parameter fragment `ps`, as packed bf16
+  // ... to a slot of gbuf (the wave's own fragments of the panel image, as write_norm keeps xhat in slot 0)
   auto styl_gbuf = [&](const int slot, const Acc2& v, const float (&mean)[2][3], const float (&rstd)[2][3], const unsigned char* ps) {
     LANE_LOCAL();
+    const float nmr[2][3] = {{-mean[0][0] * rstd[0][0], -mean[0][1] * rstd[0][1], -mean[0][2] * rstd[0][2]},
+                             {-mean[1][0] * rstd[1][0], -mean[1][1] * rstd[1][1], -mean[1][2] * rstd[1][2]}};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 gain = par_t(ps, 1, j, g4), off = par_t(ps, 2, j, g4);
@@ -579,7 +573,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         for (int tb = 0; tb < 3; ++tb) {
           float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf((v[q][j][tb][r] - mean[q][tb]) * rstd[q][tb], gain[r], off[r]));
+          for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf(fmaf(v[q][j][tb][r], rstd[q][tb], nmr[q][tb]), gain[r], off[r]));
           *reinterpret_cast<u32x2*>(Gw + (2 * slot + q) * PANEL + panel_off(l15, g4, j, tb)) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
         }
     }
@@ -587,6 +581,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   // ... or straight into the panels
   auto write_styl = [&](const Acc2& v, const float (&mean)[2][3], const float (&rstd)[2][3], const unsigned char* ps) {
     LANE_LOCAL();
+    const float nmr[2][3] = {{-mean[0][0] * rstd[0][0], -mean[0][1] * rstd[0][1], -mean[0][2] * rstd[0][2]},
+                             {-mean[1][0] * rstd[1][0], -mean[1][1] * rstd[1][1], -mean[1][2] * rstd[1][2]}};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const f32x4 gain = par_t(ps, 1, j, g4), off = par_t(ps, 2, j, g4);
@@ -596,7 +592,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         for (int tb = 0; tb < 3; ++tb) {
           float o[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf((v[q][j][tb][r] - mean[q][tb]) * rstd[q][tb], gain[r], off[r]));
+          for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf(fmaf(v[q][j][tb][r], rstd[q][tb], nmr[q][tb]), gain[r], off[r]));
           *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
         }
     }
@@ -771,8 +767,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         }
       }
       Acc2 yy;                                        // queries, then (in place) the attention output
-      zero(yy);
-      unit(yy);
+      unit_init(yy);
       {
         TSTART();
 #pragma unroll
@@ -848,12 +843,11 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         release();
       }
     } else {
-      // stylized cross-attention rows of condition c, held as packed bf16: query projection (operand: xhat in the panels),
+      // stylized cross-attention rows of condition c -> gbuf slot 1 + c: query projection (operand: xhat in the panels),
       // softmax, y = q A_clip, masked rows, LayerNorm + stylization with the parameters of MIX_c
-      auto cross = [&](Held& hd, const int c, auto to_gbuf) {
+      auto cross = [&](const int c) {
         Acc2 yy;
-        zero(yy);
-        unit(yy);
+        unit_init(yy);
         LANE_LOCAL();
         unsigned qbits[2] = {qbits0[0], qbits0[1]};
         asm volatile("" : "+v"(qbits[0]), "+v"(qbits[1]));
@@ -896,49 +890,14 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         row_stats(yy, m3, r3);
         TSTART();
         const unsigned char* ps = consume();
-        if (decltype(to_gbuf)::value) styl_gbuf(1 + c, yy, m3, r3, ps);
-        else styl_held(hd, yy, m3, r3, ps);
+        styl_gbuf(1 + c, yy, m3, r3, ps);
         release();
         TSTOP(3);
       };
-#ifdef RG2_CA_HELD      // (experiment: the text and speaker rows held in registers; spills ~120 registers around each)
-      Held h0;
-      cross(h0, 0, std::false_type());
-      mix_x();
-      barx();                                   // every wave is done reading xhat
-      store_held(h0);
-      barx();
-      gemm_unit(X);                             // += W_text h_text
-      barx();                                   // every wave is done reading h_text
-      {
-        PanelRegs t;
-        restore_issue(t, 0);                    // xhat again, landing while the accumulator goes out
-        store_R(X);
-        restore_finish(t);
-      }
-      barx();
-      cross(h0, 1, std::true_type());
-      cross(h0, 2, std::false_type());
-      {
-        PanelRegs t;
-        restore_issue(t, 2);
-        load_R(X);
-        barx();                                 // every wave is done reading xhat
-        restore_finish(t);
-      }
-      drained();
-      barx();
-      gemm_unit(X);                             // += W_audio h_audio
-      barx();
-      store_held(h0);
-      barx();
-      gemm_unit(X);                             // += W_spk h_spk
-#else
       // The stylized rows of the three conditions go to gbuf slots 1-3 and come back into the panels when their MIX unit
       // runs (held in registers beside the queries' accumulator they cost ~120 spilled registers per condition)
-      Held hx;                                  // (unused)
       PanelRegs t;
-      cross(hx, 0, std::true_type());
+      cross(0);
       mix_x();
       barx();                                   // every wave is done reading xhat
       restore_issue(t, 1);
@@ -950,8 +909,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       store_R(X);
       restore_finish(t);
       barx();
-      cross(hx, 1, std::true_type());
-      cross(hx, 2, std::true_type());
+      cross(1);
+      cross(2);
       restore_issue(t, 2);
       load_R(X);
       barx();                                   // every wave is done reading xhat
@@ -964,7 +923,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       restore_finish(t);
       barx();
       gemm_unit(X);                             // += W_spk h_spk
-#endif
     }
     if (dl && a.dump_stage == 3) dump(X);
 
@@ -980,8 +938,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
         for (int jh = 0; jh < 2; ++jh) {
           Acc2 gg;
-          zero(gg);
-          unit(gg);
+          unit_init(gg);
           TSTART();
           Held& gd = jh == 0 ? g0 : g1;
 #pragma unroll
@@ -997,12 +954,11 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         barx();                                 // every wave is done reading x
         store_held(g0);
         barx();
-        zero(yf);
-        unit(yf);                               // (the bias of linear2 rides with the first half)
+        unit_init(yf);                          // (the bias of linear2 rides with the first half)
         barx();
         store_held(g1);
         barx();
-        unit(yf);
+        unit_more(yf);
       }
       styl_unit(X, yf);
     }
@@ -1015,8 +971,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   write_raw(X);
   barx();
   Acc2 out;
-  zero(out);
-  unit(out);
+  unit_init(out);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     if (q == 1 && sB == sA) break;
@@ -1089,13 +1044,10 @@ extern "C" int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void*
   RG_REQUIRE(h, a.dump_stage == 0 || a.dump, "dump_stage needs a dump buffer");
   RG_REQUIRE(h, a.l0 == 0 && a.l1 == a.L, "the two-sequence forward runs all layers in one launch");
   RG_REQUIRE(h, a.pairs == 0 || a.pairs == 1, "pairs must be 0 or 1");
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)rg_seq2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      h->err = "rg_seq2_forward: cannot reserve LDS";
-      return RG_ERR_HIP;
-    }
-    attr = true;
+  static rg_attr_once lds_once;
+  if (!rg_reserve_lds(lds_once, rg_seq2_kernel, LDS_BYTES)) {
+    h->err = "rg_seq2_forward: cannot reserve LDS";
+    return RG_ERR_HIP;
   }
   const int split = a.split < 0 ? 0 : (a.split > a.B ? a.B : a.split);
   const int npc = ((split + 1) >> 1) + ((a.B - split + 1) >> 1);

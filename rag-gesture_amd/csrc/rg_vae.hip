@@ -277,11 +277,8 @@ static int launch_mha_mfma_group(const mha_group& g, int n, int ldq, int ldk, in
                                  int out_bf16, hipStream_t s) {
   const int Skp = (Sk + 31) & ~31;
   const size_t lds = ((size_t)Skp * (HD_ + 8) + (size_t)HD_ * (Skp + 8)) * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mha_mfma_group_kernel<HD_, HDR, MAXSK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (mha_mfma_group_kernel<HD_, HDR, MAXSK>), 160 * 1024);
   hipLaunchKernelGGL((mha_mfma_group_kernel<HD_, HDR, MAXSK>), dim3(B * H, (Sq + 63) / 64, n), dim3(256), lds, s, g, ldq, ldk, ldv, ldo,
                      H, Sq, Sk, 1.0f / sqrtf((float)HDR), out_bf16);
   return 0;
@@ -292,11 +289,8 @@ static int launch_mha_mfma(rg_handle* h, const float* q, int ldq, const float* k
                            float* o, int ldo, int B, int H, int Sq, int Sk, int out_bf16, hipStream_t s) {
   const int Skp = (Sk + 31) & ~31;
   const size_t lds = ((size_t)Skp * (HD_ + 8) + (size_t)HD_ * (Skp + 8)) * sizeof(unsigned short);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mha_mfma_kernel<HD_, HDR, MAXSK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (mha_mfma_kernel<HD_, HDR, MAXSK>), 160 * 1024);
   hipLaunchKernelGGL((mha_mfma_kernel<HD_, HDR, MAXSK>), dim3(B * H, (Sq + 63) / 64), dim3(256), lds, s, q, ldq, k, ldk, v, ldv, o, ldo,
                      H, Sq, Sk, 1.0f / sqrtf((float)HDR), out_bf16);
   return 0;
@@ -658,11 +652,8 @@ extern "C" int rg_mha(rg_handle* h, const float* q, int ldq, const float* k, int
   RG_REQUIRE(h, B > 0 && H > 0 && Sq > 0 && Sk > 0 && Sk <= 192 && hd > 0 && hd <= 256, "bad shape (Sk <= 192)");
   const size_t lds = ((size_t)Sk * (hd + 1) + (size_t)Sk * hd + 4 * hd + 4 * Sk) * sizeof(float);
   RG_REQUIRE(h, lds <= 160 * 1024, "K/V of one head do not fit LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static rg_attr_once lds_once;
+  (void)rg_reserve_lds(lds_once, (mha_kernel), 160 * 1024);
   hipLaunchKernelGGL(mha_kernel, dim3(B * H, (Sq + QB - 1) / QB), dim3(256), lds, rg_stream(stream), q, ldq, k, ldk, v,
                      ldv, o, ldo, H, Sq, Sk, hd, 1.0f / sqrtf((float)hd));
   RG_CHECK_LAUNCH(h);

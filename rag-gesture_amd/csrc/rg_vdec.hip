@@ -631,13 +631,10 @@ extern "C" int rg_vdec_step_grouped(rg_handle* h, const rg_vdec_args* args_host,
       wgs = max(wgs, 4 * g.a[i].nseq);
     }
   }
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)rg_vdec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      h->err = "rg_vdec_step: cannot reserve LDS";
-      return RG_ERR_HIP;
-    }
-    attr = true;
+  static rg_attr_once lds_once;
+  if (!rg_reserve_lds(lds_once, rg_vdec_kernel, LDS_BYTES)) {
+    h->err = "rg_vdec_step: cannot reserve LDS";
+    return RG_ERR_HIP;
   }
   hipLaunchKernelGGL(rg_vdec_kernel, dim3(wgs, n), dim3(NTH), LDS_BYTES, rg_stream(stream), g);
   RG_CHECK_LAUNCH(h);

@@ -615,13 +615,10 @@ extern "C" int rg_venc_forward_grouped(rg_handle* h, const rg_venc_args* args_ho
       wgs = max(wgs, (g.a[i].nseq + 1) / 2);
     }
   }
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)rg_venc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-      h->err = "rg_venc_forward: cannot reserve LDS";
-      return RG_ERR_HIP;
-    }
-    attr = true;
+  static rg_attr_once lds_once;
+  if (!rg_reserve_lds(lds_once, rg_venc_kernel, LDS_BYTES)) {
+    h->err = "rg_venc_forward: cannot reserve LDS";
+    return RG_ERR_HIP;
   }
   hipLaunchKernelGGL(rg_venc_kernel, dim3(wgs, n), dim3(NTH), LDS_BYTES, rg_stream(stream), g);
   RG_CHECK_LAUNCH(h);

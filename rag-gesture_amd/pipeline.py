@@ -538,7 +538,8 @@ class MotionDiffusion(torch.nn.Module):
     def to(self, *a, **k):
         return self
 
-    MAX_SESSIONS, MAX_GRAPHS = 48, 192   # LRU caps (a session holds ~45 MB of activations per 16 clips, a graph its statics)
+    MAX_SESSIONS, MAX_GRAPHS = 192, 768  # LRU caps (a session holds ~45 MB of activations per 16 clips, a graph its statics;
+    #                                       ten batch lanes x two slots x three roles must fit: an evicted session re-captures its graphs)
 
     def _session(self, B, role="sample", lane=0):
         key = (B, role, lane, self._slot)
@@ -552,6 +553,11 @@ class MotionDiffusion(torch.nn.Module):
             opts = dict(self.session_options)
             if opts.get("seq_pairs", "auto") == "auto":
                 opts["seq_pairs"] = self._seq_pairs_auto(B)
+                if opts["seq_pairs"] and role == "invert" and opts.get("seq_duo") is None:
+                    # an inversion ALONE runs only while the pipeline fills (in the steady state it shares the launches of a
+                    # pending batch's sampling): the chip is emptying or empty then, so the classifier-free pairs get workgroups
+                    # of their own (B workgroups for 1.6 ms instead of B / 2 for 2.6 ms per launch; same bits)
+                    opts["seq_pairs"], opts["seq_duo"] = False, True
             self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B, **opts)
         else:
             self._sessions[key] = self._sessions.pop(key)        # most recently used goes last

@@ -78,3 +78,38 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
         asm = f.read()
     assert "v_fma_f32" in asm or "v_mul_f32" in asm
     assert not re.search(r"\bv_pk_(?:add|mul|fma)_f32\b", asm)
+
+
+def test_lds_reservation_guard_is_per_device(tmp_path):
+    """csrc/rg_once.h: a kernel's LDS reservation (hipFuncSetAttribute, a per-device attribute) is made once per DEVICE, not once
+    per process: a second handle on another device of the same process must not find it "already done", a failed attempt is
+    retried, and there is no other state.  Host-only logic, compiled and run here."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no C++ compiler")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rag-gesture_amd", "csrc")
+    src = tmp_path / "once.cpp"
+    src.write_text("""
+#include <cstdio>
+#include "rg_once.h"
+int main() {
+  rg_attr_once once;
+  int calls[3] = {0, 0, 0};
+  bool fail = true;
+  bool r = once(0, [&] { ++calls[0]; return !fail; });          // first attempt on device 0 fails: not marked done
+  fail = false;
+  r = once(0, [&] { ++calls[0]; return true; }) && !r;          // retried, succeeds
+  r = r && once(0, [&] { ++calls[0]; return true; });            // done: not called again
+  r = r && once(1, [&] { ++calls[1]; return true; });            // another device: its own reservation
+  r = r && once(1, [&] { ++calls[1]; return true; }) && once(0, [&] { ++calls[0]; return true; });
+  r = r && once(2, [&] { ++calls[2]; return true; });
+  std::printf("%d %d %d %d\\n", (int)r, calls[0], calls[1], calls[2]);
+  return 0;
+}
+""")
+    exe = tmp_path / "once"
+    r = subprocess.run([cxx, "-std=c++17", "-Wall", "-Werror", "-I", csrc, str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.split() == ["1", "2", "1", "1"]
