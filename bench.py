@@ -341,9 +341,14 @@ class Workload:
 
         n, ms, fl = events()
         ach = fl / (ms * 1e-3) if ms > 0 else 0.0
-        kernel = {3: "rg_seq_kernel (a whole denoiser forward per workgroup -- embedding, 8 decoder layers, head -- of one sequence, or of "
-                     "a clip's conditional sequence and then its classifier-free twin; bf16 MFMA, fp32 accumulate; weights streamed by "
-                     "LDS-DMA)",
+        duo_forms = {(int(s_.sq.duo), int(s_.sq.args.pairs)) for k, s_ in model._sessions.items() if s_.sq is not None and k[1] == "cobatch"} if seq else set()
+        duo = (1, 1) in duo_forms and self.cobatch
+        kernel = {3: ("rg_seq2_kernel (a whole denoiser forward per workgroup -- embedding, 8 decoder layers, head -- of TWO conditional "
+                      "sequences, then of their two classifier-free twins: every streamed weight fragment feeds 6 MFMAs; bf16 MFMA, fp32 "
+                      "accumulate; weights streamed by LDS-DMA)" if duo else
+                      "rg_seq_kernel (a whole denoiser forward per workgroup -- embedding, 8 decoder layers, head -- of one sequence, or of "
+                      "a clip's conditional sequence and then its classifier-free twin; bf16 MFMA, fp32 accumulate; weights streamed by "
+                      "LDS-DMA)"),
                   1: "rg_gemm bf16-A kernels (gemm_dma_kernel<true,..>, gemm_bf16_big_kernel; bf16 MFMA, fp32 accumulate)",
                   2: "rg_gemm bf16x3 kernels (fp32-equivalent products: hi*hi + hi*lo + lo*hi)"}[variant]
         r = {"bound": "mfma", "kernel": kernel,
@@ -359,16 +364,30 @@ class Workload:
             seqs = 2 * round(fl / max(1, n) / per_clip)
             cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
             r["sequences_per_launch"] = seqs
-            r["workgroups_per_launch"] = seqs // 2 if paired else seqs
+            r["workgroups_per_launch"] = seqs // 4 if duo else (seqs // 2 if paired else seqs)
+            r["launch_form"] = "duo_pairs" if duo else ("pairs" if paired else "one_per_sequence")
             # a workgroup owns a compute unit for the whole launch (155 KiB of LDS): the share of the chip a launch can use
             r["cu_share"] = round(min(1.0, r["workgroups_per_launch"] / cus), 4)
             r["frac_of_occupied_cus"] = round(ach / (peak * r["cu_share"]), 5) if r["cu_share"] else None
             r["note"] = ("per launch; a launch occupies one CU per workgroup (%s), so %d concurrent lanes share the chip: `frac` prices "
                          "one lane's launch against the WHOLE chip's peak, `frac_of_occupied_cus` against the peak of the CUs it "
                          "holds; the chip-level rate is the sum over the lanes' concurrent launches (`whole_step`)"
-                         % ("one workgroup per clip: conditional sequence, then its classifier-free twin" if paired
+                         % ("one workgroup per two clips: their conditional sequences, then their classifier-free twins" if duo else
+                            "one workgroup per clip: conditional sequence, then its classifier-free twin" if paired
                             else "one workgroup per sequence", self.rotation()))
         return r
+
+
+def engines(wl):
+    """Which implementation of each stack the timed model resolved to (a checkpoint whose hyper-parameters the fused kernels are
+    not specialised for falls to the per-op launch chains; the line says which one ran)."""
+    m = wl.model
+    sess = [s_ for s_ in m._sessions.values()]
+    den = sorted({("seq2" if s_.sq.duo else "seq") + ("+pairs" if s_.sq.args.pairs else "") if s_.sq is not None else "chain" for s_ in sess})
+    vaes = list(m.model.gesture_rep_encoder.vaes.values())
+    return {"denoiser": "|".join(den) if den else None,
+            "vae_encoder": "|".join(sorted({"fused" if getattr(v, "venc", None) is not None else "chain" for v in vaes})),
+            "vae_decoder": "|".join(sorted({"fused" if getattr(v, "vdec", None) is not None else "chain" for v in vaes}))}
 
 
 def run_steps(wl, n, dist=None, world=1, sync=None):
@@ -622,9 +641,13 @@ def main():
                 if roofline.get("workgroups_per_launch") is not None:
                     # (r04_pmc_seq: 128 workgroups, one per sequence; r04s_pmc_seq_pairs: 64 workgroups, one per clip -- the twin's
                     #  pass streams the shared weights through every L2 a second time)
-                    paired = roofline["workgroups_per_launch"] < roofline["sequences_per_launch"]
-                    with open(os.path.join(ROOT, "profiles", "r04s_pmc_seq_pairs.json" if paired else "r04_pmc_seq.json")) as f:
+                    # (r05k_pmc_seq2_pairs: 32 workgroups, two clips each -- rg_seq2_kernel, what the pipeline launches)
+                    src = {"duo_pairs": "r05k_pmc_seq2_pairs.json", "pairs": "r04s_pmc_seq_pairs.json"}.get(roofline.get("launch_form"), "r04_pmc_seq.json")
+                    with open(os.path.join(ROOT, "profiles", src)) as f:
                         pm = json.load(f)
+                    # these three are NOT measured in this run: they are read from the committed rocprofv3 --pmc passes over the
+                    # same kernel build and launch form, one launch alone on the chip (profiles/pmc_seq.py)
+                    roofline["pmc_source"] = "profiles/" + src
                     roofline["traffic"] = round(pm["fetch_bytes"] + pm["write_bytes"])
                     roofline["traffic_algorithmic"] = round(pm["algorithmic_hbm_bytes"])
                     roofline["mfma_utilisation_pmc"] = round(pm["mfma_utilisation"], 4)      # (of the whole chip's MFMA cycles, one launch alone)
@@ -712,7 +735,7 @@ def main():
             "steady_state_ms_per_step": steady,   # informational (pipeline full at both ends of the clock); never `value`
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": names[kind],
+            "config": {"workload": names[kind], "engines": engines(wl),
                        "clips_per_gpu": B, "global_batch": world * B, "frames_per_clip": 150, "ddim_steps": 50,
                        "denoiser": "8 layers x 512, CFG x2 rows", "vae": "all_encoder, 8 layers, synthetic hparams",
                        "weights": "random-init at config shapes", "parallelism": "clip-sharded x%d" % world,

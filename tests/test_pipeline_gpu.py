@@ -120,6 +120,39 @@ def test_end_to_end_vs_reference_golden(rg, parity, models, golden_dir, rtag, ik
                      (6e-3 if k == "pred_hands" else 3e-3) if precision == "fp32" else 3e-2)
 
 
+@pytest.mark.parametrize("start,precision", [(10, "fp32"), (25, "fp32"), (10, "bf16"), (25, "bf16")])
+def test_inversion_start_time_vs_oracle(rg, parity, models, start, precision):
+    """`inversion_start_time` != -1 (diffusion_architecture.py:218, 386: the sampling starts from inversion level `start`
+    of the exemplar rows instead of the last one) on the device: guided and plain inversion runs against the oracle with
+    the same option, the synchronous forward and -- bit for bit -- the asynchronous submit() path."""
+    from oracle import diffusion as odf
+    model = models[("L2", precision)]
+    cfg = rg.synth.default_model_cfg(num_layers=2)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    P = rg.synth.synth_full_state(0, cfg, vae_cfgs)
+    B = 2
+    for tag, flags in (("guided", dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)),
+                       ("invonly", dict(use_inversion=True))):
+        ikw = dict(flags, inversion_start_time=start)
+        data = rg.synth.synth_batch(B, seed=4321)
+        data["re_dict"] = opipe.synthetic_re_dict(B, seed=77)
+        out = model(**dict(data, retrieval_method="discourse", inference_kwargs=dict(ikw, noise_tape=rg.synth.NoiseTape(2025))))
+        torch.cuda.synchronize()
+        lat = out["prev_latentout"].cpu()
+        d2 = rg.synth.synth_batch(B, seed=4321)
+        with torch.no_grad():
+            ref = opipe.motion_diffusion_forward(P, cfg, vae_cfgs, odf.SpacedSchedule(), d2, rg.synth.NoiseTape(2025),
+                                                 re_dict=opipe.synthetic_re_dict(B, seed=77), **ikw)
+        r = ref["prev_latentout"]
+        parity.check("e2e L2 %s inversion_start_time=%d %s: final latent vs oracle" % (tag, start, precision),
+                     relerr(lat[:, KEEP], r[:, KEEP]), 2e-3 if precision == "fp32" else 1e-2)
+        # the default (-1 = the last level) is a different result: the option is live
+        data0 = rg.synth.synth_batch(B, seed=4321)
+        data0["re_dict"] = opipe.synthetic_re_dict(B, seed=77)
+        out0 = model(**dict(data0, retrieval_method="discourse", inference_kwargs=dict(flags, noise_tape=rg.synth.NoiseTape(2025))))
+        assert not torch.equal(out0["prev_latentout"].cpu(), lat)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_end_to_end_with_retrieval_database_vs_oracle(rg, parity, precision):
     """build_architecture(cfg.model, database=train_dataset) with use_retrieval_for_test: discourse
