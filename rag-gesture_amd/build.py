@@ -27,6 +27,11 @@ ARCH = "gfx950"
 # profiles/dbg/hands_flake_probe.py); the GELU epilogue of rg_gemm showed the same signature once in 70 test runs.
 # More wait states behind the producers (s_nop patched into the assembly: behind transcendentals, in front of lane-mask
 # readers) did NOT help; not forming the packed instructions does.  Cost: see NOTEBOOK section 9 (rg_seq launch time).
+# Round 5: a stand-alone reproducer (profiles/dbg/pk_f32_repro.hip: the rg_6d_to_aa arithmetic WITH packed instructions beside up
+# to 20 busy streams, 6 x 10^5 launches, profiles/r05s_pk_f32_repro.txt) did NOT show the effect: a hardware hazard is not
+# established, the mechanism behind the product-side A/B above is unknown, and the switch stays as a mitigation.  Building only
+# the two denoiser kernels WITH packed fp32 (their workgroups own a whole compute unit: nothing shares their SIMDs) was measured
+# too: bit-identical, race_stress 40 / 40, and worth 0.5 % of a launch (2 574 vs 2 585 us) -- not taken.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
          "-mllvm", "-amdgpu-early-inline-all=true"] + NO_PACKED_FP32 + os.environ.get("RG_EXTRA_FLAGS", "").split()
