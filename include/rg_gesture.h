@@ -235,16 +235,6 @@ int rg_gather_rows(rg_handle* h, const float* table, const int64_t* idx, float* 
 int rg_sa_attention(rg_handle* h, const float* qkv, int ldqkv, const float* src_mask, void* y, int ldy,
                     float* stats, int R, int T, int D, const int* perm, int nperm, int mode, void* stream);
 
-/* rg_sa_attention (matrix-core form) + the stylization front half of the self-attention block
- * (efficient_attention.py:32-46, stylization_block.py:30-47) in one launch, one 16-wave workgroup per batch row:
- * qk fp32 [R*T][ldqk] with q (softmaxed) in columns [0,D) and k in [D,2D); v bf16 [R*T][ldv] (the QKV
- * GEMM's split output, rg_gemm_desc.split_col); writes bf16(SiLU(LN(y)*(1+scale)+shift)) [R*T][ldo], the
- * A operand of the SA-out GEMM.  D must be 512 (one wave per head); perm as for rg_sa_attention with one
- * work item per row. */
-int rg_sa_stylize(rg_handle* h, const float* qk, int ldqk, const void* v_bf16, int ldv, const float* src_mask,
-                  const float* gamma, const float* beta, const float* scale_shift, void* out_bf16, int ldo, int R, int T,
-                  int D, const int* perm, int nperm, void* stream);
-
 /* Cross-attention core of EfficientCrossAttention for ncond parallel conditions
  * (efficient_attention.py:90-98; diffusion_transformer.py:105-118): y3[:, c*D:(c+1)*D] = Q_c A_c
  * with Q_c = q3[:, c*D:(c+1)*D] (softmaxed), A_c = Apre[c][row] ([H][32][32], from rg_kv_reduce) for

@@ -18,7 +18,7 @@ if len(sys.argv) > 1:
 for case in CASES:
     m = wl.model
     m.lanes, m.sample_lanes = case["lanes"], case.get("sample_lanes")
-    m.session_options = dict(m.session_options or {}, styl_in_gemm=bool(case.get("styl")))
+    m.session_options = dict(m.session_options or {})      # (round 2's styl_in_gemm case: the knob was removed in round 5)
     m.async_results = bool(case.get("pipelined"))
     wl.cobatch = bool(case.get("cobatch")) and m.async_results
     m.max_inflight = int(case.get("inflight", 2))

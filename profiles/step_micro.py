@@ -15,10 +15,8 @@ if argv and argv[0].startswith("--B="):          # e.g. --B=16,48
 ENGINES = argv or ["chain", "seq"]
 for B, engine in [(b, e) for b in BS for e in ENGINES]:
     kw = {}
-    if engine.startswith("chain+"):      # chain variants: e.g. chain+tile64 (64x64 GEMM tiles for the N = 512 launches at every M)
-        kw = dict(tile64="force") if "tile64" in engine else {}
-        if "stylgemm" in engine:         # chain+stylgemm: the stylization passes inside the SA-out / FFN-out GEMMs
-            kw["styl_in_gemm"] = True
+    # (round 2's chain+tile64 / chain+stylgemm variants: those session knobs were removed in round 5)
+    kw = {}
     sess = rg.denoiser.DenoiserSession(W, B, engine=engine.split("+")[0], ln_mode=LN_MODE, **kw)
     d = rg.synth.synth_batch(B, seed=1)
     mask = torch.ones(B, 43)

@@ -17,7 +17,7 @@ for B, waves in [(b, w) for b in BS for w in WAVES]:
     W.h.lib.rg_set_gemm_path(W.h._h, int(os.environ.get("GEMM_PATH", "0")))
     graphs = []
     for st in streams:
-        sess = rg.denoiser.DenoiserSession(W, B, ln_mode="folded", sa_fused=bool(os.environ.get("SA_FUSED")), engine=os.environ.get("ENGINE") or None)
+        sess = rg.denoiser.DenoiserSession(W, B, ln_mode="folded", engine=os.environ.get("ENGINE") or None)
         d = rg.synth.synth_batch(B, seed=1)
         mask = torch.ones(B, 43); mask[:, [10, 21, 32]] = 0
         sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, {c: torch.ones(B, 43) for c in rg.denoiser.CONDS})

@@ -697,269 +697,6 @@ __global__ void __launch_bounds__(256) split_transpose_kernel(const float* __res
   At[(size_t)m * 2 * HD * HD + HD * HD + l * HD + d] = __builtin_bit_cast(unsigned short, lo);
 }
 
-// ------------------------------------------------------------------------------ self attention + stylization
-// One 16-wave workgroup per batch row (one wave per head), so the LayerNorm statistics of the 512-wide
-// attention output stay on the CU and the stylised bf16 A operand of the SA-out GEMM is written directly
-// (rg_sa_attention + rg_stylize in one launch; y and its statistics never go to HBM).
-// Inputs: q, k fp32 (q already softmaxed over head_dim by the QKV epilogue), v bf16 (the QKV epilogue's
-// split output): per head K fp32 [Tp][32] (6 KiB) + V bf16 [Tp][32] (3 KiB) fit 16 heads into 144 KiB of LDS.
-//   token softmax of K (fp32, registers) -> P as bf16 hi + lo over the K tile
-//   A = P^T V   : MFMA 16x16x32 bf16, P hi + lo, V bf16                        (fp32 accumulate)
-//   y = q A     : MFMA, q and A as bf16 hi + lo; the q tile is DMA'd over the K/P tile once A is in registers
-//   LN over D, *(1+scale)+shift, SiLU -> bf16
-struct SaStylizeArgs {
-  const float* qk;            // [R*T][ldqk]: q in columns [0,D), k in [D,2D)
-  const unsigned short* v;    // bf16 [R*T][ldv]
-  const float* src_mask;      // [R][T]
-  const float* gamma;         // [D]  proj_out.norm
-  const float* beta;
-  const float* scale_shift;   // [2D]
-  unsigned short* out;        // bf16 [R*T][ldo]
-  const int* perm;            // launch slot -> row group, or null
-  int ldqk, ldv, ldo, R, T, D;
-};
-
-constexpr int SS_WAVES = 16;
-
-__global__ void __launch_bounds__(SS_WAVES * 64) sa_stylize_kernel(const SaStylizeArgs a) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-  typedef __attribute__((ext_vector_type(4))) float f32x4;
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  constexpr int NTH = SS_WAVES * 64;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smb[];
-  const int T = a.T, D = a.D;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = a.perm ? a.perm[blockIdx.x] : (int)blockIdx.x;
-  if (b < 0) return;
-  const int Tp = (T + 15) & ~15;
-  const int REG = Tp * HD * 4 + Tp * HD * 2;           // per-head region: K/P/q (fp32 tile size) + V bf16
-  float* sstat = reinterpret_cast<float*>(smb + SS_WAVES * REG);   // [SS_WAVES][Tp][2]
-  float* srow = sstat + SS_WAVES * 2 * Tp;                          // [Tp][2]
-  float* smask = srow + 2 * Tp;                                     // [Tp]
-  const int h = wave;                                               // one head per wave (D = 32 * SS_WAVES)
-  unsigned char* reg = smb + h * REG;
-  float* sk = reinterpret_cast<float*>(reg);                        // K fp32 [Tp][32]; later P hi/lo; later q / y
-  unsigned short* sph = reinterpret_cast<unsigned short*>(reg);     // P hi bf16 [Tp][32]
-  unsigned short* spl = sph + Tp * HD;                              // P lo
-  unsigned short* sv = reinterpret_cast<unsigned short*>(reg + Tp * HD * 4);   // V bf16 [Tp][32]
-  const int l15 = lane & 15, g = lane >> 4;
-  // ---- K (fp32: 8 rows x 128 B per 1-KiB DMA) and V (bf16: 16 rows x 64 B) tiles of this head
-  {
-    const float* ksrc = a.qk + (size_t)b * T * a.ldqk + D + h * HD + (lane & 7) * 4;
-    for (int r0 = 0; r0 < Tp; r0 += 8) {
-      int r = r0 + (lane >> 3);
-      r = r < T ? r : T - 1;
-      __builtin_amdgcn_global_load_lds((const void*)(ksrc + (size_t)r * a.ldqk), (lds_void*)(sk + r0 * HD), 16, 0, 0);
-    }
-    const unsigned short* vsrc = a.v + (size_t)b * T * a.ldv + h * HD + (lane & 3) * 8;
-    for (int r0 = 0; r0 < Tp; r0 += 16) {
-      int r = r0 + (lane >> 2);
-      r = r < T ? r : T - 1;
-      __builtin_amdgcn_global_load_lds((const void*)(vsrc + (size_t)r * a.ldv), (lds_void*)(sv + r0 * HD), 16, 0, 0);
-    }
-  }
-  // stylization parameters of this thread's column pair (used at the very end)
-  const int col0 = (threadIdx.x & 255) * 2;
-  float g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f, sc0 = 0.f, sc1 = 0.f, sh0 = 0.f, sh1 = 0.f;
-  if (col0 < D) {
-    const float2 gg = *reinterpret_cast<const float2*>(a.gamma + col0);
-    const float2 bb = *reinterpret_cast<const float2*>(a.beta + col0);
-    const float2 sc = *reinterpret_cast<const float2*>(a.scale_shift + col0);
-    const float2 sh = *reinterpret_cast<const float2*>(a.scale_shift + D + col0);
-    g0 = gg.x; g1 = gg.y; b0 = bb.x; b1 = bb.y; sc0 = 1.0f + sc.x; sc1 = 1.0f + sc.y; sh0 = sh.x; sh1 = sh.y;
-  }
-  for (int n = threadIdx.x; n < T; n += NTH) smask[n] = a.src_mask[(size_t)b * T + n];
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  auto pk = [](float x, float y) {
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
-  };
-  auto split = [&](const float (&x)[8], bf16x8& hi, bf16x8& lo) {
-    float r[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = x[e] - (float)(__bf16)x[e];
-    hi = __builtin_bit_cast(bf16x8, u32x4{pk(x[0], x[1]), pk(x[2], x[3]), pk(x[4], x[5]), pk(x[6], x[7])});
-    lo = __builtin_bit_cast(bf16x8, u32x4{pk(r[0], r[1]), pk(r[2], r[3]), pk(r[4], r[5]), pk(r[6], r[7])});
-  };
-  // ---- softmax over tokens for column d (registers), then P = hi + lo bf16 over the K tile
-  {
-    const int d = lane & 31, half = lane >> 5;
-    constexpr int NH = TMAX / 2;
-    float kr[NH];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      const int n = half + 2 * i;
-      kr[i] = (n < T && smask[n] != 0.f) ? sk[n * HD + d] : -INFINITY;
-      mx = fmaxf(mx, kr[i]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      kr[i] = (kr[i] == -INFINITY) ? 0.f : expf(kr[i] - mx);
-      sum += kr[i];
-    }
-    sum += __shfl_xor(sum, 32);
-    const float inv = 1.0f / sum;
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane holds its K values before the tile is overwritten
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      const int n = half + 2 * i;
-      if (n < Tp) {
-        const float p = n < T ? kr[i] * inv : 0.f;
-        const __bf16 hi = (__bf16)p;
-        sph[n * HD + d] = __builtin_bit_cast(unsigned short, hi);
-        spl[n * HD + d] = __builtin_bit_cast(unsigned short, (__bf16)(p - (float)hi));
-      }
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  // ---- A[d][l] = sum_n P[n][d] V[n][l]  (rows d, columns l, K = tokens in 2 steps of 32, zero beyond Tp)
-  f32x4 accA[2][2];
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) accA[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto gather8 = [&](const unsigned short* tile, int ks, int col) {
-    unsigned short x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int n = 32 * ks + 8 * g + j;
-      x[j] = n < Tp ? tile[n * HD + col] : (unsigned short)0;
-    }
-    return __builtin_bit_cast(bf16x8, u32x4{(unsigned)x[0] | ((unsigned)x[1] << 16), (unsigned)x[2] | ((unsigned)x[3] << 16),
-                                            (unsigned)x[4] | ((unsigned)x[5] << 16), (unsigned)x[6] | ((unsigned)x[7] << 16)});
-  };
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    bf16x8 ph[2], pl[2], vf[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      ph[blk] = gather8(sph, ks, 16 * blk + l15);
-      pl[blk] = gather8(spl, ks, 16 * blk + l15);
-      vf[blk] = gather8(sv, ks, 16 * blk + l15);
-    }
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        accA[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[rb], vf[nb], accA[rb][nb], 0, 0, 0);
-        accA[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[rb], vf[nb], accA[rb][nb], 0, 0, 0);
-      }
-  }
-  // ---- q tile over the P tile (every lane's P/V reads are complete), then y = q A with A from registers:
-  // contraction slot (g, j) <-> d = 16*(j/4) + 4*g + j%4 makes accA a B fragment as it stands
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  float* sq = sk;
-  {
-    const float* qsrc = a.qk + (size_t)b * T * a.ldqk + h * HD + (lane & 7) * 4;
-    for (int r0 = 0; r0 < Tp; r0 += 8) {
-      int r = r0 + (lane >> 3);
-      r = r < T ? r : T - 1;
-      __builtin_amdgcn_global_load_lds((const void*)(qsrc + (size_t)r * a.ldqk), (lds_void*)(sq + r0 * HD), 16, 0, 0);
-    }
-  }
-  bf16x8 ah[2], al[2];
-#pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const float av[8] = {accA[0][nb][0], accA[0][nb][1], accA[0][nb][2], accA[0][nb][3],
-                         accA[1][nb][0], accA[1][nb][1], accA[1][nb][2], accA[1][nb][3]};
-    split(av, ah[nb], al[nb]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  f32x4 accY[4][2];
-#pragma unroll
-  for (int tb = 0; tb < 4; ++tb) {
-    accY[tb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    accY[tb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (16 * tb < Tp) {
-      const int row = 16 * tb + l15;
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(sq + row * HD + 4 * g);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(sq + row * HD + 16 + 4 * g);
-      const float qv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-      bf16x8 qh, ql;
-      split(qv, qh, ql);
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        accY[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql, ah[nb], accY[tb][nb], 0, 0, 0);
-        accY[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, al[nb], accY[tb][nb], 0, 0, 0);
-        accY[tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh, ah[nb], accY[tb][nb], 0, 0, 0);
-      }
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // every lane's q reads are complete before y overwrites the tile
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int tb = 0; tb < 4; ++tb)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = 16 * tb + 4 * g + e;
-      if (row < T) {
-        sq[row * HD + l15] = accY[tb][0][e];
-        sq[row * HD + 16 + l15] = accY[tb][1][e];
-      }
-    }
-  __builtin_amdgcn_s_waitcnt(0xc07f);
-  __builtin_amdgcn_wave_barrier();
-  {
-    float* mystat = sstat + wave * 2 * Tp;
-    if (lane < T) {
-      const float* yr = sq + lane * HD;
-      float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < HD; j += 2) {
-        const float v0 = yr[(j + lane) & 31], v1 = yr[(j + 1 + lane) & 31];
-        s0 += v0;
-        s1 += v1;
-        q0 = fmaf(v0, v0, q0);
-        q1 = fmaf(v1, v1, q1);
-      }
-      mystat[2 * lane] = s0 + s1;
-      mystat[2 * lane + 1] = q0 + q1;
-    }
-  }
-  __syncthreads();
-  for (int n = threadIdx.x; n < T; n += NTH) {
-    float su = 0.f, sq2 = 0.f;
-#pragma unroll
-    for (int w = 0; w < SS_WAVES; ++w) {
-      su += sstat[w * 2 * Tp + 2 * n];
-      sq2 += sstat[w * 2 * Tp + 2 * n + 1];
-    }
-    const float inv = 1.0f / (float)D;
-    const float mu = su * inv;
-    float var = sq2 * inv - mu * mu;
-    var = var < 0.f ? 0.f : var;
-    srow[2 * n] = mu;
-    srow[2 * n + 1] = rsqrtf(var + 1e-5f);
-  }
-  __syncthreads();
-  // ---- LN + stylization + SiLU -> bf16; thread -> (two adjacent columns, every 4th token)
-  if (col0 < D) {
-    const int rq = threadIdx.x >> 8;
-    const float* yt = reinterpret_cast<const float*>(smb + (col0 >> 5) * REG) + (col0 & 31);
-    unsigned short* op = a.out + (size_t)b * T * a.ldo + col0;
-#pragma unroll 4
-    for (int n = rq; n < T; n += NTH / 256) {
-      const float mu = srow[2 * n], rs = srow[2 * n + 1];
-      const float2 y = *reinterpret_cast<const float2*>(yt + n * HD);
-      float t0 = ((y.x - mu) * rs * g0 + b0) * sc0 + sh0;
-      float t1 = ((y.y - mu) * rs * g1 + b1) * sc1 + sh1;
-      t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t0 * -1.44269504088896340736f));
-      t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t1 * -1.44269504088896340736f));
-      const __bf16 lo = (__bf16)t0, hi = (__bf16)t1;
-      *reinterpret_cast<unsigned*>(op + (size_t)n * a.ldo) =
-          (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-    }
-  }
-}
-
 constexpr int CS_WAVES = 16;   // one wave per head at D = 512
 
 __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStylizeArgs a) {
@@ -1345,23 +1082,3 @@ extern "C" int rg_split_transpose_bf16(rg_handle* h, const float* A, void* At_bf
   return RG_OK;
 }
 
-extern "C" int rg_sa_stylize(rg_handle* h, const float* qk, int ldqk, const void* v_bf16, int ldv, const float* src_mask,
-                             const float* gamma, const float* beta, const float* scale_shift, void* out_bf16, int ldo, int R,
-                             int T, int D, const int* perm, int nperm, void* stream) {
-  RG_REQUIRE(h, qk && v_bf16 && src_mask && gamma && beta && scale_shift && out_bf16, "null pointer");
-  RG_REQUIRE(h, D == HD * SS_WAVES, "this kernel is one wave per head: D must be 512");
-  RG_REQUIRE(h, T >= 33 && T <= TMAX && R > 0 && ldqk % 4 == 0 && ldv % 8 == 0 && ldo % 2 == 0, "bad shape (33 <= T <= 64)");
-  RG_REQUIRE(h, !perm || nperm >= R, "perm shorter than the work list");
-  const int Tp = (T + 15) & ~15;
-  const size_t lds = (size_t)SS_WAVES * (Tp * HD * 6) + ((size_t)SS_WAVES * 2 * Tp + 2 * Tp + Tp) * sizeof(float);
-  RG_REQUIRE(h, lds <= 160 * 1024, "row group does not fit LDS");
-  static rg_attr_once lds_once;
-  (void)rg_reserve_lds(lds_once, (sa_stylize_kernel), 160 * 1024);
-  SaStylizeArgs a;
-  a.qk = qk; a.v = reinterpret_cast<const unsigned short*>(v_bf16); a.src_mask = src_mask; a.gamma = gamma; a.beta = beta;
-  a.scale_shift = scale_shift; a.out = reinterpret_cast<unsigned short*>(out_bf16); a.perm = perm;
-  a.ldqk = ldqk; a.ldv = ldv; a.ldo = ldo; a.R = R; a.T = T; a.D = D;
-  hipLaunchKernelGGL(sa_stylize_kernel, dim3(perm ? nperm : R), dim3(SS_WAVES * 64), lds, rg_stream(stream), a);
-  RG_CHECK_LAUNCH(h);
-  return RG_OK;
-}

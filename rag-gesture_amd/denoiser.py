@@ -245,8 +245,8 @@ class DenoiserSession:
     classifier-free rows).  Not re-entrant; one per (model, batch size, stream)."""
     DEFAULT_ENGINE = "seq"
 
-    def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, sa_fused=False, tile64=False, xcd_affine=True, engine=None,
-                 styl_in_gemm=False, seq_launches=1, kv_grouped=True, seq_pairs=False, seq_duo=None):
+    def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, xcd_affine=True, engine=None,
+                 seq_launches=1, kv_grouped=True, seq_pairs=False, seq_duo=None):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
@@ -264,10 +264,8 @@ class DenoiserSession:
         "prologue" = LayerNorm in a pre-pass (exact for any offset), "auto" = folded unless the session's first
         forward finds rows more than LN_GUARD_SIGMAS standard deviations off centre (one read-back, once per session).
         (The "seq" engine evaluates every LayerNorm in fp32 from the fp32 rows.)
-        styl_in_gemm: the stylization in front of the SA-out and FFN-out GEMMs (LN, scale/shift, SiLU)
-        runs inside those GEMMs, on the landed bf16 A tiles in LDS, instead of as two elementwise launches per layer.
-        Parity-green and measured SLOWER (907 vs 887 us per forward at M = 1376): off by default.
-        styl_prepass / sa_fused / tile64 / xcd_affine: measurement knobs of the launch chain (NOTEBOOK section 6)."""
+        styl_prepass / xcd_affine: measurement knobs of the launch chain (NOTEBOOK section 6).  (Round 5 removed three more
+        that no default used and every measurement had gone against: sa_fused, styl_in_gemm, tile64.)"""
         # kv_grouped (bf16): the conditions' K / V projections of DenoiserWeights.KV_GROUP layers per GEMM on a bf16 normalised
         # operand (set_conditions); False = one fp32-A GEMM with a LayerNorm prologue per layer and condition (round 1-3)
         self.kv_grouped = bool(kv_grouped)
@@ -291,7 +289,7 @@ class DenoiserSession:
         self.a_pre = f(w.L, 3, B, w.H, 32, 32)
         self.src_mask = torch.ones(self.R, T, device=dev)
         self.qmask = torch.ones(3, self.R, T, device=dev)
-        self.abf = self.xa_bf = self.v_sa = self.hcat = None
+        self.abf = self.xa_bf = self.hcat = None
         self.ln_ratio = None     # max mean^2 / var seen by the guard (chain, ln_mode "auto", after the first forward)
         self.sq = None
         if self.engine == "seq":           # activations never leave the CU: no per-op buffers
@@ -303,18 +301,13 @@ class DenoiserSession:
             self.sq = SQ.SeqForward(self, launches=seq_launches, pairs=seq_pairs, duo=duo and seq_launches == 1)
             return
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
-        # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide, or 64 wide
-        # where the producer runs 64x64 tiles, self.tn): allocated for the finer split, viewed per producer
-        self._st_a, self._st_b, self.st_c = f(M, D // 64, 2), f(M, D // 64, 2), f(M, D // G.STATS_COLS, 2)
-        parts128 = lambda t: t.view(-1)[:M * (D // G.STATS_COLS) * 2].view(M, D // G.STATS_COLS, 2)
-        self._parts128 = parts128
-        self.st_a, self.st_b = parts128(self._st_a), parts128(self._st_b)
+        # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide)
+        self.st_a, self.st_b, self.st_c = (f(M, D // G.STATS_COLS, 2) for _ in range(3))
         self.qkv, self.q3 = f(M, 3 * D), f(M, 3 * D)
         self.y_sa, self.st_sa = f(M, D), f(M, D // 128, 2)
         self.y3, self.st3 = f(M, 3 * D), f(3, M, D // 128, 2)
         self.g = torch.empty(M, w.FF, device=dev, dtype=torch.bfloat16 if w.precision == "bf16" else torch.float32)
-        self.yf, self._st_f = f(M, D), f(M, D // 64, 2)
-        self.st_f = parts128(self._st_f)
+        self.yf, self.st_f = f(M, D), f(M, D // G.STATS_COLS, 2)
         self.hcat = torch.empty(M, 4 * D, device=dev, dtype=torch.bfloat16) if w.precision == "bf16" else None
         self.ln_mode = ln_mode if (w.precision == "bf16" and styl_prepass) else "prologue"
         if w.precision == "bf16" and styl_prepass:
@@ -322,32 +315,13 @@ class DenoiserSession:
             self.abf3 = torch.empty(B * T, 3 * D, device=dev, dtype=torch.bfloat16)
             if self.ln_mode != "prologue":
                 self._xa_bf_buf = self.xa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-                # experimental: self-attention + stylization in one 16-wave kernel (rg_sa_stylize).  Measured
-                # slower than the two separate kernels at B <= 48 (it concentrates 16 heads on R <= 96 CUs:
-                # sampling 50.4 vs 48.1 ms, inversion equal), so it is off unless asked for
-                if sa_fused and D == 512:
-                    self.v_sa = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-        self.styl_gemm = bool(styl_in_gemm and self.abf is not None and self.v_sa is None and D <= 512 and D % 64 == 0
-                              and T <= 48)
-        if self.styl_gemm:
-            self.y_sa_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-            self.yf_bf = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
         self.st3c = f(3, B * T, D // 128, 2)           # cross-attention stats of the conditional rows only
         self.a_pre_t = torch.empty(w.L, 3, B, w.H, 2, 32, 32, device=dev, dtype=torch.bfloat16)  # A^T as bf16 hi/lo
-        # optional 64x64 GEMM tiles for the N = D launches while they still fit one round of workgroups (twice the
-        # CUs on the same weight bytes).  Measured: no gain (146.1 vs 143.2 ms guided, 71.6 vs 69.6 ms base): the
-        # fixed part of these launches, not the K loop, decides -- off unless tile64=True
-        self.tn = 0
-        if self.xa_bf is not None and tile64 and D % 64 == 0 and \
-                (tile64 == "force" or ((M + 63) // 64) * (D // 64) <= w.h.lib.rg_num_cus(w.h._h)):
-            self.tn = 64
-            self.st_b, self.st_f = self._st_b, self._st_f
         ng = D // 128
         order = xcd_affine_order if xcd_affine else \
             (lambda n, ipg, T_: np.arange(n * ipg, dtype=np.int32))
         dv = lambda a: torch.from_numpy(a).to(dev)
         self.perm_sa = dv(order(self.R, ng, T))
-        self.perm_sa1 = dv(order(self.R, 1, T))
         self.perm_ca = dv(order(self.R, 3 * ng, T))
         self.perm_cac = dv(order(B, 3 * ng, T))
 
@@ -401,12 +375,15 @@ class DenoiserSession:
         if w.kv_group is not None and self.kv_grouped:
             KVG = w.kv_group
             ldk = KVG * 2 * D
-            kv = torch.empty(B * kv_max, ldk, device=dev)
-            scratch = torch.empty(B * kv_max, D, device=dev)
+            # the session's own scratch (one set per call shape, made on first use): inside a captured set_conditions a
+            # torch.empty would pin ~260 MB per graph for the graph's lifetime
+            kv = self._scratch("kv", (B * kv_max, ldk), torch.float32)
+            scratch = self._scratch("ln", (B * kv_max, D), torch.float32)
+            xhat_all = self._scratch("xhat", (B * kv_max, D), torch.bfloat16)
             for ci in range(3):
                 xf, _, n_tok = srcs[ci]
                 M = B * n_tok
-                xhat = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
+                xhat = xhat_all[:M]
                 h.call("layernorm", xf, w.ln_ones, w.ln_zeros, scratch, M, D, xhat)      # exact two-pass statistics, no affine
                 for gi in range(w.L // KVG):
                     G.gemm(h, M=M, N=ldk, K=D, W=w.w_kv_grp[gi][ci], out=kv, A=xhat, bias=w.b_kv_grp[gi][ci], ldo=ldk)
@@ -426,6 +403,13 @@ class DenoiserSession:
         elif self.abf is not None and finalize:
             h.call("split_transpose_bf16", self.a_pre, self.a_pre_t, w.L * 3 * Bs * w.H)
         self._keep = (getattr(self, "_keep", []) if offset else []) + srcs
+
+    def _scratch(self, name, shape, dtype):
+        key = (name, tuple(shape), dtype)
+        pool = self.__dict__.setdefault("_scratch_pool", {})
+        if key not in pool:
+            pool[key] = torch.empty(*shape, device=self.w.dev, dtype=dtype)
+        return pool[key]
 
     # ------------------------------------------------------------------ per step
     def forward(self, x, step, step_b=None, split=None):
@@ -459,10 +443,7 @@ class DenoiserSession:
         self.ln_ratio = float(self._guard.item())
         self._guard = None
         if self.ln_ratio > self.LN_GUARD_SIGMAS ** 2:
-            self.ln_mode, self.xa_bf, self.v_sa = "prologue", None, None
-            if self.tn:   # 64-wide tiles were tied to the folded path
-                self.tn = 0
-                self.st_b, self.st_f = self._parts128(self._st_b), self._parts128(self._st_f)
+            self.ln_mode, self.xa_bf = "prologue", None
             out = self._forward_chain(x, step)
         return out
 
@@ -473,15 +454,11 @@ class DenoiserSession:
     def _forward_chain(self, x, step, step_b=None, split=None):
         w, h, B, R, M, D, T = self.w, self.h, self.B, self.R, self.M, self.w.D, self.w.T
         two = split is not None
-        if two and (self.abf is None or self.hcat is None or self.styl_gemm or self.v_sa is not None):
+        if two and (self.abf is None or self.hcat is None):
             raise capi.RgError("two step groups: bf16 launch chain with the stylization pre-pass only")
         xa, xb, xc = self.xa, self.xb, self.xc
-        sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c     # sa_: written by the embed GEMM (128-wide tiles)
-        sa_w = self._st_a if self.tn else self.st_a           # ... and by every FFN-out GEMM (self.tn-wide tiles)
-        tn = self.tn
-        styl_gemm = self.styl_gemm
-        if styl_gemm:      # the stylizing GEMMs run 128-wide tiles: their statistics come in the 128-column split
-            sb_, sa_w = self._parts128(self._st_b), self.st_a
+        sa_, sb_, sc_ = self.st_a, self.st_b, self.st_c     # sa_: written by the embed GEMM and by every FFN-out GEMM (128-wide tiles)
+        sa_w = self.st_a
         # h = joint_embed(x) + positional tables, duplicated for the two CFG branches
         G.gemm(h, M=M, N=D, K=D, W=w.w_embed, out=xa, segs=[G.Seg(x.view(B * T, D))], seg_len=D, a_row_mod=B * T,
                bias=w.b_embed, tbias=w.tbias, tb_period=T, stats_out=sa_, out2=self.xa_bf)
@@ -492,13 +469,7 @@ class DenoiserSession:
             grp = (lambda bi: ([ssb[bi]], T, B, split)) if two else (lambda bi: None)
             # --- self attention
             qkv_seg = G.Seg(xa, mode=G.A_LN, stats=sa_, gamma=lw["sa_g"], beta=lw["sa_b"])
-            if self.xa_bf is not None and self.v_sa is not None:
-                # as below, and q, k leave as fp32 [M, 2D], v as bf16 [M, D] (split output): the fused
-                # self-attention + stylization kernel keeps 16 heads of K (fp32) and V (bf16) in LDS and writes
-                # the SA-out GEMM's bf16 A operand directly
-                G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv_ln"], out=self.qkv, ldo=3 * D, A=self.xa_bf, bias=lw["c2_qkv"],
-                       ln_stats=sa_, ln_c1=lw["c1_qkv"], softmax_cols=D, out2=self.v_sa, split_col=2 * D)
-            elif self.xa_bf is not None:
+            if self.xa_bf is not None:
                 # A = bf16 copy of xa written by the producing GEMM; the LayerNorm is folded into this GEMM's
                 # epilogue (rstd * (acc - mean * c1) + c2): no normalisation pass, no extra launch
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv_ln"], out=self.qkv, A=self.xa_bf, bias=lw["c2_qkv"],
@@ -511,32 +482,16 @@ class DenoiserSession:
             else:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_qkv"], out=self.qkv, segs=[qkv_seg], seg_len=D,
                        bias=lw["b_qkv"], softmax_cols=D)
-            fused_sa = self.xa_bf is not None and self.v_sa is not None
-            if fused_sa:
-                h.call("sa_stylize", self.qkv, 3 * D, self.v_sa, D, self.src_mask, lw["sa_sg"], lw["sa_sb"], ss[0], self.abf, D,
-                       R, T, D, self.perm_sa1, self.perm_sa1.numel())
-            elif styl_gemm:
-                h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa_bf, D, self.st_sa, R, T, D,
-                       self.perm_sa, self.perm_sa.numel(), 2)
-            else:
-                h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
-                       self.perm_sa, self.perm_sa.numel(), 1 if w.precision == "bf16" else 0)
+            h.call("sa_attention", self.qkv, 3 * D, self.src_mask, self.y_sa, D, self.st_sa, R, T, D,
+                   self.perm_sa, self.perm_sa.numel(), 1 if w.precision == "bf16" else 0)
             sa_seg = G.Seg(self.y_sa, mode=G.A_STYL, stats=self.st_sa, gamma=lw["sa_sg"], beta=lw["sa_sb"], scale_shift=ss[0])
-            if fused_sa:
-                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
-                       out2=self.hcat[:, 3 * D:], tile_n=tn)
-            elif styl_gemm:
-                # A = bf16 y; LN, scale/shift and SiLU once per element on the landed tiles in LDS (rg_gemm_desc.seg)
-                G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.y_sa_bf, bias=lw["b_sao"], residual=xa,
-                       a_styl=G.Seg(None, mode=G.A_STYL, stats=self.st_sa, gamma=w.styl_gain[step, l, 0], beta=w.styl_off[step, l, 0]),
-                       stats_out=sb_, out2=self.hcat[:, 3 * D:])
-            elif self.abf is not None:
+            if self.abf is not None:
                 # stylization (LN, scale/shift, SiLU: 2 transcendentals per element) once per element in a
                 # pre-pass instead of once per column tile and wave pair inside the GEMM's A prologue
                 G.stylize(h, [sa_seg], D, M, self.abf, groups=grp(0))
                 # out2: bf16 copy of xb = 4th K-segment of the ca_mix GEMM's A operand
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, A=self.abf, bias=lw["b_sao"], residual=xa, stats_out=sb_,
-                       out2=self.hcat[:, 3 * D:], tile_n=tn)
+                       out2=self.hcat[:, 3 * D:])
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_sao"], out=xb, segs=[sa_seg], seg_len=D, bias=lw["b_sao"], residual=xa,
                        stats_out=sb_)
@@ -579,7 +534,7 @@ class DenoiserSession:
                     segs.append(G.Seg(xb))
                     # the SiLU prologue of the K = 2048 GEMM once per element instead of once per column tile
                     G.stylize(h, segs, D, M, self.hcat, m_cond=Mc, unc_nseg=3, unc_tab=lw["unc_tab"][step], qmask=self.qmask)
-                G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"], out2=self.abf, tile_n=tn)
+                G.gemm(h, M=M, N=D, K=4 * D, W=lw["w_mix"], out=xc, A=self.hcat, bias=lw["b_mix"], out2=self.abf)
             else:
                 G.gemm(h, M=M, N=3 * D, K=D, W=lw["w_q3"], out=self.q3,
                        segs=[G.Seg(xb, mode=G.A_LN, stats=sb_, gamma=lw["ca_g"], beta=lw["ca_b"])], seg_len=D,
@@ -595,33 +550,23 @@ class DenoiserSession:
                 G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, A=self.abf, bias=lw["b_ff1"], act=1)
             else:
                 G.gemm(h, M=M, N=w.FF, K=D, W=lw["w_ff1"], out=self.g, segs=[G.Seg(xc)], seg_len=D, bias=lw["b_ff1"], act=1)
-            if styl_gemm:
-                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf_bf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f,
-                       tile_n=tn)
-            elif w.precision == "bf16":
-                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f,
-                       tile_n=tn)
+            if w.precision == "bf16":
+                G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, A=self.g, bias=lw["b_ff2"], stats_out=self.st_f)
             else:
                 G.gemm(h, M=M, N=D, K=w.FF, W=lw["w_ff2"], out=self.yf, segs=[G.Seg(self.g)], seg_len=w.FF,
                        bias=lw["b_ff2"], stats_out=self.st_f)
             ff_seg = G.Seg(self.yf, mode=G.A_STYL, stats=self.st_f, gamma=lw["ff_sg"], beta=lw["ff_sb"], scale_shift=ss[4])
-            if styl_gemm:
-                G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.yf_bf, bias=lw["b_ffo"], residual=xc,
-                       a_styl=G.Seg(None, mode=G.A_STYL, stats=self.st_f, gamma=w.styl_gain[step, l, 1], beta=w.styl_off[step, l, 1]),
-                       stats_out=sa_w, out2=self.xa_bf)
-                sa_ = sa_w
-                self._guard_stats(sa_)
-            elif self.abf is not None:
+            if self.abf is not None:
                 G.stylize(h, [ff_seg], D, M, self.abf, groups=grp(4))
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, A=self.abf, bias=lw["b_ffo"], residual=xc, stats_out=sa_w,
-                       out2=self.xa_bf, tile_n=tn)
+                       out2=self.xa_bf)
                 sa_ = sa_w   # the next layer's QKV reads the statistics in this tile split
                 self._guard_stats(sa_)
             else:
                 G.gemm(h, M=M, N=D, K=D, W=lw["w_ffo"], out=xa, segs=[ff_seg], seg_len=D, bias=lw["b_ffo"], residual=xc,
                        stats_out=sa_)
         if self.xa_bf is not None:   # the last FFN-out epilogue left the bf16 copy of xa
-            G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, A=self.xa_bf, bias=w.b_out, tile_n=tn)
+            G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, A=self.xa_bf, bias=w.b_out)
         else:
             G.gemm(h, M=M, N=D, K=D, W=w.w_out, out=self.head, segs=[G.Seg(xa)], seg_len=D, bias=w.b_out)
         return self.head

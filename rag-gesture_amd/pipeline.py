@@ -618,7 +618,14 @@ class MotionDiffusion(torch.nn.Module):
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
-        cands = [torch.cuda.Stream(device=self.device) for _ in range(4 * n + 4)]
+        # (torch hands out streams from a pool of 32 per priority and wraps around: more candidates than that would alias
+        #  earlier ones as distinct Python objects -- ADVICE r04 -- so the list is capped and de-duplicated by HIP stream)
+        cands, seen = [], {torch.cuda.current_stream().cuda_stream}
+        for _ in range(min(4 * n + 4, 32)):
+            c = torch.cuda.Stream(device=self.device)
+            if c.cuda_stream not in seen:
+                seen.add(c.cuda_stream)
+                cands.append(c)
         alone(cands[0])  # warm-up
         base = min(alone(cands[0]) for _ in range(3))
         fixed = [torch.cuda.current_stream()]   # the caller's stream keeps working beside the lanes
@@ -628,7 +635,7 @@ class MotionDiffusion(torch.nn.Module):
                 break
             if all(min(together(c, o) for _ in range(2)) < 1.5 * base for o in fixed + chosen):
                 chosen.append(c)
-        rest = [c for c in cands if all(c is not o for o in chosen)]
+        rest = [c for c in cands if all(c.cuda_stream != o.cuda_stream for o in chosen)]
         return chosen, rest
 
     def _make_streams(self):
@@ -1008,7 +1015,7 @@ class MotionDiffusion(torch.nn.Module):
         # (the engine a session RESOLVES to: without sequence streams -- L > 8, ff_size != 1024, T > 48 -- it is the chain)
         seq = so.get("engine") != "chain" and getattr(self.model.weights, "seq_streams", None) is not None
         groups_ok = self.precision == "bf16" and (seq or (
-            so.get("styl_prepass", True) and not so.get("styl_in_gemm") and not so.get("sa_fused")))
+            so.get("styl_prepass", True)))
         can_defer = (groups_ok and st.use_inversion and not st.visualize_inversion and not st.ddpm and st.plan == st.plan_s
                      and all(ex for *_, ex in lanes))
         same = pend is not None and can_defer and (pend.B, pend.T) == (st.B, st.T) and \

@@ -143,56 +143,6 @@ def test_sample_loop_graph_matches_eager_and_oracle(rg, setup):
     assert e <= 2e-2
 
 
-def test_fused_self_attention_stylization_matches_separate_kernels(rg):
-    """DenoiserSession(sa_fused=True) routes the self-attention block through rg_sa_stylize (16-wave kernel, V as bf16 from the
-    QKV GEMM's split output); it must agree with the default sa_attention + stylize path to bf16 accuracy."""
-    cfg = rg.synth.default_model_cfg(num_layers=2)
-    sch = rg.schedule.Schedule()
-    W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, sch, "cuda", precision="bf16")
-    B = 3
-    g = np.random.Generator(np.random.PCG64(3))
-    x = torch.from_numpy(g.standard_normal((B, 43, 512)).astype(np.float32)).cuda()
-    d = rg.synth.synth_batch(B, seed=1)
-    mask = torch.ones(B, 43)
-    mask[:, [10, 21, 32]] = 0
-    mask[1, 7:10] = 0
-    outs = []
-    for fused in (False, True):
-        sess = rg.denoiser.DenoiserSession(W, B, sa_fused=fused, ln_mode="folded", engine="chain")
-        assert (sess.v_sa is not None) == fused
-        sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, None)
-        outs.append(sess.forward(x, 17).clone())
-    e = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
-    print("fused vs separate self-attention path: rel diff %.3e" % e)
-    assert e <= 5e-3
-
-
-@pytest.mark.parametrize("B", [3, 48])
-def test_stylization_inside_gemm_matches_separate_pass(rg, B):
-    """DenoiserSession(styl_in_gemm=True): sa_attention / the FFN's second GEMM leave y as bf16 and the SA-out / FFN-out
-    GEMMs stylize the landed A tiles in LDS (rg_gemm_desc.seg with a bf16 A).  B = 3: one workgroup per CU (ring of 5,
-    8 waves); B = 48 (M = 4128, 260 workgroups): the two-per-CU variant (ring of 3, 4 waves).  Must agree with the
-    default path (fp32 y, rg_stylize launches) to bf16 accuracy."""
-    cfg = rg.synth.default_model_cfg(num_layers=2)
-    sch = rg.schedule.Schedule()
-    W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, sch, "cuda", precision="bf16")
-    g = np.random.Generator(np.random.PCG64(3))
-    x = torch.from_numpy(g.standard_normal((B, 43, 512)).astype(np.float32)).cuda()
-    d = rg.synth.synth_batch(B, seed=1)
-    mask = torch.ones(B, 43)
-    mask[:, [10, 21, 32]] = 0
-    mask[1, 7:10] = 0
-    outs = []
-    for in_gemm in (False, True):
-        sess = rg.denoiser.DenoiserSession(W, B, styl_in_gemm=in_gemm, ln_mode="folded", engine="chain")
-        assert sess.styl_gemm == in_gemm
-        sess.set_conditions(d["word"], d["audio"], d["speaker_ids"], mask, None)
-        outs.append(sess.forward(x, 17).clone())
-    e = ((outs[1] - outs[0]).norm() / outs[0].norm()).item()
-    print("stylization inside the GEMM vs separate pass (B=%d): rel diff %.3e" % (B, e))
-    assert e <= 5e-3
-
-
 @pytest.mark.parametrize("B,duo", [(1, False), (3, False), (11, False), (1, True), (3, True), (11, True)])
 def test_seq_forward_matches_launch_chain_and_oracle(rg, parity, setup, B, duo):
     """The sequence-stationary forward (rg_seq_forward: one workgroup per sequence, one launch; duo: rg_seq2_forward, two
