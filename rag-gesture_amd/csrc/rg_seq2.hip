@@ -358,11 +358,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     for (int b = 0; b < 6; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pl + (b / 3) * PANEL + (((b % 3) * 16) << 10));
 #pragma unroll 1
     for (int s = 0; s < 16; ++s) {
-#if defined(RG2_PRIO) && RG2_PRIO >= 2     // (experiment) the later-dispatched half of the waves takes the priority on every other 2^(RG2_PRIO-2) k-steps
-      if (wave >= 4) { if ((s >> (RG2_PRIO - 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif defined(RG2_PRIO) && RG2_PRIO == 1
-      if (wave >= 4 && s == 0) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         // w[j & 1] is in registers: the oldest LDS read outstanding (behind it at most the six panel re-reads)
@@ -388,9 +383,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#ifdef RG2_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     TSTOP(0);
     TLOG();
   };

@@ -203,6 +203,12 @@ class LongformSynthesizer:
             capi.require(not self.model._pend and not self.model._ready,
                          "long-form synthesis (pipelined): the model's submit() pipeline must be empty (call flush() first)")
         queued = []          # (cidx, clips of the window) of the windows whose results are still in the pipeline
+        # window k + 1 samples from window k's latents: at most two window batches are ever busy (one sampling, the next one
+        # inverting its exemplars).  They rotate over up to four lanes (as in round 4), and the launch forms are chosen for the
+        # two chains that really run side by side, not for the model's whole rotation (pipeline._seq_form_auto)
+        rot_before, form_before = getattr(self.model, "rotation_lanes", None), getattr(self.model, "form_lanes", None)
+        if pipelined:
+            self.model.rotation_lanes, self.model.form_lanes = min(4, self.model.batch_lanes), 2
 
         def take(out):
             cidx, act = queued.pop(0)
@@ -272,6 +278,7 @@ class LongformSynthesizer:
         if pipelined:
             for out in self.model.flush():
                 take(out)
+            self.model.rotation_lanes, self.model.form_lanes = rot_before, form_before
         capi.require(not queued, "long-form synthesis: windows left in the pipeline")
         results = {ci: self._finish(state[ci], with_gt) for ci in mine}
         if gather and td.is_available() and td.is_initialized() and td.get_world_size() > 1:

@@ -372,6 +372,7 @@ class MotionDiffusion(torch.nn.Module):
         # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
         self.rotation_lanes = None     # submit(): lanes in the rotation of whole batches (None: batch_lanes / base_lanes); longform.py pins 1
+        self.form_lanes = None         # ... and how many of their chains really run side by side (None: all of them); longform.py: 2
         self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
         # co-batched pipeline (submit / flush): the batch whose exemplars are inverted and whose sampling is still to come
         # (one pipeline per lane when whole batches alternate between the lanes, cobatch_lanes="batch"; else one, key None)
@@ -552,8 +553,10 @@ class MotionDiffusion(torch.nn.Module):
                     del self._graph_owner[gk]
             opts = dict(self.session_options)
             if opts.get("seq_pairs", "auto") == "auto":
-                opts["seq_pairs"] = self._seq_pairs_auto(B)
-                if opts["seq_pairs"] and role == "invert" and opts.get("seq_duo") is None:
+                opts["seq_pairs"], duo = self._seq_form_auto(B)
+                if opts.get("seq_duo") is None:
+                    opts["seq_duo"] = duo
+                if opts["seq_pairs"] and opts["seq_duo"] and role == "invert":
                     # an inversion ALONE runs only while the pipeline fills (in the steady state it shares the launches of a
                     # pending batch's sampling): the chip is emptying or empty then, so the classifier-free pairs get workgroups
                     # of their own (B workgroups for 1.6 ms instead of B / 2 for 2.6 ms per launch; same bits)
@@ -568,12 +571,25 @@ class MotionDiffusion(torch.nn.Module):
         batch lane whose launches would not fit the chip beside the other lanes' otherwise: 2 B workgroups x the lanes in
         rotation > compute units.  Narrow launches (the sampling of a last batch, synchronous forwards, the base workload) keep
         one workgroup per sequence: 1.0 instead of 1.65 ms per launch."""
+        return self._seq_form_auto(B, cus)[0]
+
+    def _seq_form_auto(self, B, cus=None):
+        """(seq_pairs, seq_duo) of a session of B clips: the WIDEST launch form that still fits the chip beside the other lanes'
+        launches -- 2 B workgroups (one per sequence, 1.0 ms per launch), B (one per clip: conditional sequence, then its twin,
+        1.65 ms), or B / 2 (rg_seq2: two clips per workgroup, 2.6 ms, 0.78 of the CU time) -- counted over the lanes that whole
+        batches currently rotate over (batch_lanes; base_lanes for batches without inversion; what longform.py pins).  All forms
+        give the same bits."""
         cob = self._cob
         if not (self.async_results and cob is not None and cob.get("lane") is not None):
-            return False
+            return False, False
         if cus is None:
             cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        return 2 * B * self.batch_lanes > cus
+        rot = getattr(self, "_cur_rot", None) or self.batch_lanes
+        if 2 * B * rot <= cus:
+            return False, False
+        if B * rot <= cus:
+            return True, False
+        return True, True
 
     def _set_conditions(self, B, role, lane, word, audio, speaker_ids, motion_mask, query_masks):
         """DenoiserSession.set_conditions through the graph cache: its ~55 launches (pre-projections, per-layer K/V
@@ -752,6 +768,7 @@ class MotionDiffusion(torch.nn.Module):
             self._lane_plan(B)                                   # (makes the streams on first use)
             n_rot = getattr(self, "rotation_lanes", None) or (self.batch_lanes if use_inversion else self.base_lanes)
             n_rot = max(1, min(int(n_rot), len(self._lane_streams)))
+            self._cur_rot = getattr(self, "form_lanes", None) or n_rot      # chains that really run side by side (launch forms)
             pid = cob["lane"] % n_rot
             plan = plan_s = [(pid, self._lane_streams[pid], 0, B)]
         if run_async:

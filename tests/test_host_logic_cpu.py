@@ -254,6 +254,14 @@ def test_batch_lane_rules_results_in_submission_order_and_paired_launches(rg):
     assert m._seq_pairs_auto(64, cus=256) and not m._seq_pairs_auto(32, cus=256)   # 2 x 32 x 4 = 256 fits
     m.batch_lanes = 2
     assert not m._seq_pairs_auto(64, cus=256)        # two lanes of 128 workgroups fit
+    m.batch_lanes, m._cob = 8, dict(lane=7)
+    assert m._seq_form_auto(64, cus=256) == (True, True)       # co-batched chains of eight lanes: two clips per workgroup (rg_seq2)
+    assert m._seq_form_auto(16, cus=256) == (False, False)     # 2 x 16 x 8 = 256 fits: one workgroup per sequence
+    m._cur_rot = 3                                             # base batches rotate over base_lanes
+    assert m._seq_form_auto(32, cus=256) == (False, False)     # 2 x 32 x 3 = 192 fits
+    m._cur_rot = 2                                             # long-form window batches alternate between two lanes
+    assert m._seq_form_auto(96, cus=256) == (True, False)      # 96 exemplars: one workgroup per clip (192), not per two
+    m._cur_rot = None
     m.batch_lanes, m._cob = 4, None
     assert not m._seq_pairs_auto(64, cus=256)        # synchronous forwards: never
     m._cob, m.async_results = dict(lane=None), True
