@@ -341,7 +341,7 @@ class MotionDiffusion(torch.nn.Module):
                  diffusion_train=None, diffusion_test=None, init_cfg=None, inference_type="ddpm",
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
-                 vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=3,
+                 vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=8,
                  batch_lanes=8, lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused

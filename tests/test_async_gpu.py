@@ -276,7 +276,7 @@ def test_base_batches_alternate_between_base_lanes(rg):
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs), database=None, device=dev)
     model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
     model.eval()
-    batches = _batches(rg, 3, 7, dev)
+    batches = _batches(rg, 3, model.base_lanes + 2, dev)      # (more batches than lanes: two lanes see a second batch)
 
     def args(i):
         d = dict(batches[i])
@@ -305,7 +305,7 @@ def test_base_batches_alternate_between_base_lanes(rg):
 def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate, batch_lanes):
     """The regression test of the round-3 race (two tails on two lanes shared ONE decode graph): guided batches through
     submit() / flush() without any host synchronisation between them -- so tails, chains and front ends of neighbouring
-    batches really overlap -- with random delays injected on every stream, repeatedly; then base batches over three lanes.
+    batches really overlap -- with random delays injected on every stream, repeatedly; then base batches over the base lanes.
     Every pass must reproduce the synchronous forwards bit for bit.  Also with graphs off (eager launches: bisects graph
     buffers against everything else) and with the measured stream choice."""
     dev = torch.device("cuda", 0)
@@ -346,7 +346,7 @@ def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate,
             torch.cuda.synchronize()
             _same(got, want[name], model, "jitter pass %d %s" % (rep, name))
         assert model._jitter.calls > 0
-    n_lanes = max(2, 3, batch_lanes)      # lanes of a synchronous forward, base lanes, batch lanes
+    n_lanes = max(2, model.base_lanes, batch_lanes)      # lanes of a synchronous forward, base lanes, batch lanes
     assert model.lane_report["streams"] == n_lanes + 2 and len(model._lane_streams) == n_lanes and model._search_stream is not None
     if use_graphs:
         assert any(k[0] == "dec" and k[-1] >= 0 for k in model._graphs), "decode graphs are per tail lane"
