@@ -124,7 +124,8 @@ __device__ __forceinline__ void bar() {
 #ifdef RG_STAMPS
 // Diagnostic build only (build.py RG_DIAG=1): wall-clock (100 MHz) time per category, summed per wave, written to
 // a.dump[(workgroup * 8 + wave) * 8 + category] when dump_stage == 99.  Categories: 0 unit GEMMs, 1 row statistics (with their
-// barrier), 2 other barriers, 3 parameter fragments + panel writes, 4 attention math, 5 whole pass, 6 xbuf / gbuf traffic.
+// barrier), 2 other barriers, 3 parameter fragments + panel writes, 4 attention math, 5 whole pass, 6 xbuf / gbuf traffic,
+// 7 waiting in consume() (counted inside whatever category encloses it).
 #define TSTART() const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime()
 #define TSTOP(cat) tacc[cat] += __builtin_amdgcn_s_memrealtime() - t0_
 // + the duration of every gemm_frags call, in call order: a.dump[(1 << 20) + (workgroup * 8 + wave) * 512 + call]
@@ -170,7 +171,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   const int clips[2] = {cond ? sA : sA - B, cond ? sB : sB - B};
   const int st = clips[0] >= a.split ? a.step_b : a.step;
 #ifdef RG_STAMPS
-  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int ncall = 0;
   const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -296,7 +297,13 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   // relaxed wait chosen per fragment by a wave-uniform counter (1 846 vs 1 924 us per 128-sequence launch).
   auto ring_wait = [&]() { wait_vmcnt<RD - 1>(); };
   auto consume = [&]() -> const unsigned char* {
+#ifdef RG_STAMPS
+    const unsigned long long tc0_ = __builtin_amdgcn_s_memrealtime();
     ring_wait();
+    tacc[7] += __builtin_amdgcn_s_memrealtime() - tc0_;      // (category 7: waiting for a parameter / table fragment, i.e. behind a burst)
+#else
+    ring_wait();
+#endif
     return ring + head * 1024;
   };
   auto release = [&]() {
@@ -989,7 +996,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #ifdef RG_STAMPS
   if (a.dump_stage == 99 && lane0 == 0) {
     tacc[5] = __builtin_amdgcn_s_memrealtime() - tk0;
-    for (int i = 0; i < 7; ++i) a.dump[(blockIdx.x * 8 + wave) * 8 + i] = (float)tacc[i];
+    for (int i = 0; i < 8; ++i) a.dump[(blockIdx.x * 8 + wave) * 8 + i] = (float)tacc[i];
   }
 #endif
 #undef LANE_LOCAL

@@ -44,4 +44,22 @@ def run():
                   % (precision, tag, engine, err, tol, worst, et))
             if not (err <= tol and worst <= 5 * tol and et <= 3 * tol):
                 raise AssertionError("smoke: HIP path disagrees with the oracle (%s %s: %g, %g, %g)" % (precision, tag, err, worst, et))
+    # the wide-launch form of the denoiser forward (rg_seq2_forward: two sequences of a kind per workgroup, what the pipelined
+    # path launches) must give the bits of the one-workgroup-per-sequence form that the forwards above ran
+    from . import denoiser, schedule
+    from oracle import denoiser as od
+    W = denoiser.DenoiserWeights(synth.synth_denoiser_state(0, cfg), cfg, schedule.Schedule(), "cuda:0")
+    d3 = synth.synth_batch(3, seed=12)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(4)).standard_normal((3, 43, 512)).astype(np.float32)).cuda()
+    mm = torch.ones(3, 43)
+    mm[:, [10, 21, 32]] = 0
+    heads = []
+    for kw in (dict(seq_duo=False), dict(seq_duo=True, seq_pairs=True)):
+        sess = denoiser.DenoiserSession(W, 3, engine="seq", **kw)
+        sess.set_conditions(d3["word"], d3["audio"], d3["speaker_ids"], mm, od.make_query_masks(mm))
+        heads.append(sess.forward(x, 31, 7, 1).clone())
+    torch.cuda.synchronize()
+    if not (torch.isfinite(heads[1]).all() and torch.equal(heads[0], heads[1])):
+        raise AssertionError("smoke: rg_seq2_forward differs from rg_seq_forward")
+    print("smoke: rg_seq2_forward (two sequences per workgroup) == rg_seq_forward, bit for bit")
     print("smoke ok: " + "; ".join("%s/%s %.1e" % (p, t, e) for p, t, _, e, _, _ in rows))
