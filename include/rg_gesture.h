@@ -326,14 +326,11 @@ typedef struct rg_seq_args {
   const float* qmask;      /* fp32 [3][2B][T] */
   float* head;             /* fp32 [2B][T][512] result */
   float* dump;
-  float* xbuf;             /* fp32 [2B][8][12][64][4] hand-over of the residual stream between the launches of one forward, or NULL */
-  void* gbuf;              /* rg_seq2_forward: bf16 [workgroups][2][48 KiB] panel images; its xbuf is fp32 [workgroups][2][8][12][64][4] */
+  float* xbuf;             /* rg_seq2_forward: fp32 [workgroups][2][8][12][64][4] round trips of the two sequences' tiles; rg_seq_forward: unused */
+  void* gbuf;              /* rg_seq2_forward: bf16 [workgroups][4][2][48 KiB] panel images; rg_seq_forward: unused */
   int L, B, T, S;          /* layers, clips, tokens, steps in pstream / ustream */
   int step, step_b, split; /* clips [0, split) at step, clips [split, B) at step_b */
   int dump_stage, dump_layer;
-  int l0, l1;              /* this launch runs layers [l0, l1): + the embedding when l0 == 0, + the head when l1 == L.  A forward
-                              cut into several launches frees every compute unit between them (a workgroup holds its CU for the
-                              whole launch), which lets OTHER streams' kernels in between them (measured without gain on the step: NOTEBOOK 8.4) */
   int pairs;               /* 0: one workgroup per sequence (2 B workgroups); 1: one workgroup per clip runs the conditional
                               sequence, then its classifier-free twin (B workgroups, 1.7x as long: less CU time per forward,
                               for callers that run several narrow launches side by side) -- same results bit for bit */

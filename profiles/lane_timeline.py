@@ -19,8 +19,6 @@ database = rg.synth.SyntheticDataset(int(os.environ.get("DB", "32768")), seed=20
 model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=database, device=dev)
 model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
 model.eval()
-if "SEQ_LAUNCHES" in os.environ:
-    model.session_options["seq_launches"] = int(os.environ["SEQ_LAUNCHES"])
 if "SEQ_PAIRS" in os.environ:
     model.session_options["seq_pairs"] = bool(int(os.environ["SEQ_PAIRS"]))
 if "MAX_INFLIGHT" in os.environ:

@@ -205,12 +205,8 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
   };
   const int NU = UPL * L + 2;
   const int nspl = cond ? NSEG_COND : NSEG_UNC;          // fetch segments per layer
-  // this launch runs layers [l0, l1) (+ the embedding in front when l0 == 0, + the head behind when l1 == L); between two
-  // launches of one forward the residual stream travels through a.xbuf (96 KiB per sequence)
-  const int l0 = a.l0, l1 = a.l1;
-  const bool do_embed = l0 == 0, do_head = l1 == L;
-  const int pre = do_embed ? 2 : 0;
-  const int n_seg = pre + nspl * (l1 - l0) + (do_head ? 2 : 0);   // embed (P, W), layers, head (P, W)
+  const int pre = 2;
+  const int n_seg = pre + nspl * L + 2;   // embed (P, W), layers, head (P, W)
 
   // ---- fetch program of this sequence: one {address for wave 0, fragment count, wave stride in fragments} per segment,
   // in consumption order, + a sentinel that keeps the in-flight count invariant behind the end.  Classifier-free
@@ -222,11 +218,11 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     if (tid < n_seg) {
       int uid, kind, idx = 0, l = 0;
       if (tid < pre) { uid = 0; kind = tid; }
-      else if (tid >= pre + nspl * (l1 - l0)) { uid = NU - 1; kind = tid - (pre + nspl * (l1 - l0)); }
+      else if (tid >= pre + nspl * L) { uid = NU - 1; kind = tid - (pre + nspl * L); }
       else {
         const int q = tid - pre;
-        l = l0 + q / nspl;
-        const unsigned char e = cond ? SEG_COND[q - (l - l0) * nspl] : SEG_UNC[q - (l - l0) * nspl];
+        l = q / nspl;
+        const unsigned char e = cond ? SEG_COND[q - l * nspl] : SEG_UNC[q - l * nspl];
         idx = e >> 2;
         kind = e & 3;
         uid = 1 + UPL * l + idx;
@@ -278,14 +274,13 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     const int t = min(16 * tb + l15, T - 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      xr[j][tb] = do_embed ? *reinterpret_cast<const f32x4*>(a.tbias + (size_t)t * DM + 64 * wave + 16 * j + 4 * g4)
-                           : *reinterpret_cast<const f32x4*>(a.xbuf + ((((size_t)seq * NW + wave) * 12 + j * 3 + tb) * 64 + lane) * 4);
+      xr[j][tb] = *reinterpret_cast<const f32x4*>(a.tbias + (size_t)t * DM + 64 * wave + 16 * j + 4 * g4);
   }
   }
   // ---- panel P0 = bf16(x_in): fragment (tb, s) = tokens [16 tb, +16) x features [32 s, +32): lane (l15, g) holds the 8
   // features [32 s + 8 g, +8) of token 16 tb + l15
 #pragma unroll
-  for (int it = 0; do_embed && it < (TP * 64) / NTH; ++it) {
+  for (int it = 0; it < (TP * 64) / NTH; ++it) {
     const int slot = tid + NTH * it, t = slot >> 6, c8 = slot & 63;
     const float* xp = a.x + ((size_t)clip * T + min(t, T - 1)) * DM + c8 * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp), v1 = *reinterpret_cast<const f32x4*>(xp + 4);
@@ -552,13 +547,11 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
   };
 
   // =========================================================== embedding: x = joint_embed(x_in) + tables
-  if (do_embed) {
-    unit(xr, P0, TL);
-    if (a.dump_stage == 1) dump(xr);
-  }
+  unit(xr, P0, TL);
+  if (a.dump_stage == 1) dump(xr);
 
 #pragma unroll 1
-  for (int layer = l0; layer < l1; ++layer) {
+  for (int layer = 0; layer < L; ++layer) {
     const bool dl = a.dump && layer == a.dump_layer;
     float mean[3], rstd[3];
     // ======================================================= self attention (efficient_attention.py:23-45)
@@ -788,28 +781,20 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
 
   // =========================================================== output head (diffusion_transformer.py:662-666)
   LANE_LOCAL();
-  if (do_head) {
-    barx();
-    write_raw(P0, xr);
-    barx();
-    Acc out;
-    zero(out);
-    unit(out, P0, TL);
+  barx();
+  write_raw(P0, xr);
+  barx();
+  Acc out;
+  zero(out);
+  unit(out, P0, TL);
 #pragma unroll
-    for (int tb = 0; tb < 3; ++tb) {
-      const int t = 16 * tb + l15;
-      if (t < T) {
+  for (int tb = 0; tb < 3; ++tb) {
+    const int t = 16 * tb + l15;
+    if (t < T) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(a.head + ((size_t)seq * T + t) * DM + 64 * wave + 16 * j + 4 * g4) = out[j][tb];
-      }
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<f32x4*>(a.head + ((size_t)seq * T + t) * DM + 64 * wave + 16 * j + 4 * g4) = out[j][tb];
     }
-  } else {   // hand the residual stream to the next launch: 12 wave-instructions of 1 KiB, lane-linear
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int tb = 0; tb < 3; ++tb)
-        *reinterpret_cast<f32x4*>(a.xbuf + ((((size_t)seq * NW + wave) * 12 + j * 3 + tb) * 64 + lane) * 4) = xr[j][tb];
   }
   wait_vmcnt<0>();
 #ifdef RG_STAMPS
@@ -852,8 +837,6 @@ extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* 
   RG_REQUIRE(h, a.L >= 1 && a.L <= 8 && a.B >= 1 && a.T >= 1 && a.T <= TP, "unsupported shape (T <= 48, L <= 8)");
   RG_REQUIRE(h, a.step >= 0 && a.step < a.S && a.step_b >= 0 && a.step_b < a.S, "step out of range");
   RG_REQUIRE(h, a.dump_stage == 0 || a.dump, "dump_stage needs a dump buffer");
-  RG_REQUIRE(h, 0 <= a.l0 && a.l0 < a.l1 && a.l1 <= a.L, "layer range [l0, l1) must be a non-empty part of [0, L)");
-  RG_REQUIRE(h, (a.l0 == 0 && a.l1 == a.L) || a.xbuf, "a partial layer range needs the hand-over buffer xbuf");
   RG_REQUIRE(h, a.pairs == 0 || a.pairs == 1, "pairs must be 0 or 1");
   static rg_attr_once lds_once;
   if (!rg_reserve_lds(lds_once, rg_seq_kernel, LDS_BYTES)) {
@@ -870,7 +853,7 @@ extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* 
     rec.start = get_ev(); rec.stop = get_ev();
     rec.variant = 3;
     const double unit = 2.0 * a.T * DM * DM, att = 2.0 * a.T * 32 * 32 * 16;      // one 512 x 512 GEMM; one q A (or K^T V) over 16 heads
-    const int nl = a.l1 - a.l0, ends = (a.l0 == 0) + (a.l1 == a.L);
+    const int nl = a.L, ends = 2;
     const double cond = (UPL * nl + ends) * unit + nl * (2 + 3) * att, unc = (10 * nl + ends) * unit + nl * 2 * att;
     rec.flops = a.B * (cond + unc);
     (void)hipEventRecord(rec.start, rg_stream(stream));

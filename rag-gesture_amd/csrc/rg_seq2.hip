@@ -1049,7 +1049,6 @@ extern "C" int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void*
   RG_REQUIRE(h, a.L >= 1 && a.L <= 8 && a.B >= 1 && a.T >= 1 && a.T <= TP, "unsupported shape (T <= 48, L <= 8)");
   RG_REQUIRE(h, a.step >= 0 && a.step < a.S && a.step_b >= 0 && a.step_b < a.S, "step out of range");
   RG_REQUIRE(h, a.dump_stage == 0 || a.dump, "dump_stage needs a dump buffer");
-  RG_REQUIRE(h, a.l0 == 0 && a.l1 == a.L, "the two-sequence forward runs all layers in one launch");
   RG_REQUIRE(h, a.pairs == 0 || a.pairs == 1, "pairs must be 0 or 1");
   static rg_attr_once lds_once;
   if (!rg_reserve_lds(lds_once, rg_seq2_kernel, LDS_BYTES)) {

@@ -246,15 +246,11 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, xcd_affine=True, engine=None,
-                 seq_launches=1, kv_grouped=True, seq_pairs=False, seq_duo=None):
+                 kv_grouped=True, seq_pairs=False, seq_duo=None):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
         supported, else "chain" (precision="fp32" always runs the chain).
-        seq_launches (engine "seq"): kernel launches per forward (the layers cut into ranges, the residual stream handed over
-        through a 96 KiB-per-sequence buffer).  A workgroup holds its compute unit for a whole launch; cutting the forward
-        frees every CU a few times per millisecond, which lets the kernels of other streams (the next batch's front end) in
-        promptly.  Same bits for every value.
         seq_pairs (engine "seq"): one workgroup per CLIP runs the conditional sequence and then its classifier-free twin (B
         workgroups for ~1.7x the time instead of 2 B of which the classifier-free half idles the last 0.3): less CU time per
         forward for pipelines that run enough narrow chains side by side to fill the chip.  Same bits.
@@ -265,7 +261,8 @@ class DenoiserSession:
         forward finds rows more than LN_GUARD_SIGMAS standard deviations off centre (one read-back, once per session).
         (The "seq" engine evaluates every LayerNorm in fp32 from the fp32 rows.)
         styl_prepass / xcd_affine: measurement knobs of the launch chain (NOTEBOOK section 6).  (Round 5 removed three more
-        that no default used and every measurement had gone against: sa_fused, styl_in_gemm, tile64.)"""
+        that no default used and every measurement had gone against: sa_fused, styl_in_gemm, tile64; and seq_launches, the
+        forward cut into several launches by layer ranges: no gain on the step, NOTEBOOK 8.4.)"""
         # kv_grouped (bf16): the conditions' K / V projections of DenoiserWeights.KV_GROUP layers per GEMM on a bf16 normalised
         # operand (set_conditions); False = one fp32-A GEMM with a LayerNorm prologue per layer and condition (round 1-3)
         self.kv_grouped = bool(kv_grouped)
@@ -298,7 +295,7 @@ class DenoiserSession:
             # time per forward with seq_pairs) -- for the wide launches of a pipeline that fills the chip with them; None: with
             # seq_pairs.  Narrow launches are faster (in latency) with one workgroup per sequence.  Same bits either way.
             duo = bool(seq_pairs) if seq_duo is None else bool(seq_duo)
-            self.sq = SQ.SeqForward(self, launches=seq_launches, pairs=seq_pairs, duo=duo and seq_launches == 1)
+            self.sq = SQ.SeqForward(self, pairs=seq_pairs, duo=duo)
             return
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
         # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide)

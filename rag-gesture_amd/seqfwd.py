@@ -28,8 +28,7 @@ class SeqArgs(ctypes.Structure):
                 ("src_mask", _vp), ("qmask", _vp), ("head", _vp), ("dump", _vp), ("xbuf", _vp), ("gbuf", _vp),
                 ("L", ctypes.c_int), ("B", ctypes.c_int), ("T", ctypes.c_int), ("S", ctypes.c_int),
                 ("step", ctypes.c_int), ("step_b", ctypes.c_int), ("split", ctypes.c_int),
-                ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("l0", ctypes.c_int), ("l1", ctypes.c_int),
-                ("pairs", ctypes.c_int)]
+                ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("pairs", ctypes.c_int)]
 
 
 def supported(cfg, T, precision):
@@ -153,27 +152,21 @@ class SeqStreams:
 class SeqForward:
     """Buffers of one DenoiserSession for rg_seq_forward."""
 
-    def __init__(self, sess, launches=1, pairs=False, duo=True):
+    def __init__(self, sess, pairs=False, duo=True):
         """duo: two sequences of the same kind per workgroup (rg_seq2_forward: every streamed weight fragment feeds both; the
         fp32 residual stream and two bf16 panel images take round trips through scratch buffers in L2) instead of one
         (rg_seq_forward) -- same bits;
-        launches (duo=False): kernel launches per forward (the L layers cut into near-equal ranges; 1 = the whole forward in one);
         pairs: the classifier-free sequences run behind the conditional ones in the SAME workgroups (half as many workgroups,
         ~1.6x as long) instead of in workgroups of their own."""
         w = sess.w
         self.sess, self.h, self.st = sess, sess.h, w.seq_streams
         B, dev = sess.B, w.dev
         self.duo = bool(duo)
-        n = 1 if self.duo else max(1, min(int(launches), w.L))
-        cuts = [round(i * w.L / n) for i in range(n + 1)]
-        self.ranges = [(cuts[i], cuts[i + 1]) for i in range(n) if cuts[i + 1] > cuts[i]]
         self.xbuf = self.gbuf = None
         if self.duo:
             nwg = B + 2          # at most ceil(split / 2) + ceil((B - split) / 2) pairs per kind, two kinds
             self.xbuf = torch.empty(nwg * 2 * 8 * 12 * 64 * 4, device=dev, dtype=torch.float32)
             self.gbuf = torch.empty(nwg * 8 * 48 * 1024, device=dev, dtype=torch.uint8)
-        elif len(self.ranges) > 1:
-            self.xbuf = torch.empty(2 * B * 8 * 12 * 64 * 4, device=dev, dtype=torch.float32)
         self.afrag = torch.zeros(w.L, 3, B, 8, 2, 2, 2, 64, 8, device=dev, dtype=torch.bfloat16)
         a = self.args = SeqArgs()
         p = lambda t: t.data_ptr()
@@ -200,8 +193,7 @@ class SeqForward:
         a.dump = dump.data_ptr() if dump is not None else None
         a.dump_stage, a.dump_layer = int(dump_stage), int(dump_layer)
         s = torch.cuda.current_stream().cuda_stream
-        for a.l0, a.l1 in self.ranges:
-            rc = self._fn(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
-            if rc != 0:
-                raise capi.RgError("rg_seq_forward failed (%d): %s" % (rc, self.h.lib.rg_last_error(self.h._h).decode()))
+        rc = self._fn(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
+        if rc != 0:
+            raise capi.RgError("rg_seq_forward failed (%d): %s" % (rc, self.h.lib.rg_last_error(self.h._h).decode()))
         return self.sess.head

@@ -213,33 +213,14 @@ def test_seq_forward_two_step_groups(rg, setup, duo, split):
     assert not torch.equal(a, b)
 
 
-def test_seq_forward_cut_into_several_launches_is_bit_identical(rg, setup):
-    """DenoiserSession(seq_launches=n): the layers cut into n launches, the residual stream handed over through a buffer."""
-    cfg, P, W = setup[8]
-    B = 3
-    data = rg.synth.synth_batch(B, seed=79)
-    x = torch.from_numpy(np.random.Generator(np.random.PCG64(7)).standard_normal((B, 43, 512)).astype(np.float32)).cuda()
-    mm = torch.ones(B, 43)
-    mm[:, [10, 21, 32]] = 0
-    outs = []
-    for n in (1, 2, 3, 8):
-        sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_launches=n)
-        assert len(sess.sq.ranges) == n and sess.sq.ranges[0][0] == 0 and sess.sq.ranges[-1][1] == 8
-        sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
-        outs.append(sess.forward(x, 23, 40, 1).clone())
-        torch.cuda.synchronize()
-    assert all(torch.equal(o, outs[0]) for o in outs[1:])
-
-
 @pytest.mark.parametrize("B", [1, 5, 16, 64])
 def test_seq_forward_one_workgroup_per_clip_is_bit_identical(rg, setup, B):
     """All launch forms of the sequence-stationary forward give the same bits: one workgroup per sequence (the reference
-    form here), per clip, cut into several launches, and rg_seq2_forward's two sequences of a kind per workgroup with the
+    form here), per clip, and rg_seq2_forward's two sequences of a kind per workgroup with the
     classifier-free pairs in workgroups of their own or behind the conditional ones.
     DenoiserSession(seq_pairs=True): B workgroups, each running a clip's conditional sequence and then its classifier-free
     twin, instead of 2 B workgroups (what the pipeline picks for launches that would not fit the chip beside the other batch
-    lanes').  Same bits: with two step groups, real masks, cut into several launches (the hand-over buffer is per sequence),
-    and over consecutive forwards of one session (nothing of a pass survives into the next)."""
+    lanes').  Same bits: with two step groups, real masks, and over consecutive forwards of one session (nothing of a pass survives into the next)."""
     cfg, P, W = setup[8]
     data = rg.synth.synth_batch(B, seed=80)
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(8)).standard_normal((B, 43, 512)).astype(np.float32)).cuda()
@@ -247,14 +228,14 @@ def test_seq_forward_one_workgroup_per_clip_is_bit_identical(rg, setup, B):
     mm[:, [10, 21, 32]] = 0
     mm[0, 30:] = 0
     outs = {}
-    for pairs, n in ((False, 1), (True, 1), (True, 3), (False, "duo"), (True, "duo")):
+    for pairs, n in ((False, 1), (True, 1), (False, "duo"), (True, "duo")):
         duo = n == "duo"
-        sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=pairs, seq_launches=1 if duo else n, seq_duo=duo)
+        sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=pairs, seq_duo=duo)
         assert sess.sq.args.pairs == int(pairs) and sess.sq.duo == duo
         sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
         outs[pairs, n] = [sess.forward(x, st, sb, sp).clone() for st, sb, sp in ((49, None, None), (23, 40, max(1, B // 3)), (0, None, None))]
         torch.cuda.synchronize()
-    for key in ((True, 1), (True, 3), (False, "duo"), (True, "duo")):
+    for key in ((True, 1), (False, "duo"), (True, "duo")):
         for i, (a, b) in enumerate(zip(outs[key], outs[False, 1])):
             assert torch.isfinite(a).all() and torch.equal(a, b), (B, key, i, (a - b).abs().max().item())
     assert not torch.equal(outs[False, 1][0], outs[False, 1][2])
