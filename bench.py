@@ -342,10 +342,14 @@ class Workload:
         n, ms, fl = events()
         ach = fl / (ms * 1e-3) if ms > 0 else 0.0
         duo_forms = {(int(s_.sq.duo), int(s_.sq.args.pairs)) for k, s_ in model._sessions.items() if s_.sq is not None and k[1] == "cobatch"} if seq else set()
-        duo = (1, 1) in duo_forms and self.cobatch
+        duo = (1, 1) in duo_forms and self.cobatch           # two clips per workgroup: conditional pair, then the classifier-free pair
+        duo_wide = (1, 0) in duo_forms and self.cobatch and not duo      # the two pairs in workgroups of their own
         kernel = {3: ("rg_seq2_kernel (a whole denoiser forward per workgroup -- embedding, 8 decoder layers, head -- of TWO conditional "
                       "sequences, then of their two classifier-free twins: every streamed weight fragment feeds 6 MFMAs; bf16 MFMA, fp32 "
                       "accumulate; weights streamed by LDS-DMA)" if duo else
+                      "rg_seq2_kernel (a whole denoiser forward per workgroup -- embedding, 8 decoder layers, head -- of TWO sequences "
+                      "of a kind, conditional or classifier-free: every streamed weight fragment feeds 6 MFMAs; bf16 MFMA, fp32 "
+                      "accumulate; weights streamed by LDS-DMA)" if duo_wide else
                       "rg_seq_kernel (a whole denoiser forward per workgroup -- embedding, 8 decoder layers, head -- of one sequence, or of "
                       "a clip's conditional sequence and then its classifier-free twin; bf16 MFMA, fp32 accumulate; weights streamed by "
                       "LDS-DMA)"),
@@ -364,8 +368,8 @@ class Workload:
             seqs = 2 * round(fl / max(1, n) / per_clip)
             cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
             r["sequences_per_launch"] = seqs
-            r["workgroups_per_launch"] = seqs // 4 if duo else (seqs // 2 if paired else seqs)
-            r["launch_form"] = "duo_pairs" if duo else ("pairs" if paired else "one_per_sequence")
+            r["workgroups_per_launch"] = seqs // 4 if duo else (seqs // 2 if (paired or duo_wide) else seqs)
+            r["launch_form"] = "duo_pairs" if duo else ("duo" if duo_wide else ("pairs" if paired else "one_per_sequence"))
             # a workgroup owns a compute unit for the whole launch (155 KiB of LDS): the share of the chip a launch can use
             r["cu_share"] = round(min(1.0, r["workgroups_per_launch"] / cus), 4)
             r["frac_of_occupied_cus"] = round(ach / (peak * r["cu_share"]), 5) if r["cu_share"] else None
@@ -373,6 +377,8 @@ class Workload:
                          "one lane's launch against the WHOLE chip's peak, `frac_of_occupied_cus` against the peak of the CUs it "
                          "holds; the chip-level rate is the sum over the lanes' concurrent launches (`whole_step`)"
                          % ("one workgroup per two clips: their conditional sequences, then their classifier-free twins" if duo else
+                            "one workgroup per two sequences of a kind; the classifier-free half of the workgroups leaves after 0.63 of "
+                            "the launch, which `frac_of_occupied_cus` does not credit" if duo_wide else
                             "one workgroup per clip: conditional sequence, then its classifier-free twin" if paired
                             else "one workgroup per sequence", self.rotation()))
         return r
@@ -641,8 +647,9 @@ def main():
                 if roofline.get("workgroups_per_launch") is not None:
                     # (r04_pmc_seq: 128 workgroups, one per sequence; r04s_pmc_seq_pairs: 64 workgroups, one per clip -- the twin's
                     #  pass streams the shared weights through every L2 a second time)
-                    # (r05k_pmc_seq2_pairs: 32 workgroups, two clips each -- rg_seq2_kernel, what the pipeline launches)
-                    src = {"duo_pairs": "r05k_pmc_seq2_pairs.json", "pairs": "r04s_pmc_seq_pairs.json"}.get(roofline.get("launch_form"), "r04_pmc_seq.json")
+                    # (r05k_pmc_seq2_pairs: 32 workgroups, two clips each -- rg_seq2_kernel with eight batch lanes;
+                    #  r05w_pmc_seq2_wide: 64 workgroups, two sequences of a kind each -- what the default four lanes launch)
+                    src = {"duo_pairs": "r05k_pmc_seq2_pairs.json", "duo": "r05w_pmc_seq2_wide.json", "pairs": "r04s_pmc_seq_pairs.json"}.get(roofline.get("launch_form"), "r04_pmc_seq.json")
                     with open(os.path.join(ROOT, "profiles", src)) as f:
                         pm = json.load(f)
                     # these three are NOT measured in this run: they are read from the committed rocprofv3 --pmc passes over the

@@ -323,11 +323,13 @@ class MotionDiffusion(torch.nn.Module):
                         are queued before forward() blocks on the oldest.
       batch_lanes       submit() of batches WITH exemplar inversion (the co-batched pipeline): whole batches rotate over this
                         many lanes, each running [sampling of its pending batch || inversion of the new one] as one chain of 50
-                        launches.  2 lanes x 128 workgroups (one per sequence) fill the chip but leave the classifier-free half
-                        idle for the last 0.3 of every launch; 4 lanes x 64 workgroups (one per CLIP: conditional sequence, then
-                        its twin -- DenoiserSession seq_pairs, chosen automatically where the lanes' launches would not fit the
-                        chip side by side) keep every compute unit busy: 36.2 vs 38.7 ms per guided step of 16 clips over 24
-                        steps, 34.8 vs 37.8 over 48 (profiles/r04s_pairs_lanes.txt); latency per batch 320 vs 190 ms
+                        launches; the launch form follows from the lanes (_seq_form_auto).  Default 4: 4 lanes x 64 workgroups
+                        of rg_seq2_kernel (two sequences of a kind per workgroup; the 32 classifier-free workgroups leave after
+                        1.05 of the launch's 1.66 ms and the front end of the next batch runs on their compute units).  8 lanes
+                        x 32 workgroups (the classifier-free pair behind the conditional one in the same workgroup, 2.6 ms per
+                        launch) hold every compute unit all the time: 2 % more batches per second in a long run (33.1 vs 33.9
+                        ms per guided step of 16 clips over 40 steps), but twice the batches in flight, twice the latency per
+                        batch and a longer fill and drain (36.4 vs 35.5 ms over 20 steps; profiles/r05w_lanes_forms.txt)
       lane_streams      the caller's own streams for the lanes / the search / the base and batch lanes
                         (max(lanes, base_lanes, batch_lanes) + 2 of them)
       calibrate_lanes   (default) pick streams that were measured to run concurrently (distinct hardware queues) first --
@@ -342,7 +344,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=8,
-                 batch_lanes=8, lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
+                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -566,19 +568,12 @@ class MotionDiffusion(torch.nn.Module):
             self._sessions[key] = self._sessions.pop(key)        # most recently used goes last
         return self._sessions[key]
 
-    def _seq_pairs_auto(self, B, cus=None):
-        """One workgroup per clip instead of one per sequence (DenoiserSession seq_pairs; same bits) for the sessions of a
-        batch lane whose launches would not fit the chip beside the other lanes' otherwise: 2 B workgroups x the lanes in
-        rotation > compute units.  Narrow launches (the sampling of a last batch, synchronous forwards, the base workload) keep
-        one workgroup per sequence: 1.0 instead of 1.65 ms per launch."""
-        return self._seq_form_auto(B, cus)[0]
-
     def _seq_form_auto(self, B, cus=None):
         """(seq_pairs, seq_duo) of a session of B clips: the WIDEST launch form that still fits the chip beside the other lanes'
-        launches -- 2 B workgroups (one per sequence, 1.0 ms per launch), B (one per clip: conditional sequence, then its twin,
-        1.65 ms), or B / 2 (rg_seq2: two clips per workgroup, 2.6 ms, 0.78 of the CU time) -- counted over the lanes that whole
-        batches currently rotate over (batch_lanes; base_lanes for batches without inversion; what longform.py pins).  All forms
-        give the same bits."""
+        launches -- 2 B workgroups (one per sequence, 1.0 ms per launch), B (rg_seq2: two sequences of a kind per workgroup,
+        1.66 ms; the classifier-free half of the workgroups leaves after 1.05), or B / 2 (rg_seq2, the classifier-free pair
+        behind the conditional one in the same workgroup, 2.6 ms) -- counted over the lanes that whole batches currently rotate
+        over (batch_lanes; base_lanes for batches without inversion; what longform.py pins).  All forms give the same bits."""
         cob = self._cob
         if not (self.async_results and cob is not None and cob.get("lane") is not None):
             return False, False
@@ -588,7 +583,7 @@ class MotionDiffusion(torch.nn.Module):
         if 2 * B * rot <= cus:
             return False, False
         if B * rot <= cus:
-            return True, False
+            return False, True
         return True, True
 
     def _set_conditions(self, B, role, lane, word, audio, speaker_ids, motion_mask, query_masks):

@@ -175,8 +175,7 @@ def test_cobatched_pipeline_equals_synchronous_forwards(rg, mode):
     elif mode == "batch4-small":
         model.batch_lanes = 4
     elif mode == "batch4-pairs":
-        assert model.batch_lanes == 8 and model.cobatch_lanes == "batch"
-        model.batch_lanes = 4
+        assert model.batch_lanes == 4 and model.cobatch_lanes == "batch"
         torch.cuda.synchronize()     # (the references above ran one workgroup per sequence: new sessions from here on)
         model._sessions.clear(), model._graphs.clear(), model._graph_owner.clear()
         model.session_options["seq_pairs"] = True

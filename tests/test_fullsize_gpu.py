@@ -137,18 +137,22 @@ def test_config3_guided_b16_full_db_vs_oracle(rg, parity):
     _check_clips(rg, parity, "config 3 (synchronous forward)", (0, 7, 15), B, P, cfg, vae_cfgs, cpu_db, keep, tape, ex, out, ikw)
 
 
-def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity):
-    """What bench.py times: asynchronous submission, co-batched pipeline, whole batches rotating over the batch lanes (eight;
-    DenoiserSession seq_pairs + seq_duo, picked by the pipeline for launches of this width: a workgroup runs two conditional
-    sequences, then their classifier-free twins).  Batch n shares a lane with batches n - 8 and n + 8: of seventeen different
-    batches the ninth has its exemplar inversion co-batched with an earlier batch's sampling loop and its own sampling with a
-    later batch's inversion: every step-group code path and the real exemplar counts meet the independent reference here."""
+@pytest.mark.parametrize("lanes", [None, 8])
+def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity, lanes):
+    """What bench.py times: asynchronous submission, co-batched pipeline, whole batches rotating over the batch lanes -- the
+    default four (DenoiserSession seq_duo, picked by the pipeline for launches of this width: 64 workgroups of rg_seq2_kernel,
+    two sequences of a kind each) and eight (seq_pairs + seq_duo: a workgroup runs two conditional sequences, then their
+    classifier-free twins).  Batch n shares a lane with batches n - L and n + L: of 2 L + 1 different batches batch L has its
+    exemplar inversion co-batched with an earlier batch's sampling loop and its own sampling with a later batch's inversion:
+    every step-group code path and the real exemplar counts meet the independent reference here."""
     dev = torch.device("cuda", 0)
     B, N_DB = 16, 32768
     cfg, vae_cfgs, database, model, P, cpu_db = _guided_setup(rg, dev, B, N_DB)
     model.async_results = True
+    assert model.batch_lanes == 4
+    if lanes is not None:
+        model.batch_lanes = lanes
     L = model.batch_lanes
-    assert L == 8
     ikw = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
     outs, keeps, tapes, exs = [], [], [], []
     for n in range(2 * L + 1):
@@ -165,8 +169,9 @@ def test_config3_as_benchmarked_submit_flush_vs_oracle(rg, parity):
         model.wait_results(r)
     torch.cuda.synchronize()
     paired = {k[:2]: (s.sq.args.pairs, int(s.sq.duo)) for k, s in model._sessions.items() if s.sq is not None}
-    assert [v for k, v in paired.items() if k[1] == "cobatch"] and all(v == (1, 1) for k, v in paired.items() if k[1] == "cobatch"), paired
-    # (16 clips + their exemplars in a launch, eight lanes: 32 workgroups of two clips each)
+    form = (1, 1) if L == 8 else (0, 1)
+    assert [v for k, v in paired.items() if k[1] == "cobatch"] and all(v == form for k, v in paired.items() if k[1] == "cobatch"), paired
+    # (16 clips + their exemplars in a launch: four lanes x 64 workgroups of two sequences, or eight x 32 of two clips each)
     assert any(k[0] == "cobatch" for k in model._graphs)
     assert len(exs[L]) >= B
     assert not torch.equal(outs[0]["prev_latentout"], outs[L]["prev_latentout"])

@@ -238,8 +238,8 @@ def test_slot_bookkeeping_is_per_lane(rg):
 def test_batch_lane_rules_results_in_submission_order_and_paired_launches(rg):
     """Two host-side rules of the four-lane pipeline.  (i) Wherever a pending batch has to finish on its own, everything
     submitted before it finishes first: a batch without inversion picks its lane among `base_lanes`, so the pending batch it meets
-    there need not be the oldest one (found on the GPU as results out of order, NOTEBOOK 9.8).  (ii) One workgroup per clip is
-    chosen exactly where the batch lanes' launches would not fit the compute units side by side."""
+    there need not be the oldest one (found on the GPU as results out of order, NOTEBOOK 9.8).  (ii) The narrower launch
+    forms are chosen exactly where the batch lanes' launches would not fit the compute units side by side."""
     import types
     MD = rg.pipeline.MotionDiffusion
     m = MD.__new__(MD)
@@ -247,23 +247,24 @@ def test_batch_lane_rules_results_in_submission_order_and_paired_launches(rg):
                2: types.SimpleNamespace(seq=6)}
     assert m._pending_upto(5) == [3, 0, 1]           # a base batch on lane 1 meets batch 5: 3 and 4 go first
     assert m._pending_upto(3) == [3] and m._pending_upto(2) == [] and m._pending_upto(99) == [3, 0, 1, 2]
-    m.async_results, m.batch_lanes, m._cob = True, 8, dict(lane=7)
-    assert m._seq_pairs_auto(64, cus=256) and m._seq_pairs_auto(48, cus=256)       # co-batched chains, 48-exemplar inversions
-    assert not m._seq_pairs_auto(16, cus=256) and m._seq_pairs_auto(32, cus=256)   # a draining batch's 16 clips: 2 x 16 x 8 = 256 fits
-    m.batch_lanes = 4
-    assert m._seq_pairs_auto(64, cus=256) and not m._seq_pairs_auto(32, cus=256)   # 2 x 32 x 4 = 256 fits
+    m.async_results, m.batch_lanes, m._cob = True, 4, dict(lane=3)
+    F = lambda B: m._seq_form_auto(B, cus=256)                 # -> (seq_pairs, seq_duo)
+    assert F(64) == (False, True)       # co-batched chains of the default four lanes: 64 workgroups of two sequences of a kind (rg_seq2)
+    assert F(48) == (False, True)       # 48-exemplar inversions of a filling pipeline: 48 workgroups
+    assert F(16) == (False, False) and F(32) == (False, False)      # a draining batch's clips: 2 x 32 x 4 = 256 fits, one workgroup per sequence
+    m.batch_lanes = 8
+    assert F(64) == (True, True)        # eight lanes: 32 workgroups, the classifier-free pair behind the conditional one
+    assert F(48) == (True, True) and F(32) == (False, True) and F(16) == (False, False)      # 2 x 16 x 8 = 256 fits
     m.batch_lanes = 2
-    assert not m._seq_pairs_auto(64, cus=256)        # two lanes of 128 workgroups fit
-    m.batch_lanes, m._cob = 8, dict(lane=7)
-    assert m._seq_form_auto(64, cus=256) == (True, True)       # co-batched chains of eight lanes: two clips per workgroup (rg_seq2)
-    assert m._seq_form_auto(16, cus=256) == (False, False)     # 2 x 16 x 8 = 256 fits: one workgroup per sequence
-    m._cur_rot = 3                                             # base batches rotate over base_lanes
-    assert m._seq_form_auto(32, cus=256) == (False, False)     # 2 x 32 x 3 = 192 fits
-    m._cur_rot = 2                                             # long-form window batches alternate between two lanes
-    assert m._seq_form_auto(96, cus=256) == (True, False)      # 96 exemplars: one workgroup per clip (192), not per two
+    assert F(64) == (False, False)      # two lanes of 128 workgroups fit
+    m.batch_lanes = 8
+    m._cur_rot = 3                      # base batches rotate over base_lanes
+    assert F(32) == (False, False)      # 2 x 32 x 3 = 192 fits
+    m._cur_rot = 2                      # long-form window batches alternate between two lanes
+    assert F(96) == (False, True)       # 96 exemplars: 96 workgroups of two sequences, not 48 of two clips
     m._cur_rot = None
     m.batch_lanes, m._cob = 4, None
-    assert not m._seq_pairs_auto(64, cus=256)        # synchronous forwards: never
+    assert F(64) == (False, False)      # synchronous forwards: always one workgroup per sequence
     m._cob, m.async_results = dict(lane=None), True
-    assert not m._seq_pairs_auto(64, cus=256)        # lanes split a batch (cobatch_lanes="split"): one workgroup per sequence
+    assert F(64) == (False, False)      # lanes split a batch (cobatch_lanes="split"): one workgroup per sequence
 
