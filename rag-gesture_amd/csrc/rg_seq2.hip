@@ -281,10 +281,9 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     cur_rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
   };
   auto issue = [&](int slot) {
-    #ifndef RG2_RING_AUX
-#define RG2_RING_AUX 0
-#endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_rsrc, (lds_void*)(ring + slot * 1024), 16, lane16, ir << 10, 0, RG2_RING_AUX);
+    // (aux 0: cached in L2.  Non-temporal loads cut the HBM-side traffic of a launch from x8.4 to x6.3 of the algorithmic bytes but
+    //  cost 11 % of its time: the four workgroups of an XCD share one fetch of the stream through its L2)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cur_rsrc, (lds_void*)(ring + slot * 1024), 16, lane16, ir << 10, 0, 0);
     if (__builtin_expect(++ir == cur_cnt, 0)) {
       ir = 0;
       ++ie;
