@@ -373,6 +373,12 @@ class Workload:
             # a workgroup owns a compute unit for the whole launch (155 KiB of LDS): the share of the chip a launch can use
             r["cu_share"] = round(min(1.0, r["workgroups_per_launch"] / cus), 4)
             r["frac_of_occupied_cus"] = round(ach / (peak * r["cu_share"]), 5) if r["cu_share"] else None
+            if duo_wide:
+                # half of the workgroups run classifier-free pairs and leave after 1 054 of the conditional pairs' 1 725 us
+                # (in-kernel stamps of the diagnostic build, profiles/r05b_seq2_stamps.txt -- NOT measured in this run): the CU
+                # time a launch really holds is (1 + 0.611) / 2 of workgroups x launch time
+                r["cu_time_held_share"] = round(r["cu_share"] * (1 + 1054.1 / 1725.5) / 2, 4)
+                r["frac_of_held_cu_time"] = round(ach / (peak * r["cu_time_held_share"]), 5)
             r["note"] = ("per launch; a launch occupies one CU per workgroup (%s), so %d concurrent lanes share the chip: `frac` prices "
                          "one lane's launch against the WHOLE chip's peak, `frac_of_occupied_cus` against the peak of the CUs it "
                          "holds; the chip-level rate is the sum over the lanes' concurrent launches (`whole_step`)"
@@ -554,6 +560,9 @@ def main():
     if world > 1 or os.environ.get("RG_BENCH_FORCE_DIST") == "1":   # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:      # (the switch without a launcher: a world of one)
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", str(local_rank)), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k_, v_)
         dist.init_process_group(backend="nccl", device_id=dev)
 
     Workload.database_index = lambda self: self.model.model.database.index
@@ -660,6 +669,8 @@ def main():
                     roofline["mfma_utilisation_pmc"] = round(pm["mfma_utilisation"], 4)      # (of the whole chip's MFMA cycles, one launch alone)
                     if roofline.get("cu_share"):
                         roofline["mfma_utilisation_pmc_of_occupied_cus"] = round(pm["mfma_utilisation"] / roofline["cu_share"], 4)
+                    if roofline.get("cu_time_held_share"):
+                        roofline["mfma_utilisation_pmc_of_held_cu_time"] = round(pm["mfma_utilisation"] / roofline["cu_time_held_share"], 4)
                 else:
                     with open(os.path.join(ROOT, "profiles", "r02m_pmc_gemm_traffic.json")) as f:
                         rows = json.load(f)
