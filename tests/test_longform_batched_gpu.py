@@ -45,15 +45,17 @@ def test_run_many_equals_per_clip_runs(rg, precision):
         assert np.abs(one["poses"] - many[ci]["poses"]).max() <= 1e-4
 
 
-@pytest.mark.parametrize("guided,batch_lanes", [(True, 2), (True, 4), (False, 4)])
-def test_pipelined_windows_equal_the_sequential_loop(rg, guided, batch_lanes, tmp_path):
+@pytest.mark.parametrize("guided,batch_lanes,n_windows", [(True, 2, (5, 2, 5, 5)), (True, 4, (5, 2, 5, 5)), (False, 4, (5, 2, 5, 5)),
+                                                          (True, 4, (4, 2, 1, 1)), (True, 2, (4, 2, 1, 1))])
+def test_pipelined_windows_equal_the_sequential_loop(rg, guided, batch_lanes, n_windows, tmp_path):
     """run_many(pipelined=True): the windows go through submit() / flush() with the previous window's latent still pending
     (pipeline.PendingLatent) -- retrieval + exemplar inversion of window k + 1 beside the sampling loop of window k.  Same
     noise tape, clips of different lengths (the batch shrinks: the pending latent is row-selected), BASELINE config 5's
     flags (llm retrieval on cached answers, inversion + insertion guidance + prev-latent): every latent and every output
     must equal the sequential loop's, bit for bit.  Window batches rotate over `batch_lanes` lanes: with two, window k + 2 shares
     its launches with window k (co-batched chains); with four (the default) the inversions of the next windows run as chains
-    of their own on the other lanes."""
+    of their own on the other lanes.  Window counts (4, 2, 1, 1): batches of 4, 2, 1, 1 clips -- several batches of fewer clips
+    than lanes in a row (the lane of a batch must not depend on its size: ADVICE round 4)."""
     dev = torch.device("cuda", 0)
     cfg = rg.synth.default_model_cfg(num_layers=2)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder", num_layers=2)
@@ -64,7 +66,7 @@ def test_pipelined_windows_equal_the_sequential_loop(rg, guided, batch_lanes, tm
     model.eval()
     cache = rg.retrieval.LLMResponseCache(str(tmp_path / "llm_cache.json"), call=rg.synth.synth_llm_answer)
     model.model.database.llm_output = cache.get
-    n_windows = [5, 2, 5, 5]          # windows 0-1: 4 clips, 2-4: 3 clips (window 4 shares its launches with window 2)
+    n_windows = list(n_windows)       # (5, 2, 5, 5): windows 0-1: 4 clips, 2-4: 3 clips (window 4 shares its launches with window 2)
     clips = [rg.synth.synth_longform_clip(40 + 100 * ci, windows=w, device=dev) for ci, w in enumerate(n_windows)]
     feats = {(ci, w): rg.synth.synth_query(300 + 10 * ci + w)["text_features"].to(dev) for ci, n in enumerate(n_windows) for w in range(n)}
     audio = {(ci, w): rg.synth.synth_batch(1, seed=1000 + 10 * ci + w, device=dev)["audio"] for ci, n in enumerate(n_windows) for w in range(n)}
@@ -81,7 +83,7 @@ def test_pipelined_windows_equal_the_sequential_loop(rg, guided, batch_lanes, tm
     model.async_results = True
     pip = synth.run_many([copy(c) for c in clips], features, noise_tape=rg.synth.NoiseTape(71), retrieval_method="llm", **flags)
     torch.cuda.synchronize()
-    if guided and batch_lanes == 2:
+    if guided and batch_lanes == 2 and max(n_windows) > 4:
         assert any(k[0] == "cobatch" for k in model._graphs), "the pipelined run should have gone through co-batched chains"
     assert not model._pend and not model._ready
     for ci in range(len(clips)):
