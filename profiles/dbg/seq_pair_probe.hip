@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -43,7 +44,14 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
       if (++iu == stream_units) { iu = 0; soff = wave * (FPU * 1024); }
     }
   };
-  if constexpr (PF != 2) {
+  auto dma_frag = [&](int slot, int unit, int f) {     // (PF == 3) fragment f of a unit by LDS-DMA into a ring slot
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)(ring + slot * 1024), 16, lane * 16,
+                                             (((unit % stream_units) * NW + wave) * FPU + f) * 1024, 0, 0);
+  };
+  if constexpr (PF == 3) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) dma_frag(s, 0, s);
+  } else if constexpr (PF != 2) {
 #pragma unroll
     for (int s = 0; s < RD; ++s) issue(s);
   }
@@ -159,6 +167,45 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
         }
       }
     }
+    if constexpr (PF == 3) {     // hybrid: a unit's first six fragments through the LDS ring (issued before the unit starts: by the
+      // previous unit's last six iterations -- in the kernel, across its epilogue), the other 58 straight into registers; one
+      // in-order pipeline of six fragments in flight, the destination depends on the fragment's position only.  The first and
+      // the last pair of k-steps are peeled so that no group has a branch (the compiler's own vmcnt placement stays exact).
+      static_assert(NJ == 4 && RD == 6, "hybrid ring");
+      bf16x8 pf[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16) << 10));
+      wait_vmcnt<5>();
+      wr[0] = *reinterpret_cast<const u32x4*>(rl);
+      auto group = [&](const int s2, auto first_tag, auto last_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          const int j = f & 3;
+          if (FIRST && f + 1 < 6) {      // the next fragment comes through LDS: it has landed when at most 4 younger loads are out
+            wait_vmcnt<4>();
+            wr[f + 1] = *reinterpret_cast<const u32x4*>(rl + (f + 1) * 1024);
+          }
+          const bf16x8 wv = __builtin_bit_cast(bf16x8, wr[f]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            acc[j][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, pf[b], acc[j][b], 0, 0, 0);
+            if (j == NJ - 1) {
+              pf[b] = *reinterpret_cast<const bf16x8*>(pl + ((b * 16 + s2 + (f >> 2) + 1) << 10));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          if (LAST && f >= 2) dma_frag(f - 2, u + 1, f - 2);      // fragments 0-5 of the next unit: LDS (slot last read by this unit's fragment f - 2)
+          else wr[(f + 6) & 7] = *frag_ptr(u, s2 * 4 + f + 6);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      group(0, std::true_type(), std::false_type());
+#pragma unroll 1
+      for (int s2 = 2; s2 < 14; s2 += 2) group(s2, std::false_type(), std::false_type());
+      group(14, std::false_type(), std::true_type());
+    }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     tg += __builtin_amdgcn_s_memrealtime() - tu0;
     if (BAR) {
@@ -243,6 +290,7 @@ int main() {
     run<2, 4, 6, 0, 1, 1, 2>(stream, stream_units, R, grid, out, clk);    // ... on every other k-step
     run<2, 4, 6, 0, 1, 1, 3>(stream, stream_units, R, grid, out, clk);    // ... on every other pair of k-steps
     run<2, 4, 6, 0, 1, 1, 4>(stream, stream_units, R, grid, out, clk);    // ... four
+    run<2, 4, 6, 0, 3, 1>(stream, stream_units, R, grid, out, clk);       // hybrid: six fragments per unit through LDS, 58 into registers
     run<2, 4, 6, 0, 2, 1>(stream, stream_units, R, grid, out, clk);       // register ring
     run<2, 4, 6, 0, 2, 1, 1>(stream, stream_units, R, grid, out, clk);
     run<2, 4, 6, 0, 2, 1, 2>(stream, stream_units, R, grid, out, clk);

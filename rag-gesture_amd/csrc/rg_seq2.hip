@@ -392,11 +392,93 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     TSTOP(0);
     TLOG();
   };
+  // ---- the same unit GEMM with the weight stream's fragments 6 ... of the unit loaded STRAIGHT INTO REGISTERS (eight of them in
+  // rotation, six fragments in flight as before): only the unit's first six fragments -- issued before the unit starts, across
+  // its epilogue, when the registers are busy -- come through the LDS ring; the last six iterations refill the ring's slots for
+  // whatever the stream holds next (parameter fragment, next unit).  One in-order pipeline, the destination depends on the
+  // fragment's position only; `head` leaves as it came.  Why: the LDS array carries 2 x 512 KiB less per unit and CU (DMA writes
+  // + weight reads), and the weight operand no longer waits for an LDS read (profiles/dbg/seq_pair_probe.hip PF = 3: 5.7 against
+  // 7.3 us per unit on 64 CUs, 7.3 against 9.0 with the chip full).  32 more VGPRs: for the call sites that have them.
+  auto issue_reg = [&](u32x4& dst) {
+    dst = __builtin_amdgcn_raw_buffer_load_b128(cur_rsrc, lane16, ir << 10, 0);
+    if (__builtin_expect(++ir == cur_cnt, 0)) {
+      ir = 0;
+      ++ie;
+      load_seg();
+    }
+  };
+  auto gemm_frags_reg = [&](auto& acc, auto nj_tag, auto std_tag) {
+    constexpr int NJ = decltype(nj_tag)::value;
+    constexpr bool STD = decltype(std_tag)::value;
+    constexpr int NF = 16 * NJ;                    // fragments of the unit (64 or 32)
+    static_assert(NF % 8 == 0 && 8 % NJ == 0 && RD == 6, "groups of eight fragments, six in flight");
+    LANE_LOCAL();
+    TSTART();
+    const unsigned char* pl = smem + lane * 16;
+    const unsigned char* rl = ring + lane * 16;
+    bf16x8 pf[6];
+    u32x4 wr[8];
+    int hs = head;                                  // ring slot of the next LDS-resident fragment (first group) / to refill (last group)
+    ring_wait();
+    wr[0] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
+    hs = hs + 1 == RD ? 0 : hs + 1;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pl + (b / 3) * PANEL + (((b % 3) * 16) << 10));
+    auto group = [&](const int s0, auto first_tag, auto last_tag) {      // fragments [NJ s0, NJ s0 + 8)
+      constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        constexpr int dummy = 0; (void)dummy;
+        const int j = f % NJ, s = s0 + f / NJ;
+        if (FIRST && f + 1 < 6) {      // the next fragment sits in the ring: landed when at most 4 younger loads are outstanding
+          wait_vmcnt<4>();
+          wr[f + 1] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
+          hs = hs + 1 == RD ? 0 : hs + 1;
+        }
+        const bf16x8 wv = __builtin_bit_cast(bf16x8, wr[f]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          f32x4& c = acc[b / 3][j][b % 3];
+          c = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b], wv, c, 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, pf[b], c, 0, 0, 0);
+          if (j == NJ - 1) {
+            pf[b] = *reinterpret_cast<const bf16x8*>(pl + (b / 3) * PANEL + (((b % 3) * 16 + s + 1) << 10));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (LAST && f >= 2) {          // the stream's next six items go to the ring (slots in the order they were read from)
+          issue(hs);
+          hs = hs + 1 == RD ? 0 : hs + 1;
+        } else {
+          issue_reg(wr[(f + 6) & 7]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    group(0, std::true_type(), std::false_type());
+#pragma unroll 1
+    for (int s0 = 8 / NJ; s0 < 16 - 8 / NJ; s0 += 8 / NJ) group(s0, std::false_type(), std::false_type());
+    group(16 - 8 / NJ, std::false_type(), std::true_type());
+    TSTOP(0);
+    TLOG();
+  };
   auto drained = [&]() {        // every vector-memory operation of the wave has completed (see wait_vm_all)
     wait_vm_all();
   };
-  auto gemm_unit = [&](Acc2& acc) { gemm_frags(acc, std::integral_constant<int, 4>(), std::false_type()); };
-  auto gemm_head_std = [&](f32x4 (&acc)[2][2][3]) { gemm_frags(acc, std::integral_constant<int, 2>(), std::true_type()); };
+  // call sites of the unit GEMM (SITE<n>): bit n of RG2_REG_SITES = the site's weights go straight into registers (gemm_frags_reg)
+#ifndef RG2_REG_SITES
+#define RG2_REG_SITES 0xE7B
+#endif
+#define SITE(n) std::integral_constant<int, n>()
+  auto gemm_unit = [&](Acc2& acc, auto site) {
+    if constexpr (((RG2_REG_SITES) >> decltype(site)::value) & 1) gemm_frags_reg(acc, std::integral_constant<int, 4>(), std::false_type());
+    else gemm_frags(acc, std::integral_constant<int, 4>(), std::false_type());
+  };
+  auto gemm_head_std = [&](f32x4 (&acc)[2][2][3]) {
+    if constexpr (((RG2_REG_SITES) >> 1) & 1) gemm_frags_reg(acc, std::integral_constant<int, 2>(), std::true_type());
+    else gemm_frags(acc, std::integral_constant<int, 2>(), std::true_type());
+  };
 
   // parameter fragment [4][64] fp32 at the head of every unit: vector p for this wave's 64 features
   auto par_t = [&](const unsigned char* slot, int p, int j, int g4) -> f32x4 {   // T layout: features 16 j + 4 g4 + r
@@ -414,14 +496,14 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     }
   };
   // plain unit: acc += bias, then acc += W x panel
-  auto unit = [&](Acc2& acc) {
+  auto unit = [&](Acc2& acc, auto site) {
     const unsigned char* ps = consume();
     add_bias_t(acc, ps);
     release();
-    gemm_unit(acc);
+    gemm_unit(acc, site);
   };
   // ... acc = bias + W x panel (no zero-fill + add: 192 VALU instructions per unit)
-  auto unit_init = [&](Acc2& acc) {
+  auto unit_init = [&](Acc2& acc, auto site) {
     {
       LANE_LOCAL();
       const unsigned char* ps = consume();
@@ -435,13 +517,13 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       }
       release();
     }
-    gemm_unit(acc);
+    gemm_unit(acc, site);
   };
   // ... acc += W x panel; the unit's parameter fragment (a zero bias: the second half of FFN linear2) is only taken off the ring
-  auto unit_more = [&](Acc2& acc) {
+  auto unit_more = [&](Acc2& acc, auto site) {
     (void)consume();
     release();
-    gemm_unit(acc);
+    gemm_unit(acc, site);
   };
 
   // ---- LayerNorm statistics of the three tokens a lane holds, both sequences: per-wave (sum, M2 about the wave's own mean)
@@ -604,7 +686,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     }
   };
   // output projection of a block: acc = the residual stream (back from xbuf) + bias + W x stylize(y)
-  auto styl_unit = [&](Acc2& acc, const Acc2& y) {
+  auto styl_unit = [&](Acc2& acc, const Acc2& y, auto site) {
     float m3[2][3], r3[2][3];
     row_stats(y, m3, r3);            // (its barrier: every wave is done with the panels' previous content)
     load_R(acc);                     // the residual stream, landing while y is stylized
@@ -617,7 +699,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       TSTOP(3);
     }
     barx();
-    gemm_unit(acc);
+    gemm_unit(acc, site);
   };
   // softmax over the 32 features of each of the wave's two heads, T layout (features: 8 in the lane x 4 lane groups)
   auto softmax_q = [&](Acc& q) {
@@ -667,7 +749,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   };
 
   // =========================================================== embedding: x = joint_embed(x_in) + tables
-  unit(X);
+  unit(X, SITE(0));
   if (a.dump_stage == 1) dump(X);
 
 #pragma unroll 1
@@ -773,7 +855,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         }
       }
       Acc2 yy;                                        // queries, then (in place) the attention output
-      unit_init(yy);
+      unit_init(yy, SITE(2));
       {
         TSTART();
 #pragma unroll
@@ -785,7 +867,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         TSTOP(4);
       }
       if (dl && a.dump_stage == 10) dump(yy);
-      styl_unit(X, yy);                               // x += proj_out(...)  (stylization_block.py:40, efficient_attention.py:44)
+      styl_unit(X, yy, SITE(3));                               // x += proj_out(...)  (stylization_block.py:40, efficient_attention.py:44)
     }
     if (dl && a.dump_stage == 2) dump(X);
 
@@ -810,7 +892,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         }
         release();
       }
-      gemm_unit(X);
+      gemm_unit(X, SITE(4));
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -853,7 +935,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       // softmax, y = q A_clip, masked rows, LayerNorm + stylization with the parameters of MIX_c
       auto cross = [&](const int c) {
         Acc2 yy;
-        unit_init(yy);
+        unit_init(yy, SITE(5));
         LANE_LOCAL();
         unsigned qbits[2] = {qbits0[0], qbits0[1]};
         asm volatile("" : "+v"(qbits[0]), "+v"(qbits[1]));
@@ -909,7 +991,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       restore_issue(t, 1);
       restore_finish(t);
       barx();
-      gemm_unit(X);                             // += W_text h_text
+      gemm_unit(X, SITE(6));                    // += W_text h_text
       barx();                                   // every wave is done reading h_text
       restore_issue(t, 0);                      // xhat again, landing while the accumulator goes out
       store_R(X);
@@ -923,12 +1005,12 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       restore_finish(t);
       drained();
       barx();
-      gemm_unit(X);                             // += W_audio h_audio
+      gemm_unit(X, SITE(6));                    // += W_audio h_audio
       barx();
       restore_issue(t, 3);
       restore_finish(t);
       barx();
-      gemm_unit(X);                             // += W_spk h_spk
+      gemm_unit(X, SITE(6));                    // += W_spk h_spk
     }
     if (dl && a.dump_stage == 3) dump(X);
 
@@ -941,12 +1023,10 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       Acc2 yf;
       {
         Held g0, g1;
-#pragma unroll
-        for (int jh = 0; jh < 2; ++jh) {
+        auto ff1 = [&](Held& gd, auto site) {      // one half of linear1 + GELU, kept as packed bf16
           Acc2 gg;
-          unit_init(gg);
+          unit_init(gg, site);
           TSTART();
-          Held& gd = jh == 0 ? g0 : g1;
 #pragma unroll
           for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -956,17 +1036,19 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
                 gd[q][j][tb] = u32x2{pack2(gelu_fast(gg[q][j][tb][0]), gelu_fast(gg[q][j][tb][1])),
                                      pack2(gelu_fast(gg[q][j][tb][2]), gelu_fast(gg[q][j][tb][3]))};
           TSTOP(3);
-        }
+        };
+        ff1(g0, SITE(11));                      // (nothing held yet: the register form of the unit fits)
+        ff1(g1, SITE(7));
         barx();                                 // every wave is done reading x
         store_held(g0);
         barx();
-        unit_init(yf);                          // (the bias of linear2 rides with the first half)
+        unit_init(yf, SITE(8));                          // (the bias of linear2 rides with the first half)
         barx();
         store_held(g1);
         barx();
-        unit_more(yf);
+        unit_more(yf, SITE(9));
       }
-      styl_unit(X, yf);
+      styl_unit(X, yf, SITE(3));
     }
     if (dl && a.dump_stage == 4) dump(X);
   }
@@ -977,7 +1059,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   write_raw(X);
   barx();
   Acc2 out;
-  unit_init(out);
+  unit_init(out, SITE(10));
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     if (q == 1 && sB == sA) break;
