@@ -376,12 +376,81 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     }
     TSTOP(0);
   };
+  // ---- the same unit GEMM with the weight stream's fragments RD ... of the unit loaded STRAIGHT INTO REGISTERS (eight in
+  // rotation, RD fragments in flight as before): only the unit's first RD fragments -- issued before the unit starts, across
+  // its epilogue -- come through the LDS ring; the last RD iterations refill the ring's slots for whatever the stream holds
+  // next.  One in-order pipeline, the destination depends on the fragment's position only; `head` leaves as it came (rg_seq2.hip).
+  auto issue_reg = [&](u32x4& dst) {
+    dst = __builtin_amdgcn_raw_buffer_load_b128(cur_rsrc, lane16, ir << 10, 0);
+    if (++ir == cur_cnt) {
+      ir = 0;
+      ++ie;
+      load_seg();
+    }
+  };
+  auto gemm_frags_reg = [&](auto& acc, const unsigned char* panel, auto nj_tag, auto std_tag) {
+    constexpr int NJ = decltype(nj_tag)::value;
+    constexpr bool STD = decltype(std_tag)::value;
+    static_assert((16 * NJ) % 8 == 0 && 8 % NJ == 0 && RD <= 8 && RD >= 2, "groups of eight fragments, RD in flight");
+    LANE_LOCAL();
+    TSTART();
+    const unsigned char* pl = panel + lane * 16;
+    const unsigned char* rl = ring + lane * 16;
+    bf16x8 pf[3];
+    u32x4 wr[8];
+    int hs = head;
+    wait_vmcnt<RD - 1>();
+    wr[0] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
+    hs = hs + 1 == RD ? 0 : hs + 1;
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) pf[tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16) << 10));
+    auto group = [&](const int s0, auto first_tag, auto last_tag) {      // fragments [NJ s0, NJ s0 + 8)
+      constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int j = f % NJ, s = s0 + f / NJ;
+        if (FIRST && f + 1 < RD) {      // the next fragment sits in the ring: landed when at most RD - 2 younger loads are outstanding
+          wait_vmcnt<RD - 2>();
+          wr[f + 1] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
+          hs = hs + 1 == RD ? 0 : hs + 1;
+        }
+        const bf16x8 wv = __builtin_bit_cast(bf16x8, wr[f]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb) {
+          acc[j][tb] = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[tb], wv, acc[j][tb], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, pf[tb], acc[j][tb], 0, 0, 0);
+          if (j == NJ - 1) {           // re-read for the next k-step right behind its last use (behind the panel's end: valid LDS, unused)
+            pf[tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16 + s + 1) << 10));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (LAST && f >= 8 - RD) {     // the stream's next RD items go to the ring (slots in the order they were read from)
+          issue(hs);
+          hs = hs + 1 == RD ? 0 : hs + 1;
+        } else {
+          issue_reg(wr[(f + RD) & 7]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    group(0, std::true_type(), std::false_type());
+#pragma unroll 1
+    for (int s0 = 8 / NJ; s0 < 16 - 8 / NJ; s0 += 8 / NJ) group(s0, std::false_type(), std::false_type());
+    group(16 - 8 / NJ, std::false_type(), std::true_type());
+    TSTOP(0);
+  };
+#ifndef RG1_REG
+#define RG1_REG 3
+#endif
   auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
-    gemm_frags(acc, panel, std::integral_constant<int, 4>(), std_tag);
+    if constexpr ((RG1_REG) & 1) gemm_frags_reg(acc, panel, std::integral_constant<int, 4>(), std_tag);
+    else gemm_frags(acc, panel, std::integral_constant<int, 4>(), std_tag);
   };
   // half unit, standard layout: the 32 features of ONE head (32 fragments: per step the head's two 16-feature blocks)
   auto gemm_head_std = [&](f32x4 (&acc)[2][3], const unsigned char* panel) {
-    gemm_frags(acc, panel, std::integral_constant<int, 2>(), std::true_type());
+    if constexpr ((RG1_REG) & 2) gemm_frags_reg(acc, panel, std::integral_constant<int, 2>(), std::true_type());
+    else gemm_frags(acc, panel, std::integral_constant<int, 2>(), std::true_type());
   };
   std::false_type TL;
 
