@@ -230,7 +230,74 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
 #pragma unroll
   for (int s = 0; s < RD; ++s) issue(s);
 
-  auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
+  // unit GEMM (see rg_seq.hip: gemm_frags_reg): the unit's first RD fragments -- issued before the unit starts, across its
+  // epilogue -- come through the LDS ring, the other 64 - RD straight into registers (eight in rotation, RD in flight as before);
+  // the last RD iterations refill the ring's slots for whatever the stream holds next.  `head` leaves as it came.
+  auto issue_reg = [&](u32x4& dst) {
+    dst = __builtin_amdgcn_raw_buffer_load_b128(cur_rsrc, lane16, ir << 10, 0);
+    if (++ir == cur_cnt) {
+      ir = 0;
+      ++ie;
+      load_seg();
+    }
+  };
+#ifndef RGD_REG
+#define RGD_REG 0x7
+#endif
+#define SITE(n) std::integral_constant<int, n>()
+  auto gemm_unit_reg = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
+    constexpr bool STD = decltype(std_tag)::value;
+    constexpr int NJ = 4;
+    static_assert(RD <= 8 && RD >= 2, "RD fragments in flight, eight registers in rotation");
+    LANE_LOCAL();
+    const unsigned char* pl = panel + lane * 16;
+    const unsigned char* rl = ring + lane * 16;
+    bf16x8 pf[3];
+    u32x4 wr[8];
+    int hs = head;
+    wait_vmcnt<RD - 1>();
+    wr[0] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
+    hs = hs + 1 == RD ? 0 : hs + 1;
+#pragma unroll
+    for (int tb = 0; tb < 3; ++tb) pf[tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16) << 10));
+    auto group = [&](const int s0, auto first_tag, auto last_tag) {      // fragments [4 s0, 4 s0 + 8)
+      constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const int j = f % NJ, s = s0 + f / NJ;
+        if (FIRST && f + 1 < RD) {      // the next fragment sits in the ring: landed when at most RD - 2 younger loads are outstanding
+          wait_vmcnt<RD - 2>();
+          wr[f + 1] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
+          hs = hs + 1 == RD ? 0 : hs + 1;
+        }
+        const bf16x8 wv = __builtin_bit_cast(bf16x8, wr[f]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tb = 0; tb < 3; ++tb) {
+          acc[j][tb] = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[tb], wv, acc[j][tb], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, pf[tb], acc[j][tb], 0, 0, 0);
+          if (j == NJ - 1) {           // re-read for the next k-step right behind its last use (behind the panel's end: valid LDS, unused)
+            pf[tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16 + s + 1) << 10));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (LAST && f >= 8 - RD) {
+          issue(hs);
+          hs = hs + 1 == RD ? 0 : hs + 1;
+        } else {
+          issue_reg(wr[(f + RD) & 7]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    group(0, std::true_type(), std::false_type());
+#pragma unroll 1
+    for (int s0 = 2; s0 < 14; s0 += 2) group(s0, std::false_type(), std::false_type());
+    group(14, std::false_type(), std::true_type());
+  };
+  // (site: bit n of RGD_REG = this call site has the 32 VGPRs for the register form)
+  auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag, auto site) {
+    if constexpr (((RGD_REG) >> decltype(site)::value) & 1) { gemm_unit_reg(acc, panel, std_tag); return; }
     constexpr bool STD = decltype(std_tag)::value;
     constexpr int NJ = 4;
     LANE_LOCAL();
@@ -287,7 +354,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     const unsigned char* ps = consume();
     add_bias_t(acc, ps);
     release();
-    gemm_unit(acc, panel, TL);
+    gemm_unit(acc, panel, TL, SITE(0));
   };
   auto row_stats = [&](const Acc& v, float (&mean)[3], float (&rstd)[3]) {
     LANE_LOCAL();
@@ -432,7 +499,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
       }
       add_bias_t(xr, ps);
       release();
-      gemm_unit(xr, P1, TL);
+      gemm_unit(xr, P1, TL, SITE(1));
       float mean[3], rstd[3];
       row_stats(xr, mean, rstd);
       LANE_LOCAL();
@@ -472,7 +539,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
         }
         add_bias_t(xr, ps);
         release();
-        gemm_unit(xr, P1, TL);
+        gemm_unit(xr, P1, TL, SITE(2));
       }
       float mean[3], rstd[3];
       row_stats(xr, mean, rstd);
@@ -578,7 +645,7 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     }
     release();
   }
-  gemm_unit(vv, P0, STDL);
+  gemm_unit(vv, P0, STDL, SITE(3));
   VSTAMP(7);
   {
     LANE_LOCAL();
