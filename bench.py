@@ -374,10 +374,10 @@ class Workload:
             r["cu_share"] = round(min(1.0, r["workgroups_per_launch"] / cus), 4)
             r["frac_of_occupied_cus"] = round(ach / (peak * r["cu_share"]), 5) if r["cu_share"] else None
             if duo_wide:
-                # half of the workgroups run classifier-free pairs and leave after 1 054 of the conditional pairs' 1 725 us
-                # (in-kernel stamps of the diagnostic build, profiles/r05b_seq2_stamps.txt -- NOT measured in this run): the CU
+                # half of the workgroups run classifier-free pairs and leave after 1 003 of the conditional pairs' 1 641 us
+                # (in-kernel stamps of the diagnostic build, profiles/r05B_seq2_stamps.txt -- NOT measured in this run): the CU
                 # time a launch really holds is (1 + 0.611) / 2 of workgroups x launch time
-                r["cu_time_held_share"] = round(r["cu_share"] * (1 + 1054.1 / 1725.5) / 2, 4)
+                r["cu_time_held_share"] = round(r["cu_share"] * (1 + 1002.5 / 1641.4) / 2, 4)
                 r["frac_of_held_cu_time"] = round(ach / (peak * r["cu_time_held_share"]), 5)
             r["note"] = ("per launch; a launch occupies one CU per workgroup (%s), so %d concurrent lanes share the chip: `frac` prices "
                          "one lane's launch against the WHOLE chip's peak, `frac_of_occupied_cus` against the peak of the CUs it "
@@ -656,9 +656,11 @@ def main():
                 if roofline.get("workgroups_per_launch") is not None:
                     # (r04_pmc_seq: 128 workgroups, one per sequence; r04s_pmc_seq_pairs: 64 workgroups, one per clip -- the twin's
                     #  pass streams the shared weights through every L2 a second time)
-                    # (r05k_pmc_seq2_pairs: 32 workgroups, two clips each -- rg_seq2_kernel with eight batch lanes;
-                    #  r05w_pmc_seq2_wide: 64 workgroups, two sequences of a kind each -- what the default four lanes launch)
-                    src = {"duo_pairs": "r05k_pmc_seq2_pairs.json", "duo": "r05w_pmc_seq2_wide.json", "pairs": "r04s_pmc_seq_pairs.json"}.get(roofline.get("launch_form"), "r04_pmc_seq.json")
+                    # (r05B_pmc_seq2_pairs: 32 workgroups, two clips each -- rg_seq2_kernel with eight batch lanes;
+                    #  r05B_pmc_seq2_wide: 64 workgroups, two sequences of a kind each -- what the default four lanes launch;
+                    #  both of the build with the register path for the weight fragments.  The one-sequence forms' files are
+                    #  round-4 passes of rg_seq_kernel BEFORE it got that path: only their traffic figures still apply)
+                    src = {"duo_pairs": "r05B_pmc_seq2_pairs.json", "duo": "r05B_pmc_seq2_wide.json", "pairs": "r04s_pmc_seq_pairs.json"}.get(roofline.get("launch_form"), "r04_pmc_seq.json")
                     with open(os.path.join(ROOT, "profiles", src)) as f:
                         pm = json.load(f)
                     # these three are NOT measured in this run: they are read from the committed rocprofv3 --pmc passes over the
