@@ -428,7 +428,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        constexpr int dummy = 0; (void)dummy;
         const int j = f % NJ, s = s0 + f / NJ;
         if (FIRST && f + 1 < 6) {      // the next fragment sits in the ring: landed when at most 4 younger loads are outstanding
           wait_vmcnt<4>();
