@@ -327,59 +327,13 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
   for (int s = 0; s < RD; ++s) issue(s);
 
 
-  // ---- unit GEMM: acc += W_unit x panel over K = 512 (16 steps of 32); NJ weight fragments per step from the ring
-  // (NJ = 4: the wave's 64 features, NJ = 2: the 32 features of one head).  STD = false: T layout (A = weights); true:
-  // standard layout (A = panel).  Per fragment f: [its LDS read has landed -> refill its ring slot] [fragment f + 1 has
-  // landed in LDS -> issue its LDS read] [MFMAs of f]: the LDS latency of the next fragment hides behind these MFMAs and
-  // every ring slot is in flight again as soon as its bytes are in registers.  Two steps per loop iteration with static
-  // register names (no rotation copies: a copy of a register with a pending LDS read makes the compiler wait for it at
-  // once); the panel fragments of step s + 1 are read during the last fragment of step s.
-  auto gemm_frags = [&](auto& acc, const unsigned char* panel, auto nj_tag, auto std_tag) {
-    constexpr int NJ = decltype(nj_tag)::value;
-    constexpr bool STD = decltype(std_tag)::value;
-    static_assert(NJ % 2 == 0, "fragments per step alternate between two registers");
-    LANE_LOCAL();
-    TSTART();
-    const unsigned char* pl = panel + lane * 16;
-    const unsigned char* rl = ring + lane * 16;
-    bf16x8 w[2], pf[2][3];
-    wait_vmcnt<RD - 1>();
-    w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
-#pragma unroll
-    for (int tb = 0; tb < 3; ++tb) pf[0][tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16) << 10));
-#pragma unroll 1
-    for (int s2 = 0; s2 < 16; s2 += 2) {
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const bool last = ss == 1 && j == NJ - 1 && s2 == 14;   // the unit's last fragment
-          wait_lds();                                             // w[j & 1] (and pf[ss]) are in registers
-          issue(head);                                            // refill the slot they came from
-          head = head + 1 == RD ? 0 : head + 1;
-          if (!last) {
-            wait_vmcnt<RD - 1>();
-            w[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
-          }
-          if (j == NJ - 1 && !last) {
-#pragma unroll
-            for (int tb = 0; tb < 3; ++tb) pf[ss ^ 1][tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16 + s2 + ss + 1) << 10));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int tb = 0; tb < 3; ++tb)
-            acc[j][tb] = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ss][tb], w[j & 1], acc[j][tb], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[ss][tb], acc[j][tb], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-    TSTOP(0);
-  };
-  // ---- the same unit GEMM with the weight stream's fragments RD ... of the unit loaded STRAIGHT INTO REGISTERS (eight in
-  // rotation, RD fragments in flight as before): only the unit's first RD fragments -- issued before the unit starts, across
+  // ---- unit GEMM: acc += W_unit x panel over K = 512 (16 steps of 32); NJ weight fragments per step (NJ = 4: the wave's 64
+  // features, NJ = 2: the 32 features of one head).  STD = false: T layout (A = weights); true: standard layout (A = panel).
+  // The weight stream's fragments RD ... of the unit are loaded STRAIGHT INTO REGISTERS (eight in
+  // rotation, RD fragments in flight): only the unit's first RD fragments -- issued before the unit starts, across
   // its epilogue -- come through the LDS ring; the last RD iterations refill the ring's slots for whatever the stream holds
   // next.  One in-order pipeline, the destination depends on the fragment's position only; `head` leaves as it came (rg_seq2.hip).
+  // (Until late in round 5 every fragment went through the ring: 1 030 instead of 901 us per forward, same bits.)
   auto issue_reg = [&](u32x4& dst) {
     dst = __builtin_amdgcn_raw_buffer_load_b128(cur_rsrc, lane16, ir << 10, 0);
     if (++ir == cur_cnt) {
@@ -440,17 +394,12 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     group(16 - 8 / NJ, std::false_type(), std::true_type());
     TSTOP(0);
   };
-#ifndef RG1_REG
-#define RG1_REG 3
-#endif
   auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
-    if constexpr ((RG1_REG) & 1) gemm_frags_reg(acc, panel, std::integral_constant<int, 4>(), std_tag);
-    else gemm_frags(acc, panel, std::integral_constant<int, 4>(), std_tag);
+    gemm_frags_reg(acc, panel, std::integral_constant<int, 4>(), std_tag);
   };
   // half unit, standard layout: the 32 features of ONE head (32 fragments: per step the head's two 16-feature blocks)
   auto gemm_head_std = [&](f32x4 (&acc)[2][3], const unsigned char* panel) {
-    if constexpr ((RG1_REG) & 2) gemm_frags_reg(acc, panel, std::integral_constant<int, 2>(), std::true_type());
-    else gemm_frags(acc, panel, std::integral_constant<int, 2>(), std::true_type());
+    gemm_frags_reg(acc, panel, std::integral_constant<int, 2>(), std::true_type());
   };
   std::false_type TL;
 

@@ -254,10 +254,7 @@ __global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_group grp) {
       load_seg();
     }
   };
-#ifndef RGV_REG
-#define RGV_REG 1
-#endif
-  auto gemm_unit_reg = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
+  auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
     constexpr bool STD = decltype(std_tag)::value;
     constexpr int NJ = 4;
     static_assert(RD <= 8 && RD >= 2, "RD fragments in flight, eight registers in rotation");
@@ -306,46 +303,6 @@ __global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_group grp) {
 #pragma unroll 1
     for (int s0 = 2; s0 < 14; s0 += 2) group(s0, std::false_type(), std::false_type());
     group(14, std::false_type(), std::true_type());
-  };
-  auto gemm_unit = [&](Acc& acc, const unsigned char* panel, auto std_tag) {
-    if constexpr (RGV_REG) { gemm_unit_reg(acc, panel, std_tag); return; }
-    constexpr bool STD = decltype(std_tag)::value;
-    constexpr int NJ = 4;
-    LANE_LOCAL();
-    const unsigned char* pl = panel + lane * 16;
-    const unsigned char* rl = ring + lane * 16;
-    bf16x8 w[2], pf[2][3];
-    wait_vmcnt<RD - 1>();
-    w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
-#pragma unroll
-    for (int tb = 0; tb < 3; ++tb) pf[0][tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16) << 10));
-#pragma unroll 1
-    for (int s2 = 0; s2 < 16; s2 += 2) {
-#pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const bool last = ss == 1 && j == NJ - 1 && s2 == 14;
-          wait_lds();
-          issue(head);
-          head = head + 1 == RD ? 0 : head + 1;
-          if (!last) {
-            wait_vmcnt<RD - 1>();
-            w[(j + 1) & 1] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
-          }
-          if (j == NJ - 1 && !last) {
-#pragma unroll
-            for (int tb = 0; tb < 3; ++tb) pf[ss ^ 1][tb] = *reinterpret_cast<const bf16x8*>(pl + ((tb * 16 + s2 + ss + 1) << 10));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int tb = 0; tb < 3; ++tb)
-            acc[j][tb] = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ss][tb], w[j & 1], acc[j][tb], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[ss][tb], acc[j][tb], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
   };
   std::false_type TL;
   std::true_type STDL;
