@@ -179,9 +179,15 @@ __global__ void __launch_bounds__(32 / NJ * 64) probe(const unsigned char* __res
       wr[0] = *reinterpret_cast<const u32x4*>(rl);
       auto group = [&](const int s2, auto first_tag, auto last_tag) {
         constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+        // PRIO 2: the later-dispatched half of the waves at priority 1 in every other group (two k-steps); 3: every other k-step;
+        // 4: the later half at priority 1 throughout; 5: the EARLIER half at priority 1 in every other group
+        if (PRIO == 2 && wave >= NW / 2) { if ((s2 >> 1) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        if (PRIO == 4 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+        if (PRIO == 5 && wave < NW / 2) { if ((s2 >> 1) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
           const int j = f & 3;
+          if (PRIO == 3 && wave >= NW / 2 && (f & 3) == 0) { if ((f >> 2) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
           if (FIRST && f + 1 < 6) {      // the next fragment comes through LDS: it has landed when at most 4 younger loads are out
             wait_vmcnt<4>();
             wr[f + 1] = *reinterpret_cast<const u32x4*>(rl + (f + 1) * 1024);
@@ -286,15 +292,12 @@ int main() {
   printf("today's rg_seq GEMM phases: 130 units x 43 rows / 720 us = 7.76 rows x units / us / CU; go >= 11.6 (43-row)\n");
   for (int grid : {64, 256}) {
     run<2, 4, 6, 0, 1, 1>(stream, stream_units, R, grid, out, clk);       // LDS ring, barrier per unit
-    run<2, 4, 6, 0, 1, 1, 1>(stream, stream_units, R, grid, out, clk);    // second half of the waves at priority 1
-    run<2, 4, 6, 0, 1, 1, 2>(stream, stream_units, R, grid, out, clk);    // ... on every other k-step
-    run<2, 4, 6, 0, 1, 1, 3>(stream, stream_units, R, grid, out, clk);    // ... on every other pair of k-steps
-    run<2, 4, 6, 0, 1, 1, 4>(stream, stream_units, R, grid, out, clk);    // ... four
     run<2, 4, 6, 0, 3, 1>(stream, stream_units, R, grid, out, clk);       // hybrid: six fragments per unit through LDS, 58 into registers
+    run<2, 4, 6, 0, 3, 1, 2>(stream, stream_units, R, grid, out, clk);    // ... with priority alternation (see PRIO in the kernel)
+    run<2, 4, 6, 0, 3, 1, 3>(stream, stream_units, R, grid, out, clk);
+    run<2, 4, 6, 0, 3, 1, 4>(stream, stream_units, R, grid, out, clk);
+    run<2, 4, 6, 0, 3, 1, 5>(stream, stream_units, R, grid, out, clk);
     run<2, 4, 6, 0, 2, 1>(stream, stream_units, R, grid, out, clk);       // register ring
-    run<2, 4, 6, 0, 2, 1, 1>(stream, stream_units, R, grid, out, clk);
-    run<2, 4, 6, 0, 2, 1, 2>(stream, stream_units, R, grid, out, clk);
-    run<2, 4, 6, 0, 2, 1, 3>(stream, stream_units, R, grid, out, clk);
   }
   return 0;
 }
