@@ -19,8 +19,9 @@ for _ in range(3):
     sess.sq.run(x, 30, dump=dump, dump_stage=99)
 torch.cuda.synchronize()
 nwg = B // 2 if pairs else B
-t = dump[:nwg * 64].view(nwg, 8, 8).cpu() / 100.0      # us; pairs: the stamps of the LAST pass (classifier-free pair)
-names = ["unit GEMMs", "row statistics", "barriers", "params+panel", "attention math", "pass", "xbuf/gbuf", "consume waits"]
+t = dump[:nwg * 96].view(nwg, 8, 12).cpu() / 100.0      # us; pairs: the stamps of the LAST pass (classifier-free pair)
+names = ["unit GEMMs", "row statistics", "barriers", "params+panel", "attention math", "pass", "xbuf/gbuf", "consume waits",
+         "panel writes outside units", "mix_x scalings / table adds", "prologue", "-"]
 # workgroup -> kind (rg_seq2_kernel: XCD-interleaved when the pair count per kind is a multiple of 4)
 npc = B // 2
 kinds = [((b & 7) >= 4) if npc % 4 == 0 else (b >= npc) for b in range(nwg)] if not pairs else [True] * nwg
@@ -29,8 +30,8 @@ for tag, k in (("conditional pairs", False), ("classifier-free pairs", True)):
     if not idx:
         continue
     m = t[idx].mean(dim=(0, 1))
-    rest = m[5] - m[0] - m[1] - m[2] - m[3] - m[4] - m[6]
-    print("%s (mean over workgroups and waves, us): " % tag + "  ".join("%s %.1f" % (names[i], m[i]) for i in (0, 1, 2, 3, 4, 6, 7, 5))
+    rest = m[5] - m[0] - m[1] - m[2] - m[3] - m[4] - m[6] - m[8] - m[9] - m[10]
+    print("%s (mean over workgroups and waves, us): " % tag + "  ".join("%s %.1f" % (names[i], m[i]) for i in (0, 1, 2, 3, 4, 6, 8, 9, 10, 7, 5))
           + "  rest %.1f" % rest + "   pass min / max over workgroups %.1f / %.1f" % (t[idx][:, :, 5].min(), t[idx][:, :, 5].max()))
     print("   per wave: " + "  ".join("w%d: gemm %.0f stats %.0f bar %.0f" % (w, t[idx][:, w, 0].mean(), t[idx][:, w, 1].mean(), t[idx][:, w, 2].mean()) for w in range(8)))
 

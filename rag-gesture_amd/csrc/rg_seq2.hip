@@ -123,7 +123,8 @@ __device__ __forceinline__ void bar() {
 
 #ifdef RG_STAMPS
 // Diagnostic build only (build.py RG_DIAG=1): wall-clock (100 MHz) time per category, summed per wave, written to
-// a.dump[(workgroup * 8 + wave) * 8 + category] when dump_stage == 99.  Categories: 0 unit GEMMs, 1 row statistics (with their
+// a.dump[(workgroup * 8 + wave) * 12 + category] when dump_stage == 99 (8: panel writes outside the units' epilogues; 9: the
+// mix_x scalings and classifier-free table adds; 10: the prologue up to the ring's first fill).  Categories: 0 unit GEMMs, 1 row statistics (with their
 // barrier), 2 other barriers, 3 parameter fragments + panel writes, 4 attention math, 5 whole pass, 6 xbuf / gbuf traffic,
 // 7 waiting in consume() (counted inside whatever category encloses it).
 #define TSTART() const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime()
@@ -171,7 +172,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   const int clips[2] = {cond ? sA : sA - B, cond ? sB : sB - B};
   const int st = clips[0] >= a.split ? a.step_b : a.step;
 #ifdef RG_STAMPS
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int ncall = 0;
   const unsigned long long tk0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -313,6 +314,9 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   load_seg();
 #pragma unroll
   for (int s = 0; s < RD; ++s) issue(s);
+#ifdef RG_STAMPS
+  tacc[10] = __builtin_amdgcn_s_memrealtime() - tk0;
+#endif
 
   // ---- fp32 round trip of the wave's [2 x 48 x 64] tile through xbuf, and the bf16 panel image in gbuf
   float* const Rw = a.xbuf + ((size_t)blockIdx.x * 2 * NW + wave) * (12 * 64 * 4);      // + q * NW * 12 * 256 floats
@@ -582,15 +586,18 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   };
   auto store_held = [&](const Held& hd) {
     LANE_LOCAL();
+    TSTART();
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) = hd[q][j][tb];
+    TSTOP(8);
   };
   auto write_raw = [&](const Acc2& v) {
     LANE_LOCAL();
+    TSTART();
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -599,11 +606,13 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         for (int tb = 0; tb < 3; ++tb)
           *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) =
               u32x2{pack2(v[q][j][tb][0], v[q][j][tb][1]), pack2(v[q][j][tb][2], v[q][j][tb][3])};
+    TSTOP(8);
   };
   // panel = (v - mean) rstd; KEEP: the image also goes to gbuf (the wave's own 12 fragments, restored by restore_panel)
   auto write_norm = [&](const Acc2& v, const float (&mean)[2][3], const float (&rstd)[2][3], auto keep_tag) {
     constexpr bool KEEP = decltype(keep_tag)::value;
     LANE_LOCAL();
+    TSTART();
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -617,6 +626,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
           *reinterpret_cast<u32x2*>(smem + off) = p;
           if (KEEP) *reinterpret_cast<u32x2*>(Gw + off) = p;
         }
+    TSTOP(8);
   };
   // the wave's own fragments of both panels back from gbuf (16 bytes per lane and fragment)
   typedef u32x4 PanelRegs[2][3][2];
@@ -880,6 +890,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     auto mix_x = [&]() {
       {
         LANE_LOCAL();
+        TSTART();
         const unsigned char* ps = consume();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -890,8 +901,10 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
             for (int tb = 0; tb < 3; ++tb) X[q][j][tb] = (c1 * mean[q][tb] + b) * rstd[q][tb];
         }
         release();
+        TSTOP(9);
       }
       gemm_unit(X, SITE(4));
+      TSTART();
 #pragma unroll
       for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -904,11 +917,13 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
             asm volatile("" : "+v"(X[q][j][tb]));
           }
         }
+      TSTOP(9);
     };
     if (!cond) {
       mix_x();
       // classifier-free rows: + sum_c W_c h_c with h_c one of two tabulated rows per (step, layer, condition)
       LANE_LOCAL();
+      TSTART();
       unsigned qbits[2] = {qbits0[0], qbits0[1]};
       asm volatile("" : "+v"(qbits[0]), "+v"(qbits[1]));
 #pragma unroll
@@ -929,6 +944,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         }
         release();
       }
+      TSTOP(9);
     } else {
       // stylized cross-attention rows of condition c -> gbuf slot 1 + c: query projection (operand: xhat in the panels),
       // softmax, y = q A_clip, masked rows, LayerNorm + stylization with the parameters of MIX_c
@@ -1076,7 +1092,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #ifdef RG_STAMPS
   if (a.dump_stage == 99 && lane0 == 0) {
     tacc[5] = __builtin_amdgcn_s_memrealtime() - tk0;
-    for (int i = 0; i < 8; ++i) a.dump[(blockIdx.x * 8 + wave) * 8 + i] = (float)tacc[i];
+    for (int i = 0; i < 12; ++i) a.dump[(blockIdx.x * 8 + wave) * 12 + i] = (float)tacc[i];
   }
 #endif
 #undef LANE_LOCAL
