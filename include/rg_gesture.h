@@ -308,7 +308,7 @@ int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bia
  *            (mix_x: vector 1 = row sums of the bf16 weight, for the un-normalised x segment).
  *   ustream  fp32  [S][L][8][2 KiB]           classifier-free sequences: sum_k W_mix_c[n][k] * unc_tab[flag][c][k] for
  *            (c, flag) = (0,0) (0,1) (1,0) (1,1) | (2,0) (2,1): their cross-attention output is a constant of (step, layer).
- *   afrag    bf16  [L][3][B][8][2 heads][2 column blocks][hi, lo][64 lanes][8]   A = softmax_N(K)^T V of every clip,
+ *   afrag    bf16  [L][3][B][8][2 heads][2 column blocks][64 lanes][8]   A = softmax_N(K)^T V of every clip,
  *            condition and head (rg_kv_reduce) as MFMA A-operand fragments: element e of lane (jj, g) is
  *            A[i][16 jb + jj], i = e < 4 ? 4 g + e : 16 + 4 g + e - 4.
  * Clips >= split run at step index step_b (two diffusion loops sharing the launch: sampler.cobatched_loop).

@@ -37,7 +37,7 @@ flops = B * ((16 * L + 2) * unit + L * 5 * att + (10 * L + 2) * unit + L * 2 * a
 alg = (st.wstream.numel() * 2 + 2 * (st.pstream[0].numel() * 4 + st.ustream[0].numel() * 4) + sess.sq.afrag.numel() * 2
        + B * T * 512 * 4 + 2 * B * T * 512 * 4)
 # bytes the workgroups pull through their LDS rings (what the per-CU intake sees): every sequence streams its own copy
-per_cond = (16 * L + 2) * 520 * 1024 + L * 3 * 64 * 1024
+per_cond = (16 * L + 2) * 520 * 1024 + L * 3 * 32 * 1024
 per_unc = (10 * L + 2) * 520 * 1024 + L * 16 * 1024
 if DUO:   # + the fp32 tile round trips (3 per layer) and bf16 panel images (4 per layer for conditional pairs) through xbuf / gbuf: L2-resident scratch
     scratch = (B // 2) * L * ((3 + 3) * 2 * 96 * 1024 + (2 + 2) * 2 * 96 * 1024 + 4 * 2 * 2 * 48 * 1024)

@@ -95,10 +95,8 @@ __device__ __forceinline__ float gelu_fast(float v) {
 // Attention products (softmax_N(K)^T V, softmax(q) A): ATT_HL = true feeds the matrix cores bf16 hi + lo operand pairs
 // (hi * hi + hi * lo + lo * hi ~ fp32 products, 3 MFMAs and the residual arithmetic per fragment), false = plain bf16
 // operands with fp32 accumulation (what every GEMM around them does; y is rounded to bf16 right after its stylization).
-#ifndef RG_SEQ_ATT_HL
-#define RG_SEQ_ATT_HL 0
-#endif
-constexpr bool ATT_HL = RG_SEQ_ATT_HL != 0;
+// (Off, and the conditions' A fragments come as plain bf16: measured in round 3, no build has used the pairs since.)
+constexpr bool ATT_HL = false;
 // 8 fp32 values -> bf16 hi fragment and the bf16 residual fragment
 __device__ __forceinline__ void split_hl(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
   u32x4 h, l = u32x4{0u, 0u, 0u, 0u};
@@ -234,10 +232,10 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
         adr = reinterpret_cast<const unsigned char*>(a.wstream) + ((size_t)uid * 512 << 10);
         cnt = (uid > 0 && uid < NU - 1 && idx == U_KV) ? 128 : 64;
         stride = cnt;
-      } else if (cond) {          // A fragments of (layer, condition, clip): afrag [L][3][B][8][8 KiB]
+      } else if (cond) {          // A fragments of (layer, condition, clip): afrag [L][3][B][8][4 KiB]
         const int c = (idx - U_Q3_0) >> 1;
-        adr = reinterpret_cast<const unsigned char*>(a.afrag) + ((size_t)((l * 3 + c) * B + clip) * 64 << 10);
-        cnt = 8; stride = 8;
+        adr = reinterpret_cast<const unsigned char*>(a.afrag) + ((size_t)((l * 3 + c) * B + clip) * 32 << 10);
+        cnt = 4; stride = 4;
       } else {                    // classifier-free cross-attention contribution: ustream [S][L][8][2 KiB]
         adr = reinterpret_cast<const unsigned char*>(a.ustream) + ((size_t)(st * L + l) * 16 << 10);
         cnt = 2; stride = 2;
@@ -744,9 +742,7 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
             const unsigned char* s0 = consume();
             ah[jb] = *reinterpret_cast<const bf16x8*>(s0 + lane * 16);
             release();
-            const unsigned char* s1 = consume();
-            al[jb] = *reinterpret_cast<const bf16x8*>(s1 + lane * 16);
-            release();
+            al[jb] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};      // (ATT_HL is off: the stream does not carry low-order halves)
           }
           qa_head(yy, qq, h, ah, al);
         }

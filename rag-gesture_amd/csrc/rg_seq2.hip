@@ -209,10 +209,10 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         adr = reinterpret_cast<const unsigned char*>(a.wstream) + ((size_t)uid * 512 << 10);
         cnt = (uid > 0 && uid < NU - 1 && idx == U_KV) ? 128 : 64;
         stride = cnt;
-      } else if (cond) {          // A fragments of (layer, condition, clip): afrag [L][3][B][8][8 KiB]
+      } else if (cond) {          // A fragments of (layer, condition, clip): afrag [L][3][B][8][4 KiB]
         const int c = (idx - U_Q3_0) >> 1;
-        adr = reinterpret_cast<const unsigned char*>(a.afrag) + ((size_t)((l * 3 + c) * B + (kind == 2 ? clips[0] : clips[1])) * 64 << 10);
-        cnt = 8; stride = 8;
+        adr = reinterpret_cast<const unsigned char*>(a.afrag) + ((size_t)((l * 3 + c) * B + (kind == 2 ? clips[0] : clips[1])) * 32 << 10);
+        cnt = 4; stride = 4;
       } else {                    // classifier-free cross-attention contribution: ustream [S][L][8][2 KiB]
         adr = reinterpret_cast<const unsigned char*>(a.ustream) + ((size_t)(st * L + l) * 16 << 10);
         cnt = 2; stride = 2;
@@ -966,8 +966,6 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
               for (int jb = 0; jb < 2; ++jb) {
                 const unsigned char* s0 = consume();
                 ah[jb] = *reinterpret_cast<const bf16x8*>(s0 + lane * 16);
-                release();
-                (void)consume();          // (the fragment's low-order half: the stream carries it for the hi + lo build of rg_seq.hip)
                 release();
               }
               qa_head(yy[q], h, ah);

@@ -54,7 +54,7 @@ def pack_kv(Wk, Wv):
 
 def a_fragments(a_pre):
     """fp32 A [..., H = 16, 32 i, 32 j] (softmax_N(K)^T V per head) -> bf16 MFMA A-operand fragments
-    [..., 8 waves, 2 heads, 2 column blocks, (hi, lo), 64 lanes, 8]: element e of lane (jj, g) = A[i][16 jb + jj],
+    [..., 8 waves, 2 heads, 2 column blocks, 64 lanes, 8]: element e of lane (jj, g) = A[i][16 jb + jj],
     i = 4 g + e for e < 4, 16 + 4 g + e - 4 otherwise (the order in which the kernel's query accumulators enumerate i)."""
     dev = a_pre.device
     g = torch.arange(4, device=dev).view(4, 1)
@@ -64,10 +64,9 @@ def a_fragments(a_pre):
     A = a_pre.index_select(-2, idx).view(*lead, 16, 4, 8, 2, 16)                    # ..., h, g, e, jb, jj
     n = len(lead)
     A = A.permute(*range(n), n, n + 3, n + 1, n + 4, n + 2).contiguous()             # ..., h, jb, g, jj, e
-    hi = A.to(torch.bfloat16)
-    lo = (A - hi.float()).to(torch.bfloat16)
-    fr = torch.stack([hi, lo], dim=n + 2)                                           # ..., h, jb, hl, g, jj, e
-    return fr.view(*lead, 8, 2, 2, 2, 64, 8).contiguous()
+    # (until late in round 5 a low-order bf16 half rode along for an hi + lo product that no build used: a quarter of the
+    #  fragments a conditional sequence took off its ring per cross-attention were discarded)
+    return A.to(torch.bfloat16).view(*lead, 8, 2, 2, 64, 8).contiguous()
 
 
 class SeqStreams:
@@ -167,7 +166,7 @@ class SeqForward:
             nwg = B + 2          # at most ceil(split / 2) + ceil((B - split) / 2) pairs per kind, two kinds
             self.xbuf = torch.empty(nwg * 2 * 8 * 12 * 64 * 4, device=dev, dtype=torch.float32)
             self.gbuf = torch.empty(nwg * 8 * 48 * 1024, device=dev, dtype=torch.uint8)
-        self.afrag = torch.zeros(w.L, 3, B, 8, 2, 2, 2, 64, 8, device=dev, dtype=torch.bfloat16)
+        self.afrag = torch.zeros(w.L, 3, B, 8, 2, 2, 64, 8, device=dev, dtype=torch.bfloat16)
         a = self.args = SeqArgs()
         p = lambda t: t.data_ptr()
         a.wstream, a.pstream, a.ustream, a.afrag = p(self.st.wstream), p(self.st.pstream), p(self.st.ustream), p(self.afrag)
