@@ -657,10 +657,11 @@ def main():
                     # (r04_pmc_seq: 128 workgroups, one per sequence; r04s_pmc_seq_pairs: 64 workgroups, one per clip -- the twin's
                     #  pass streams the shared weights through every L2 a second time)
                     # (r05B_pmc_seq2_pairs: 32 workgroups, two clips each -- rg_seq2_kernel with eight batch lanes;
-                    #  r05B_pmc_seq2_wide: 64 workgroups, two sequences of a kind each -- what the default four lanes launch;
-                    #  both of the build with the register path for the weight fragments.  The one-sequence forms' files are
+                    #  r05D_pmc_seq2_wide: 64 workgroups, two sequences of a kind each -- what the default four lanes launch, the
+                    #  last build; r05B_*: the build with the register path, before the conditions' A fragments lost their
+                    #  unused low-order halves (48 MB more traffic and algorithmic bytes per launch).  The one-sequence forms' files are
                     #  round-4 passes of rg_seq_kernel BEFORE it got that path: only their traffic figures still apply)
-                    src = {"duo_pairs": "r05B_pmc_seq2_pairs.json", "duo": "r05B_pmc_seq2_wide.json", "pairs": "r04s_pmc_seq_pairs.json"}.get(roofline.get("launch_form"), "r04_pmc_seq.json")
+                    src = {"duo_pairs": "r05B_pmc_seq2_pairs.json", "duo": "r05D_pmc_seq2_wide.json", "pairs": "r04s_pmc_seq_pairs.json"}.get(roofline.get("launch_form"), "r04_pmc_seq.json")
                     with open(os.path.join(ROOT, "profiles", src)) as f:
                         pm = json.load(f)
                     # these three are NOT measured in this run: they are read from the committed rocprofv3 --pmc passes over the

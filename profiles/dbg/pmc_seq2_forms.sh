@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
 P=$1
-for FORM in wide pairs; do
+for FORM in ${FORMS:-wide pairs}; do
   if [ $FORM = wide ]; then export SEQ_PAIRS=0 SEQ_DUO=1; else export SEQ_PAIRS=1 SEQ_DUO=1; fi
   D=gpurun_out/pmc7_$FORM
   rm -rf $D && mkdir -p $D
