@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256, 2) sa_attention_kernel(const float* __res
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     auto pk = [](float x, float y) {
-      return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
+      return rg_pack2_bf16(x, y);
     };
     auto split = [&](const float (&x)[8], bf16x8& hi, bf16x8& lo) {
       float r[8];
@@ -653,8 +653,7 @@ __global__ void __launch_bounds__(256) stylize_kernel(const StylizeArgs a) {
     u4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const __bf16 lo = (__bf16)v[2 * e], hi = (__bf16)v[2 * e + 1];
-      o[e] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+      o[e] = rg_pack2_bf16(v[2 * e], v[2 * e + 1]);
     }
     *reinterpret_cast<u4*>(dst + k) = o;
   }
@@ -794,7 +793,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
   __builtin_amdgcn_wave_barrier();
   RG_STAMP3(2);
   auto pk = [](float x, float y) {
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)y) << 16);
+    return rg_pack2_bf16(x, y);
   };
   for (int hh = 0; hh < hpw; ++hh) {
     const int h = wave * hpw + hh;
@@ -906,9 +905,7 @@ __global__ void __launch_bounds__(CS_WAVES * 64) ca_stylize_kernel(const CaStyli
       float t1 = ((y.y - mu) * rs * g1 + b1) * sc1 + sh1;
       t0 = t0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t0 * -1.44269504088896340736f));
       t1 = t1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t1 * -1.44269504088896340736f));
-      const __bf16 lo = (__bf16)t0, hi = (__bf16)t1;
-      *reinterpret_cast<unsigned*>(op + (size_t)n * a.ldo) =
-          (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+      *reinterpret_cast<unsigned*>(op + (size_t)n * a.ldo) = rg_pack2_bf16(t0, t1);
     }
   }
   RG_STAMP3(8);

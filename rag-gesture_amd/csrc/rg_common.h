@@ -67,3 +67,33 @@ static inline int rg_grid_1d(int64_t work_items, int block) {
   if (g < 1) g = 1;
   return (int)g;
 }
+
+// Two fp32 -> one dword of packed bf16 (lo in bits 0-15), round-to-nearest-even: ONE v_cvt_pk_bf16_f32.  (Written as two scalar
+// conversions + shift + or, the compiler emits two v_cvt_pk_bf16_f32, a shift and an SDWA or: four VALU instructions per pair,
+// ~10 % of the vector instructions of the sequence-stationary kernels' epilogues.)  Same rounding, same bits.
+typedef __attribute__((ext_vector_type(2))) float rg_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 rg_bf16x2;
+__device__ __forceinline__ unsigned rg_pack2_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(rg_f32x2{lo, hi}, rg_bf16x2));
+}
+
+// GELU (erf form, torch's default) for the fused kernels' epilogues:  GELU(v) = max(v, 0) - |v| h(x),  x = |v| / sqrt(2),
+// h = erfc(x) / 2 = 2^-g(x) with g a degree-7 polynomial (g(0) = 1), fitted on x in [0, 4.5] (profiles/dbg/gelu_fit.py); beyond
+// that g keeps growing (positive leading coefficient) and h underflows to 0.  Seven fused multiply-adds and ONE transcendental
+// (Abramowitz-Stegun 7.1.26, used until round 5, needs a reciprocal AND an exponential and five more vector instructions).
+// Max abs error 7.6e-7 (A-S: 6.9e-7), and RELATIVE error <= 2e-5 of erfc down to 1e-9, i.e. also in GELU's negative tail.
+__device__ __forceinline__ float rg_gelu_erf(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  float p = fmaf(1.904678831e-05f, x, -4.679475024e-04f);
+  p = fmaf(p, x, 5.123828382e-03f);
+  p = fmaf(p, x, -3.364521737e-02f);
+  p = fmaf(p, x, 1.520822882e-01f);
+  p = fmaf(p, x, 9.172845077e-01f);
+  p = fmaf(p, x, 1.628025418e+00f);
+  p = fmaf(p, -x, -1.0f);                                  // -g(x)
+  return fmaf(-fabsf(v), __builtin_amdgcn_exp2f(p), fmaxf(v, 0.0f));
+}
+// e^(q - m) as one fused multiply-add and the hardware's 2^x (the caller passes nm2 = -m log2(e))
+__device__ __forceinline__ float rg_exp_sub(float q, float nm2) {
+  return __builtin_amdgcn_exp2f(fmaf(q, 1.44269504088896340736f, nm2));
+}

@@ -23,9 +23,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-}
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return rg_pack2_bf16(lo, hi); }
 __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
 }

@@ -49,7 +49,7 @@ constexpr int OFF_P1 = TP * 1024;
 constexpr int OFF_RING = 2 * TP * 1024;
 constexpr int MAX_SEG = 8 * 34 + 5;                      // fetch segments of a conditional sequence at L = 8, + sentinel
 constexpr int OFF_DESC = OFF_RING + NW * RD * 1024;      // [MAX_SEG] x 16 B fetch segments {address (wave 0), count, wave stride}
-constexpr int OFF_STAT = OFF_DESC + MAX_SEG * 16;         // [NW][TP][2] fp32 partial (sum, M2)
+constexpr int OFF_STAT = OFF_DESC + MAX_SEG * 16;         // [NW][TP][2] fp32 partial (sum, sum of squares)
 constexpr int LDS_BYTES = OFF_STAT + NW * TP * 2 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
@@ -77,21 +77,11 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return rg_pack2_bf16(lo, hi); }
 __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
-// GELU (erf form), erf by Abramowitz-Stegun 7.1.26 (abs. error 1.5e-7): as the bf16 path of rg_gemm
-__device__ __forceinline__ float gelu_fast(float v) {
-  const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float e = 1.0f - pl * t * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
-  return 0.5f * v + 0.5f * fabsf(v) * e;
-}
+__device__ __forceinline__ float gelu_fast(float v) { return rg_gelu_erf(v); }
 // Attention products (softmax_N(K)^T V, softmax(q) A): ATT_HL = true feeds the matrix cores bf16 hi + lo operand pairs
 // (hi * hi + hi * lo + lo * hi ~ fp32 products, 3 MFMAs and the residual arithmetic per fragment), false = plain bf16
 // operands with fp32 accumulation (what every GEMM around them does; y is rounded to bf16 right after its stylization).
@@ -423,41 +413,41 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
   };
 
   // ---- LayerNorm statistics of the three tokens a lane holds (all 512 features: 16 in the lane, x 4 lane groups,
-  // x 8 waves): per-wave (sum, M2 about the wave's own mean) combined exactly (Chan), one barrier
+  // x 8 waves): per-wave (sum, sum of squares) in ONE pass over the registers, added up across the waves behind one barrier;
+  // variance = E[x^2] - mean^2 in fp32 (relative error ~1e-7 (1 + mean^2 / variance): the rows normalised here -- residual
+  // stream, attention and FFN outputs -- have |mean| of the order of their deviation or below).  Until round 5: per-wave M2
+  // about the wave's own mean, combined by Chan's formula -- 1.8x the vector instructions, a fifth of a layer's epilogue work.
+  // (Between two calls lies a workgroup barrier at every call site: one buffer of partials is enough here; rg_seq2.hip alternates two.)
   auto row_stats = [&](const Acc& v, float (&mean)[3], float (&rstd)[3]) {
     LANE_LOCAL();
     TSTART();
+    float* const sSt = sStat;
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
-      float s = 0.f;
+      float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
+      for (int j = 0; j < 4; ++j) {
+        s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(v[j][tb][r], v[j][tb][r], ss);
+      }
       s = xsum4(s);
-      const float mw = s * (1.0f / 64);
-      float m2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m2 = fmaf(v[j][tb][r] - mw, v[j][tb][r] - mw, m2);
-      m2 = xsum4(m2);
-      if (g4 == 0) *reinterpret_cast<float2*>(sStat + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, m2);
+      ss = xsum4(ss);
+      if (g4 == 0) *reinterpret_cast<float2*>(sSt + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, ss);
     }
     bar();   // (inside the row-statistics stamp)
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) tot += sStat[(w * TP + 16 * tb + l15) * 2];
-      const float mu = tot * (1.0f / DM);
-      float m2 = 0.f;
+      float tot = 0.f, tot2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
-        const float2 p = *reinterpret_cast<const float2*>(sStat + (w * TP + 16 * tb + l15) * 2);
-        const float d = p.x * (1.0f / 64) - mu;
-        m2 += p.y + 64.0f * d * d;
+        const float2 p = *reinterpret_cast<const float2*>(sSt + (w * TP + 16 * tb + l15) * 2);
+        tot += p.x;
+        tot2 += p.y;
       }
+      const float mu = tot * (1.0f / DM);
       mean[tb] = mu;
-      rstd[tb] = rsqrtf(m2 * (1.0f / DM) + 1e-5f);
+      rstd[tb] = rsqrtf(fmaxf(fmaf(-mu, mu, tot2 * (1.0f / DM)), 0.f) + 1e-5f);
     }
     TSTOP(1);
   };
@@ -526,15 +516,16 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
         f32x4& q1 = q[2 * h + 1][tb];
         float mx = fmaxf(fmaxf(fmaxf(q0[0], q0[1]), fmaxf(q0[2], q0[3])), fmaxf(fmaxf(q1[0], q1[1]), fmaxf(q1[2], q1[3])));
         mx = xmax4(mx);
+        const float nm2 = mx * -1.44269504088896340736f;
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          q0[r] = __expf(q0[r] - mx);
-          q1[r] = __expf(q1[r] - mx);
+          q0[r] = rg_exp_sub(q0[r], nm2);
+          q1[r] = rg_exp_sub(q1[r], nm2);
           sum += q0[r] + q1[r];
         }
         sum = xsum4(sum);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         q0 *= inv;
         q1 *= inv;
       }
@@ -613,17 +604,18 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
               for (int r = 0; r < 4; ++r)
                 if ((tokbits >> (4 * tb + r)) & 1u) mx = fmaxf(mx, kk[j][tb][r]);
             mx = xmax4(mx);
+            const float nm2 = mx * -1.44269504088896340736f;
             float sum = 0.f;
 #pragma unroll
             for (int tb = 0; tb < 3; ++tb)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float e = ((tokbits >> (4 * tb + r)) & 1u) ? __expf(kk[j][tb][r] - mx) : 0.f;
+                const float e = ((tokbits >> (4 * tb + r)) & 1u) ? rg_exp_sub(kk[j][tb][r], nm2) : 0.f;
                 kk[j][tb][r] = e;
                 sum += e;
               }
             sum = xsum4(sum);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
             for (int tb = 0; tb < 3; ++tb) kk[j][tb] *= inv;
           }
@@ -694,7 +686,7 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
       gemm_unit(xr, P0, TL);
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
-        const float sd = 1.0f / rstd[tb];
+        const float sd = __builtin_amdgcn_rcpf(rstd[tb]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           xr[j][tb] *= sd;

@@ -7,14 +7,15 @@
 // 6.7 us per unit = 0.77 of the pipe) and the weight bytes per row halve.
 // What had to move for that (NOTEBOOK 9.4 counted the registers): a wave's 256 VGPRs hold ONE fp32 [2 x 48 x 64] tile, so
 //   * the residual stream no longer lives in registers across a block: it takes the fp32 round trip through `xbuf` (L2, lane-
-//     linear 1-KiB wave instructions) three times per layer -- stored when a block starts, loaded back as the accumulator
+//     linear 1-KiB wave instructions) twice per layer (self attention, FFN) -- stored when a block starts, loaded back as the accumulator
 //     initialiser of the block's output projection while the stylization in front of it is being computed;
 //   * one bf16 panel per sequence (2 x 48 KiB) instead of two.  Operands that the old kernel parked in the second panel either
 //     wait in registers as packed bf16 (48 VGPRs for both sequences: the two GELU halves of the FFN, units re-ordered FF1_0,
 //     FF1_1, FF2_0, FF2_1) or go through `gbuf` (L2) as bf16 panel images, every wave writing and later restoring its own
-//     fragments: the normalised x of the cross-attention block (the three query projections need it, the MIX units overwrite
-//     it) and the stylized rows of the three conditions (held in registers beside the queries' accumulator they spilled ~120
-//     registers each).  Cross-attention order: Q3_0, MIXX, MIX_0 | Q3_1, Q3_2, MIX_1, MIX_2, the accumulator in xbuf between;
+//     fragments: the stylized rows of the three conditions (held in registers beside the queries' accumulator they spilled
+//     ~120 registers each).  Cross-attention order (round 6): Q3_0, Q3_1, Q3_2, MIXX | MIX_0, MIX_1, MIX_2 -- every unit that
+//     reads the normalised x first (the residual stream is dead there, so nothing but the queries is live), then the three
+//     units that read the stylized rows: no second copy of xhat, no round trip of the accumulator (round 5 had both);
 //   * the six panel fragments of a k-step live in one set of registers, re-read in place behind their last MFMA;
 //   * everything that touches memory besides the ring is issued at the START of an epilogue (statistics, barriers), never in
 //     front of a GEMM loop: the ring's counted vmcnt then rarely waits for it.  No scratch, 251 VGPRs.
@@ -45,9 +46,10 @@ constexpr int PANEL = TP * 1024;                         // bytes of one sequenc
 constexpr int OFF_RING = 2 * PANEL;
 constexpr int NSEG_COND = 36, NSEG_UNC = 19;             // fetch segments per layer
 constexpr int MAX_SEG = 8 * NSEG_COND + 5;               // + embed (2), head (2), sentinel
-constexpr int OFF_DESC = OFF_RING + NW * RD * 1024;      // [MAX_SEG] x 16 B fetch segments {address (wave 0), count, wave stride}
-constexpr int OFF_STAT = OFF_DESC + MAX_SEG * 16;        // [2][NW][TP][2] fp32 partial (sum, M2)
-constexpr int LDS_BYTES = OFF_STAT + 2 * NW * TP * 2 * 4;
+constexpr int OFF_DESC = OFF_RING + NW * RD * 1024;      // [MAX_SEG] x 8 B fetch segments {address of wave 0 (48 bits), count (8), wave stride (8)}
+constexpr int OFF_STAT = OFF_DESC + ((MAX_SEG * 8 + 15) & ~15);   // [parity 2][sequence 2][NW][TP][2] fp32 partial (sum, M2)
+constexpr int STAT_HALF = 2 * NW * TP * 2;               // floats of one parity's partials
+constexpr int LDS_BYTES = OFF_STAT + 2 * STAT_HALF * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
 enum { U_KV = 0, U_KV2, U_Q, U_SAO, U_MIXX, U_Q3_0, U_MIX_0, U_Q3_1, U_MIX_1, U_Q3_2, U_MIX_2, U_FF1_0, U_FF2_0, U_FF1_1, U_FF2_1, U_FFO };
@@ -56,9 +58,10 @@ enum { U_KV = 0, U_KV2, U_Q, U_SAO, U_MIXX, U_Q3_0, U_MIX_0, U_Q3_1, U_MIX_1, U_
 #define SEG(u, k) ((u) << 2 | (k))
 __constant__ const unsigned char SEG2_COND[NSEG_COND + 1] = {
     SEG(U_KV, 0), SEG(U_KV, 1), SEG(U_Q, 0), SEG(U_Q, 1), SEG(U_SAO, 0), SEG(U_SAO, 1),
-    SEG(U_Q3_0, 0), SEG(U_Q3_0, 1), SEG(U_Q3_0, 2), SEG(U_Q3_0, 3), SEG(U_MIX_0, 0), SEG(U_MIXX, 0), SEG(U_MIXX, 1), SEG(U_MIX_0, 1),
+    SEG(U_Q3_0, 0), SEG(U_Q3_0, 1), SEG(U_Q3_0, 2), SEG(U_Q3_0, 3), SEG(U_MIX_0, 0),
     SEG(U_Q3_1, 0), SEG(U_Q3_1, 1), SEG(U_Q3_1, 2), SEG(U_Q3_1, 3), SEG(U_MIX_1, 0),
-    SEG(U_Q3_2, 0), SEG(U_Q3_2, 1), SEG(U_Q3_2, 2), SEG(U_Q3_2, 3), SEG(U_MIX_2, 0), SEG(U_MIX_1, 1), SEG(U_MIX_2, 1),
+    SEG(U_Q3_2, 0), SEG(U_Q3_2, 1), SEG(U_Q3_2, 2), SEG(U_Q3_2, 3), SEG(U_MIX_2, 0),
+    SEG(U_MIXX, 0), SEG(U_MIXX, 1), SEG(U_MIX_0, 1), SEG(U_MIX_1, 1), SEG(U_MIX_2, 1),
     SEG(U_FF1_0, 0), SEG(U_FF1_0, 1), SEG(U_FF1_1, 0), SEG(U_FF1_1, 1), SEG(U_FF2_0, 0), SEG(U_FF2_0, 1), SEG(U_FF2_1, 0), SEG(U_FF2_1, 1),
     SEG(U_FFO, 0), SEG(U_FFO, 1), 0};
 __constant__ const unsigned char SEG2_UNC[NSEG_UNC + 1] = {
@@ -71,21 +74,11 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return rg_pack2_bf16(lo, hi); }
 __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
-// GELU (erf form), erf by Abramowitz-Stegun 7.1.26 (abs. error 1.5e-7): as the bf16 path of rg_gemm
-__device__ __forceinline__ float gelu_fast(float v) {
-  const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float e = 1.0f - pl * t * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
-  return 0.5f * v + 0.5f * fabsf(v) * e;
-}
+__device__ __forceinline__ float gelu_fast(float v) { return rg_gelu_erf(v); }
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
   return __builtin_bit_cast(bf16x8, u32x4{pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])});
 }
@@ -189,7 +182,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   // + a sentinel that keeps the in-flight count invariant behind the end
   if (tid <= n_seg) {
     const unsigned char* adr = reinterpret_cast<const unsigned char*>(a.wstream);
-    unsigned cnt = 1u << 30, stride = 0;
+    unsigned cnt = 0, stride = 0;                        // (the sentinel: a count the cursor never reaches)
     if (tid < n_seg) {
       int uid, kind, idx = 0, l = 0;
       if (tid < 2) { uid = 0; kind = tid; }
@@ -206,7 +199,11 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         adr = reinterpret_cast<const unsigned char*>(a.pstream) + ((size_t)(st * NU + uid) * 8 << 10);
         cnt = 1; stride = 1;
       } else if (kind == 1) {     // weights: wstream [NU][8][64][1 KiB] (U_KV: [8][128] over two slots)
+#ifdef RG2_HOT_STREAM      // diagnostic (wrong results): every unit streams the SAME 512 KiB, so the stream always hits in L2
+        adr = reinterpret_cast<const unsigned char*>(a.wstream) + ((size_t)1 * 512 << 10);
+#else
         adr = reinterpret_cast<const unsigned char*>(a.wstream) + ((size_t)uid * 512 << 10);
+#endif
         cnt = (uid > 0 && uid < NU - 1 && idx == U_KV) ? 128 : 64;
         stride = cnt;
       } else if (cond) {          // A fragments of (layer, condition, clip): afrag [L][3][B][8][4 KiB]
@@ -218,8 +215,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         cnt = 2; stride = 2;
       }
     }
-    const unsigned long long av = reinterpret_cast<unsigned long long>(adr);
-    *reinterpret_cast<u32x4*>(smem + OFF_DESC + tid * 16) = u32x4{(unsigned)av, (unsigned)(av >> 32), cnt, stride};
+    const unsigned long long av = reinterpret_cast<unsigned long long>(adr);      // (device addresses: 48 bits)
+    *reinterpret_cast<u32x2*>(smem + OFF_DESC + tid * 8) = u32x2{(unsigned)av, ((unsigned)(av >> 32) & 0xffffu) | cnt << 16 | stride << 24};
   }
 
   // ---- token masks, per lane and sequence: bit (4 tb + r) of tokbits = token 16 tb + 4 g4 + r takes part in the self
@@ -274,11 +271,11 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   __amdgpu_buffer_rsrc_t cur_rsrc;
   const int lane16 = lane0 * 16;
   auto load_seg = [&]() {
-    const u32x4 d = *reinterpret_cast<const u32x4*>(smem + OFF_DESC + ie * 16);
-    const unsigned lo = __builtin_amdgcn_readfirstlane(d[0]), hi = __builtin_amdgcn_readfirstlane(d[1]);
-    cur_cnt = __builtin_amdgcn_readfirstlane(d[2]);
-    const unsigned stride = __builtin_amdgcn_readfirstlane(d[3]);
-    unsigned char* base = reinterpret_cast<unsigned char*>(((unsigned long long)hi << 32) | lo) + ((size_t)(wave * stride) << 10);
+    const u32x2 d = *reinterpret_cast<const u32x2*>(smem + OFF_DESC + ie * 8);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(d[0]), w1 = __builtin_amdgcn_readfirstlane(d[1]);
+    cur_cnt = (w1 >> 16) & 0xffu;
+    const unsigned stride = w1 >> 24;
+    unsigned char* base = reinterpret_cast<unsigned char*>(((unsigned long long)(w1 & 0xffffu) << 32) | lo) + ((size_t)(wave * stride) << 10);
     cur_rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000);
   };
   auto issue = [&](int slot) {
@@ -353,9 +350,12 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   // beside a 96-register accumulator and a held operand): each is re-read for the next k-step right behind its last MFMA of
   // this one, five MFMAs and the next fragment's bookkeeping ahead of its first use.  (The re-read of the last k-step falls
   // behind the panel's end: valid LDS, never used.)
-  auto gemm_frags = [&](auto& acc, auto nj_tag, auto std_tag) {
+  // INIT: the accumulators START as bi[j] (the unit's bias, one f32x4 per 16-feature block, the same for every token block of
+  // both sequences): the first k-step's MFMAs take it as their C operand, so nothing copies it into the 96 registers first.
+  auto gemm_frags = [&](auto& acc, auto nj_tag, auto std_tag, auto init_tag, const f32x4* const bi) {
     constexpr int NJ = decltype(nj_tag)::value;
     constexpr bool STD = decltype(std_tag)::value;
+    constexpr bool INIT = decltype(init_tag)::value;
     static_assert(NJ % 2 == 0, "fragments per step alternate between two registers");
     LANE_LOCAL();
     TSTART();
@@ -366,8 +366,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     w[0] = *reinterpret_cast<const bf16x8*>(rl + head * 1024);
 #pragma unroll
     for (int b = 0; b < 6; ++b) pf[b] = *reinterpret_cast<const bf16x8*>(pl + (b / 3) * PANEL + (((b % 3) * 16) << 10));
-#pragma unroll 1
-    for (int s = 0; s < 16; ++s) {
+    auto kstep = [&](const int s, auto first_tag) {
+      constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         // w[j & 1] is in registers: the oldest LDS read outstanding (behind it at most the six panel re-reads)
@@ -383,8 +383,9 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           f32x4& c = acc[b / 3][j][b % 3];
-          c = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b], w[j & 1], c, 0, 0, 0)
-                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[b], c, 0, 0, 0);
+          const f32x4 cin = (INIT && FIRST) ? bi[j] : c;
+          c = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b], w[j & 1], cin, 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j & 1], pf[b], cin, 0, 0, 0);
           if (j == NJ - 1) {
             pf[b] = *reinterpret_cast<const bf16x8*>(pl + (b / 3) * PANEL + (((b % 3) * 16 + s + 1) << 10));
             __builtin_amdgcn_sched_barrier(0);
@@ -392,6 +393,14 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    if constexpr (INIT) {
+      kstep(0, std::true_type());
+#pragma unroll 1
+      for (int s = 1; s < 16; ++s) kstep(s, std::false_type());
+    } else {
+#pragma unroll 1
+      for (int s = 0; s < 16; ++s) kstep(s, std::false_type());
     }
     TSTOP(0);
     TLOG();
@@ -411,11 +420,17 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       load_seg();
     }
   };
-  auto gemm_frags_reg = [&](auto& acc, auto nj_tag, auto std_tag) {
+  auto gemm_frags_reg = [&](auto& acc, auto nj_tag, auto std_tag, auto init_tag, const f32x4* const bi) {
     constexpr int NJ = decltype(nj_tag)::value;
     constexpr bool STD = decltype(std_tag)::value;
+    constexpr bool INIT = decltype(init_tag)::value;
     constexpr int NF = 16 * NJ;                    // fragments of the unit (64 or 32)
-    static_assert(NF % 8 == 0 && 8 % NJ == 0 && RD == 6, "groups of eight fragments, six in flight");
+    static_assert(NF % 8 == 0 && 8 % NJ == 0 && RD == 6, "groups of eight fragments, six in flight across the unit's ends");
+#ifndef RG2_LA
+#define RG2_LA 6
+#endif
+    constexpr int LA = RG2_LA;                     // fragments in flight inside the unit (6, or 7: the quad of fragment f - 1 refilled at once)
+    static_assert(LA == 6 || LA == 7, "look-ahead");
     LANE_LOCAL();
     TSTART();
     const unsigned char* pl = smem + lane * 16;
@@ -433,8 +448,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         const int j = f % NJ, s = s0 + f / NJ;
-        if (FIRST && f + 1 < 6) {      // the next fragment sits in the ring: landed when at most 4 younger loads are outstanding
-          wait_vmcnt<4>();
+        if (FIRST && f + 1 < 6) {      // the next fragment sits in the ring: landed when at most LA - 2 younger loads are outstanding
+          if (LA == 6 || f == 0) wait_vmcnt<4>(); else wait_vmcnt<5>();
           wr[f + 1] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
           hs = hs + 1 == RD ? 0 : hs + 1;
         }
@@ -443,8 +458,9 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           f32x4& c = acc[b / 3][j][b % 3];
-          c = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b], wv, c, 0, 0, 0)
-                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, pf[b], c, 0, 0, 0);
+          const f32x4 cin = (INIT && FIRST && f < NJ) ? bi[j] : c;      // (the unit's first k-step: fragments 0 ... NJ - 1)
+          c = STD ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[b], wv, cin, 0, 0, 0)
+                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv, pf[b], cin, 0, 0, 0);
           if (j == NJ - 1) {
             pf[b] = *reinterpret_cast<const bf16x8*>(pl + (b / 3) * PANEL + (((b % 3) * 16 + s + 1) << 10));
             __builtin_amdgcn_sched_barrier(0);
@@ -453,8 +469,11 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         if (LAST && f >= 2) {          // the stream's next six items go to the ring (slots in the order they were read from)
           issue(hs);
           hs = hs + 1 == RD ? 0 : hs + 1;
-        } else {
+        } else if (LA == 6) {
           issue_reg(wr[(f + 6) & 7]);
+        } else {                       // LA == 7: one more in flight from the unit's first fragment to its last group
+          if (FIRST && f == 0) issue_reg(wr[6]);
+          if (!(LAST && f >= 1)) issue_reg(wr[(f + 7) & 7]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -475,12 +494,16 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #endif
 #define SITE(n) std::integral_constant<int, n>()
   auto gemm_unit = [&](Acc2& acc, auto site) {
-    if constexpr (((RG2_REG_SITES) >> decltype(site)::value) & 1) gemm_frags_reg(acc, std::integral_constant<int, 4>(), std::false_type());
-    else gemm_frags(acc, std::integral_constant<int, 4>(), std::false_type());
+    if constexpr (((RG2_REG_SITES) >> decltype(site)::value) & 1) gemm_frags_reg(acc, std::integral_constant<int, 4>(), std::false_type(), std::false_type(), nullptr);
+    else gemm_frags(acc, std::integral_constant<int, 4>(), std::false_type(), std::false_type(), nullptr);
   };
-  auto gemm_head_std = [&](f32x4 (&acc)[2][2][3]) {
-    if constexpr (((RG2_REG_SITES) >> 1) & 1) gemm_frags_reg(acc, std::integral_constant<int, 2>(), std::true_type());
-    else gemm_frags(acc, std::integral_constant<int, 2>(), std::true_type());
+  auto gemm_unit_init = [&](Acc2& acc, auto site, const f32x4 (&bi)[4]) {      // acc = bi + W x panel
+    if constexpr (((RG2_REG_SITES) >> decltype(site)::value) & 1) gemm_frags_reg(acc, std::integral_constant<int, 4>(), std::false_type(), std::true_type(), bi);
+    else gemm_frags(acc, std::integral_constant<int, 4>(), std::false_type(), std::true_type(), bi);
+  };
+  auto gemm_head_std = [&](f32x4 (&acc)[2][2][3], const f32x4 (&bi)[2]) {       // acc = bi + panel x W (one head, standard layout)
+    if constexpr (((RG2_REG_SITES) >> 1) & 1) gemm_frags_reg(acc, std::integral_constant<int, 2>(), std::true_type(), std::true_type(), bi);
+    else gemm_frags(acc, std::integral_constant<int, 2>(), std::true_type(), std::true_type(), bi);
   };
 
   // parameter fragment [4][64] fp32 at the head of every unit: vector p for this wave's 64 features
@@ -505,22 +528,17 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     release();
     gemm_unit(acc, site);
   };
-  // ... acc = bias + W x panel (no zero-fill + add: 192 VALU instructions per unit)
+  // ... acc = bias + W x panel: the bias is the C operand of the first k-step's MFMAs (no zero-fill + add, no copies)
   auto unit_init = [&](Acc2& acc, auto site) {
+    f32x4 bi[4];
     {
       LANE_LOCAL();
       const unsigned char* ps = consume();
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 b = par_t(ps, 0, j, g4);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int tb = 0; tb < 3; ++tb) acc[q][j][tb] = b;
-      }
+      for (int j = 0; j < 4; ++j) bi[j] = par_t(ps, 0, j, g4);
       release();
     }
-    gemm_unit(acc, site);
+    gemm_unit_init(acc, site, bi);
   };
   // ... acc += W x panel; the unit's parameter fragment (a zero bias: the second half of FFN linear2) is only taken off the ring
   auto unit_more = [&](Acc2& acc, auto site) {
@@ -529,27 +547,30 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     gemm_unit(acc, site);
   };
 
-  // ---- LayerNorm statistics of the three tokens a lane holds, both sequences: per-wave (sum, M2 about the wave's own mean)
-  // combined exactly (Chan), ONE barrier for both
+  // ---- LayerNorm statistics of the three tokens a lane holds, both sequences: per-wave (sum, sum of squares) in one pass over
+  // the registers, added up across the waves behind ONE barrier for both sequences (formulas: rg_seq.hip row_stats, bit for bit).
+  // The partials alternate between two halves of sStat, call by call: a wave that is still reading one call's partials is
+  // never overtaken by another wave's writes of the next call (between two calls of the same parity lies the other call's barrier).
+  int stat_par = 0;
   auto row_stats = [&](const Acc2& v, float (&mean)[2][3], float (&rstd)[2][3]) {
     LANE_LOCAL();
     TSTART();
+    float* const sSt = sStat + stat_par * STAT_HALF;
+    stat_par ^= 1;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
-        float s = 0.f;
+        float s = 0.f, ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s += (v[q][j][tb][0] + v[q][j][tb][1]) + (v[q][j][tb][2] + v[q][j][tb][3]);
+        for (int j = 0; j < 4; ++j) {
+          s += (v[q][j][tb][0] + v[q][j][tb][1]) + (v[q][j][tb][2] + v[q][j][tb][3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ss = fmaf(v[q][j][tb][r], v[q][j][tb][r], ss);
+        }
         s = xsum4(s);
-        const float mw = s * (1.0f / 64);
-        float m2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) m2 = fmaf(v[q][j][tb][r] - mw, v[q][j][tb][r] - mw, m2);
-        m2 = xsum4(m2);
-        if (g4 == 0) *reinterpret_cast<float2*>(sStat + ((q * NW + wave) * TP + 16 * tb + l15) * 2) = make_float2(s, m2);
+        ss = xsum4(ss);
+        if (g4 == 0) *reinterpret_cast<float2*>(sSt + ((q * NW + wave) * TP + 16 * tb + l15) * 2) = make_float2(s, ss);
       }
     bar();   // (inside the row-statistics stamp)
     int so = l15;               // (row of the partials; see below)
@@ -562,19 +583,16 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       for (int tb = 0; tb < 3; ++tb) {
         float2 p[NW];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) p[w] = *reinterpret_cast<const float2*>(sStat + ((q * NW + w) * TP + 16 * tb + so) * 2);
-        float tot = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) tot += p[w].x;
-        const float mu = tot * (1.0f / DM);
-        float m2 = 0.f;
+        for (int w = 0; w < NW; ++w) p[w] = *reinterpret_cast<const float2*>(sSt + ((q * NW + w) * TP + 16 * tb + so) * 2);
+        float tot = 0.f, tot2 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-          const float d = p[w].x * (1.0f / 64) - mu;
-          m2 += p[w].y + 64.0f * d * d;
+          tot += p[w].x;
+          tot2 += p[w].y;
         }
+        const float mu = tot * (1.0f / DM);
         mean[q][tb] = mu;
-        rstd[q][tb] = rsqrtf(m2 * (1.0f / DM) + 1e-5f);
+        rstd[q][tb] = rsqrtf(fmaxf(fmaf(-mu, mu, tot2 * (1.0f / DM)), 0.f) + 1e-5f);
       }
     }
     TSTOP(1);
@@ -608,9 +626,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
               u32x2{pack2(v[q][j][tb][0], v[q][j][tb][1]), pack2(v[q][j][tb][2], v[q][j][tb][3])};
     TSTOP(8);
   };
-  // panel = (v - mean) rstd; KEEP: the image also goes to gbuf (the wave's own 12 fragments, restored by restore_panel)
-  auto write_norm = [&](const Acc2& v, const float (&mean)[2][3], const float (&rstd)[2][3], auto keep_tag) {
-    constexpr bool KEEP = decltype(keep_tag)::value;
+  // panel = (v - mean) rstd
+  auto write_norm = [&](const Acc2& v, const float (&mean)[2][3], const float (&rstd)[2][3]) {
     LANE_LOCAL();
     TSTART();
 #pragma unroll
@@ -622,9 +639,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
           const float r = rstd[q][tb], nm = -mean[q][tb] * r;      // (v - mean) rstd as ONE fused multiply-add per value
           const u32x2 p = u32x2{pack2(fmaf(v[q][j][tb][0], r, nm), fmaf(v[q][j][tb][1], r, nm)),
                                 pack2(fmaf(v[q][j][tb][2], r, nm), fmaf(v[q][j][tb][3], r, nm))};
-          const int off = q * PANEL + panel_off(l15, g4, j, tb);
-          *reinterpret_cast<u32x2*>(smem + off) = p;
-          if (KEEP) *reinterpret_cast<u32x2*>(Gw + off) = p;
+          *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) = p;
         }
     TSTOP(8);
   };
@@ -656,7 +671,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   };
   // StylizationBlock front half: SiLU(LN(y) * (1 + scale) + shift) with gain = gamma (1 + scale), off = beta (1 + scale)
   // + shift = vectors 1, 2 of the consuming unit's parameter fragment `ps`, as packed bf16
-  // ... to a slot of gbuf (the wave's own fragments of the panel image, as write_norm keeps xhat in slot 0)
+  // ... to a slot of gbuf (the wave's own fragments of the panel image; slot 0 is unused since round 6)
   auto styl_gbuf = [&](const int slot, const Acc2& v, const float (&mean)[2][3], const float (&rstd)[2][3], const unsigned char* ps) {
     LANE_LOCAL();
     const float nmr[2][3] = {{-mean[0][0] * rstd[0][0], -mean[0][1] * rstd[0][1], -mean[0][2] * rstd[0][2]},
@@ -720,15 +735,16 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         f32x4& q1 = q[2 * h + 1][tb];
         float mx = fmaxf(fmaxf(fmaxf(q0[0], q0[1]), fmaxf(q0[2], q0[3])), fmaxf(fmaxf(q1[0], q1[1]), fmaxf(q1[2], q1[3])));
         mx = xmax4(mx);
+        const float nm2 = mx * -1.44269504088896340736f;
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          q0[r] = __expf(q0[r] - mx);
-          q1[r] = __expf(q1[r] - mx);
+          q0[r] = rg_exp_sub(q0[r], nm2);
+          q1[r] = rg_exp_sub(q1[r], nm2);
           sum += q0[r] + q1[r];
         }
         sum = xsum4(sum);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
         q0 *= inv;
         q1 *= inv;
       }
@@ -768,7 +784,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     // ======================================================= self attention (efficient_attention.py:23-45)
     store_R(X);                                       // x comes back as the accumulator of the output projection
     row_stats(X, mean, rstd);
-    write_norm(X, mean, rstd, std::false_type());     // panels = xhat; gamma is folded into the weights, beta into the bias
+    write_norm(X, mean, rstd);     // panels = xhat; gamma is folded into the weights, beta into the bias
     barx();
     {
       bf16x8 Af[2][2][2];                             // [sequence][head][16-column block]: A_h = softmax_N(K_h)^T V_h as A operands
@@ -789,16 +805,9 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           f32x4 kk[2][2][3], vv[2][2][3];
-#pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-              for (int tb = 0; tb < 3; ++tb) {
-                kk[q][j][tb] = f32x4{bk[2 * h + j], bk[2 * h + j], bk[2 * h + j], bk[2 * h + j]};
-                vv[q][j][tb] = f32x4{bv[2 * h + j], bv[2 * h + j], bv[2 * h + j], bv[2 * h + j]};
-              }
-          gemm_head_std(kk);
+          const f32x4 bki[2] = {f32x4{bk[2 * h], bk[2 * h], bk[2 * h], bk[2 * h]}, f32x4{bk[2 * h + 1], bk[2 * h + 1], bk[2 * h + 1], bk[2 * h + 1]}};
+          const f32x4 bvi[2] = {f32x4{bv[2 * h], bv[2 * h], bv[2 * h], bv[2 * h]}, f32x4{bv[2 * h + 1], bv[2 * h + 1], bv[2 * h + 1], bv[2 * h + 1]}};
+          gemm_head_std(kk, bki);
           {
             TSTART();
             // softmax over the tokens, per feature column (lane): tokens 16 tb + 4 g4 + r; masked / padded tokens weigh 0
@@ -813,23 +822,24 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
                   for (int r = 0; r < 4; ++r)
                     if ((tokbits[q] >> (4 * tb + r)) & 1u) mx = fmaxf(mx, kk[q][j][tb][r]);
                 mx = xmax4(mx);
+                const float nm2 = mx * -1.44269504088896340736f;
                 float sum = 0.f;
 #pragma unroll
                 for (int tb = 0; tb < 3; ++tb)
 #pragma unroll
                   for (int r = 0; r < 4; ++r) {
-                    const float e = ((tokbits[q] >> (4 * tb + r)) & 1u) ? __expf(kk[q][j][tb][r] - mx) : 0.f;
+                    const float e = ((tokbits[q] >> (4 * tb + r)) & 1u) ? rg_exp_sub(kk[q][j][tb][r], nm2) : 0.f;
                     kk[q][j][tb][r] = e;
                     sum += e;
                   }
                 sum = xsum4(sum);
-                const float inv = 1.0f / sum;
+                const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                 for (int tb = 0; tb < 3; ++tb) kk[q][j][tb] *= inv;
               }
             TSTOP(4);
           }
-          gemm_head_std(vv);
+          gemm_head_std(vv, bvi);
           // A_h[i][jc] = sum_t P[t][i] V[t][jc] (contraction over tokens: step 0 = token blocks 0 | 1, step 1 = block 2 | zeros)
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
@@ -883,8 +893,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     // ======================================================= three cross attentions + ca_mix (efficient_attention.py:62-102,
     // diffusion_transformer.py:110-122), as [h_text | h_audio | h_spk | x] @ W_fused^T (rg_gesture.h: ca_mix fusion)
     row_stats(X, mean, rstd);
-    if (cond) write_norm(X, mean, rstd, std::true_type());      // xhat: the queries' operand (their gamma / beta folded) and
-    else write_norm(X, mean, rstd, std::false_type());          // the x segment; conditional sequences need it twice
+    write_norm(X, mean, rstd);     // xhat: the queries' operand (their gamma / beta folded) and the x segment
     barx();
     // x W_x^T + b = sd * (xhat W_x^T + rstd * (mean * rowsum(W_x) + b)),  sd = 1 / rstd; X becomes the block's accumulator
     auto mix_x = [&]() {
@@ -909,7 +918,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) {
-          const float sd = 1.0f / rstd[q][tb];
+          const float sd = __builtin_amdgcn_rcpf(rstd[q][tb]);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             X[q][j][tb] *= sd;
@@ -995,35 +1004,25 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         release();
         TSTOP(3);
       };
-      // The stylized rows of the three conditions go to gbuf slots 1-3 and come back into the panels when their MIX unit
-      // runs (held in registers beside the queries' accumulator they cost ~120 spilled registers per condition)
+      // All four units that read xhat first (the residual stream is dead between the block's LayerNorm and its accumulator:
+      // nothing of X is live beside the queries), then the three MIX units.  The stylized rows of the three conditions go to
+      // gbuf slots 1-3 and come back into the panels when their MIX unit runs (held in registers beside the queries'
+      // accumulator they cost ~120 spilled registers per condition); each image is requested BEFORE the barrier that frees the
+      // panels, so that its L2 latency runs while the wave waits for the others.  Accumulation order into X as in rg_seq.hip.
       PanelRegs t;
       cross(0);
-      mix_x();
-      barx();                                   // every wave is done reading xhat
-      restore_issue(t, 1);
-      restore_finish(t);
-      barx();
-      gemm_unit(X, SITE(6));                    // += W_text h_text
-      barx();                                   // every wave is done reading h_text
-      restore_issue(t, 0);                      // xhat again, landing while the accumulator goes out
-      store_R(X);
-      restore_finish(t);
-      barx();
       cross(1);
       cross(2);
-      restore_issue(t, 2);
-      load_R(X);
-      barx();                                   // every wave is done reading xhat
-      restore_finish(t);
-      drained();
-      barx();
-      gemm_unit(X, SITE(6));                    // += W_audio h_audio
-      barx();
-      restore_issue(t, 3);
-      restore_finish(t);
-      barx();
-      gemm_unit(X, SITE(6));                    // += W_spk h_spk
+      mix_x();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        restore_issue(t, 1 + c);
+        barx();                                 // every wave is done reading the panels (xhat; h of condition c - 1)
+        restore_finish(t);
+        drained();
+        barx();
+        gemm_unit(X, SITE(6));                  // += W_c h_c  (text, audio, speaker)
+      }
     }
     if (dl && a.dump_stage == 3) dump(X);
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
-__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return rg_pack2_bf16(lo, hi); }
 // GELU (erf form), erf by Abramowitz-Stegun 7.1.26 (abs. error 1.5e-7): as the bf16 path of rg_gemm
 __device__ __forceinline__ float gelu_fast(float v) {
   const float x = fabsf(v) * 0.70710678118654752440f;
