@@ -33,6 +33,11 @@ enum rg_status {
   RG_ERR_NO_DEVICE = -3
 };
 
+/* ABI version of THIS header: bumped whenever an argument block (rg_seq_args, ...) or an entry point changes shape.  A caller
+ * compares it with rg_version() of the library it loaded (rag-gesture_amd/capi.py load_library does and refuses a mismatch).
+ * 110 (round 6): rg_seq_args gains `form`; rg_seqx_forward, rg_lane_form.  100 -> 105 were the unversioned states of rounds
+ * 1-5 (round 5 changed rg_seq_args -- gbuf in, l0 / l1 out -- and the afrag layout without a bump: ADVICE r05). */
+#define RG_VERSION 110
 int rg_version(void);
 int rg_create(rg_handle** out, int device);
 void rg_destroy(rg_handle* h);
@@ -328,6 +333,8 @@ typedef struct rg_seq_args {
   float* dump;
   float* xbuf;             /* rg_seq2_forward: fp32 [workgroups][2][8][12][64][4] round trips of the two sequences' tiles; rg_seq_forward: unused */
   void* gbuf;              /* rg_seq2_forward: bf16 [workgroups][4][2][48 KiB] panel images; rg_seq_forward: unused */
+  const int* form;         /* rg_seqx_forward: DEVICE flag of the launching lane (rg_lane_form): 0 = two sequences per workgroup
+                              as rg_seq2_forward, 1 = one per workgroup as rg_seq_forward; the other two entry points ignore it */
   int L, B, T, S;          /* layers, clips, tokens, steps in pstream / ustream */
   int step, step_b, split; /* clips [0, split) at step, clips [split, B) at step_b */
   int dump_stage, dump_layer;
@@ -338,6 +345,20 @@ typedef struct rg_seq_args {
 
 int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);
 int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);
+
+/* The same forward with the launch form chosen ON THE DEVICE when the launch starts (csrc/rg_seqx.hip): launched with the
+ * grid of the one-sequence form, it runs rg_seq2_forward's workgroups (the surplus ones leave at once) or rg_seq_forward's,
+ * as args->form says -- same bits either way.  rg_lane_form is the arbitration in front of it, on the same stream: state is
+ * int [nlanes][RG_LANE_STRIDE] in device memory (one 128-byte line per lane, written by that lane's launches only),
+ * zero-initialised by the caller and shared by the lanes (streams) of one pipeline; state[l][0] = workgroups lane l's current
+ * launches hold, state[l][1] = lane l's flag (args->form = &state[l][1]).  The lane takes the wide form
+ * (wide_wgs workgroups) when the other lanes' workgroups + wide_wgs <= budget (the chip's compute units), else the narrow one
+ * (narrow_wgs); narrow_wgs == wide_wgs publishes a fixed-form launch's load, 0 / 0 an idle lane (the end of a chain).
+ * Nothing in the reference corresponds to this: its launches are whatever PyTorch eager issues
+ * (mogen/models/architectures/diffusion_architecture.py:283-452 drives one batch at a time). */
+#define RG_LANE_STRIDE 32
+int rg_seqx_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);
+int rg_lane_form(rg_handle* h, int* state, int lane, int nlanes, int narrow_wgs, int wide_wgs, int budget, void* stream);
 
 /* Sequence-stationary body-part VAE encoder: the whole skip-transformer stack of `TransformerVAE.encode_to_dist`
  * (mogen/models/transformers/gesture_vae.py:111-193: chunk sequences of frame_chunk_size frames + the two distribution

@@ -71,16 +71,20 @@ def main():
     ap.add_argument("--tag", default=None)
     ap.add_argument("--pairs", action="store_true", help="one workgroup per clip in every rg_seq launch of the asynchronous passes")
     ap.add_argument("--batch-lanes", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=2, help="denoiser depth (8: the benchmarked size)")
+    ap.add_argument("--db", type=int, default=512)
+    ap.add_argument("--model-kwargs", default="{}", help="JSON: more constructor arguments (dynamic_forms, ...)")
     a = ap.parse_args()
     rg = importlib.import_module("rag-gesture_amd")
     if a.old:
         rg.pipeline.MotionDiffusion._graph_run = old_graph_run
     dev = torch.device("cuda", 0)
-    cfg = rg.synth.default_model_cfg(num_layers=2)
+    cfg = rg.synth.default_model_cfg(num_layers=a.layers)
     vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
-    db = rg.synth.SyntheticDataset(512, seed=11, device=dev, feat_device=dev)
+    db = rg.synth.SyntheticDataset(a.db, seed=11, device=dev, feat_device=dev)
     model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=db, device=dev,
-                                  calibrate_lanes=a.calibrate, **({} if a.batch_lanes is None else dict(batch_lanes=a.batch_lanes)))
+                                  calibrate_lanes=a.calibrate, **({} if a.batch_lanes is None else dict(batch_lanes=a.batch_lanes)),
+                                  **json.loads(a.model_kwargs))
     model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
     model.eval()
     model.use_graphs = not a.no_graphs
@@ -134,8 +138,9 @@ def main():
         for i, (g, w) in enumerate(zip(got, want)):
             for k in KEYS:
                 if not np.array_equal(g[k], w[k]):
+                    clips = [int(c) for c in np.nonzero((g[k] != w[k]).reshape(g[k].shape[0], -1).any(axis=1))[0]]
                     miss.append(dict(batch=i, key=k, max_abs=float(np.nanmax(np.abs(g[k].astype(np.float64) - w[k]))),
-                                     n=int((g[k] != w[k]).sum()), of=int(w[k].size)))
+                                     n=int((g[k] != w[k]).sum()), of=int(w[k].size), clips=clips))
         row = dict(rep=rep, ok=not miss and len(got) == len(want), mismatches=miss[:6])
         bad += not row["ok"]
         rows.append(row)

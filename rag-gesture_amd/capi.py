@@ -42,6 +42,15 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(rg_[a-z0-9_]+)\s*\(", text)))
 
 
+def header_version():
+    """RG_VERSION of include/rg_gesture.h."""
+    with open(HEADER_PATH) as f:
+        m = re.search(r"^#define\s+RG_VERSION\s+(\d+)", f.read(), flags=re.M)
+    if not m:
+        raise RgError("include/rg_gesture.h defines no RG_VERSION")
+    return int(m.group(1))
+
+
 _SCALARS = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint, "int64_t": ctypes.c_int64,
             "float": ctypes.c_float, "double": ctypes.c_double}
 
@@ -79,6 +88,11 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise RgError("HIP extension not built: %s is missing (run __graft_entry__.build())" % LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
+        _lib.rg_version.restype = ctypes.c_int
+        want, got = header_version(), _lib.rg_version()
+        if want != got:      # (argument blocks are passed by pointer: a library built against another header would misread them silently)
+            _lib = None
+            raise RgError("%s is ABI version %d, include/rg_gesture.h is %d: rebuild (__graft_entry__.build())" % (LIB_PATH, got, want))
         for name, (restype, argtypes) in header_prototypes().items():
             fn = getattr(_lib, name, None)
             if fn is not None:

@@ -1,7 +1,7 @@
 // Handle lifetime + error reporting for the C ABI (include/rg_gesture.h).
 #include "rg_common.h"
 
-extern "C" int rg_version(void) { return 100; }
+extern "C" int rg_version(void) { return RG_VERSION; }
 
 extern "C" int rg_create(rg_handle** out, int device) {
   if (!out) return RG_ERR_INVALID;

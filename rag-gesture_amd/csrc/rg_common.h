@@ -68,13 +68,35 @@ static inline int rg_grid_1d(int64_t work_items, int block) {
   return (int)g;
 }
 
+// A kernel that says this is allocated all 256 vector registers per wave whatever it uses (the clobber raises its register
+// count): with two waves per SIMD (512 threads, one workgroup per compute unit) NOTHING else can be resident on its SIMDs.
+// Why (round 6, NOTEBOOK 11.3): rg_seq2_kernel went from 251 to 247 registers, 16 per SIMD came free, waves of the pipeline's
+// small kernels (8-16 registers) moved in beside it -- and one workgroup in ~10^5 (two clips of a batch) came out wrong, in 10
+// of 10 full-depth runs of profiles/race_stress.py; with all 256 allocated: 0 of 8, same code.  Which instruction misbehaves
+// beside a foreign wave is not known (the two-conversion bf16 pack fails the same way, so it is not the packed conversion;
+// round 4 met the same signature and blamed packed fp32 arithmetic, build.py).  Every sequence-stationary kernel owns its SIMDs.
+#define RG_OWN_THE_SIMD() asm volatile("; v255 reserved: the kernel's waves fill their SIMDs" ::: "v255")
+
 // Two fp32 -> one dword of packed bf16 (lo in bits 0-15), round-to-nearest-even: ONE v_cvt_pk_bf16_f32.  (Written as two scalar
 // conversions + shift + or, the compiler emits two v_cvt_pk_bf16_f32, a shift and an SDWA or: four VALU instructions per pair,
 // ~10 % of the vector instructions of the sequence-stationary kernels' epilogues.)  Same rounding, same bits.
 typedef __attribute__((ext_vector_type(2))) float rg_f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 rg_bf16x2;
-__device__ __forceinline__ unsigned rg_pack2_bf16(float lo, float hi) {
+__device__ __forceinline__ unsigned rg_pack2_bf16_one(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(rg_f32x2{lo, hi}, rg_bf16x2));
+}
+// The same value from two conversions whose HIGH result halves are never used (what every kernel did until round 6).
+__device__ __forceinline__ unsigned rg_pack2_bf16_two(float lo, float hi) {
+  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+// Kernels whose workgroups own their SIMDs outright (two waves x 256 registers: rg_seq2, rg_venc) define RG_PACK2_ONE before
+// including this header; every other kernel keeps the two-conversion form -- see build.py NO_PACKED_FP32 for why.
+__device__ __forceinline__ unsigned rg_pack2_bf16(float lo, float hi) {
+#if defined(RG_PACK2_ONE) || defined(RG_PACK2_ONE_EVERYWHERE)
+  return rg_pack2_bf16_one(lo, hi);
+#else
+  return rg_pack2_bf16_two(lo, hi);
+#endif
 }
 
 // GELU (erf form, torch's default) for the fused kernels' epilogues:  GELU(v) = max(v, 0) - |v| h(x),  x = |v| / sqrt(2),

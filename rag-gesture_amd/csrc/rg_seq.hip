@@ -27,6 +27,7 @@
 // reference: mogen/models/transformers/diffusion_transformer.py:105-127 (DecoderLayer), :74-87 (FFN), :620-668 (forward);
 // mogen/models/attentions/efficient_attention.py:23-45, 62-102; mogen/models/utils/stylization_block.py:29-40;
 // mogen/models/transformers/raggesture.py:1041-1085 (classifier-free row doubling).
+#define RG_PACK2_ONE      // (the kernel owns its SIMDs, RG_OWN_THE_SIMD: rg_common.h rg_pack2_bf16)
 #include "rg_common.h"
 #include <type_traits>
 
@@ -811,8 +812,10 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
 #endif
 }
 
-__global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#undef LANE_LOCAL
+
+// The work of workgroup `block` of a launch of (pairs ? B : 2 B) workgroups.
+__device__ __forceinline__ void seq_block(const rg_seq_args& a, const int block, const int pairs, unsigned char* const smem) {
   const int B = a.B;
   // Workgroup -> sequence(s).
   // pairs == 0: one workgroup per sequence.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one,
@@ -823,17 +826,24 @@ __global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
   // of B workgroups then holds B compute units for 1.7 units of time instead of 2 B for 1.0, of which the classifier-free
   // half idles the last 0.3: 15 % less CU time per forward, for callers whose launches are narrow enough to run side by
   // side.  Every workgroup of the launch walks the same part of the stream at the same time.
-  int seq0 = blockIdx.x;
-  if (!a.pairs && (B & 3) == 0) {
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  int seq0 = block;
+  if (!pairs && (B & 3) == 0) {
+    const int x = block & 7, q = block >> 3;
     seq0 = x < 4 ? 4 * q + x : B + 4 * q + (x - 4);
   }
-  const int npass = a.pairs ? 2 : 1;
+  const int npass = pairs ? 2 : 1;
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     run_sequence(a, seq0 + pass * B, smem);
     __syncthreads();     // descriptors, panels and statistics of the pass are dead in every wave
   }
+}
+
+#ifndef RG_SEQ_BODY_ONLY      // (rg_seqx.hip includes this file for run_sequence / seq_block only)
+__global__ void __launch_bounds__(NTH) rg_seq_kernel(const rg_seq_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  RG_OWN_THE_SIMD();
+  seq_block(a, blockIdx.x, a.pairs, smem);
 }
 
 extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream) {
@@ -872,3 +882,4 @@ extern "C" int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* 
   }
   return RG_OK;
 }
+#endif  // RG_SEQ_BODY_ONLY

@@ -25,6 +25,9 @@
 // reference: mogen/models/transformers/diffusion_transformer.py:105-127 (DecoderLayer), :74-87 (FFN), :620-668 (forward);
 // mogen/models/attentions/efficient_attention.py:23-45, 62-102; mogen/models/utils/stylization_block.py:29-40;
 // mogen/models/transformers/raggesture.py:1041-1085 (classifier-free row doubling).
+#ifndef RG2_PACK_TWO       // (experiment switch: the two-conversion form here too)
+#define RG_PACK2_ONE      // the one-instruction bf16 pair (rg_common.h rg_pack2_bf16): ONLY because rg_seq2_kernel owns its SIMDs (RG_OWN_THE_SIMD below)
+#endif
 #include "rg_common.h"
 #include <type_traits>
 
@@ -493,6 +496,9 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #define RG2_REG_SITES 0xE7B
 #endif
 #define SITE(n) std::integral_constant<int, n>()
+  // (Round 6 tried the same loop k-step-major with the panel fragment outermost -- four weight quads per k-step, every panel
+  //  fragment re-read 20 MFMAs ahead of its next use instead of 5, no read bursts: 1 408 against 1 364 us per launch, the
+  //  weights' lead shrinks from 1.5 k-steps to 1; NOTEBOOK 11.)
   auto gemm_unit = [&](Acc2& acc, auto site) {
     if constexpr (((RG2_REG_SITES) >> decltype(site)::value) & 1) gemm_frags_reg(acc, std::integral_constant<int, 4>(), std::false_type(), std::false_type(), nullptr);
     else gemm_frags(acc, std::integral_constant<int, 4>(), std::false_type(), std::false_type(), nullptr);
@@ -1104,23 +1110,29 @@ __device__ __forceinline__ void pair_clips(const int p, const int split, const i
   else { c0 = split + 2 * (p - n0); c1 = min(c0 + 1, B - 1); }
 }
 
-__global__ void __launch_bounds__(NTH) rg_seq2_kernel(const rg_seq_args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// workgroups of a launch: pairs per kind x (pairs ? 1 : 2)
+__device__ __host__ __forceinline__ int seq2_grid(const int B, const int split_in, const int pairs) {
+  const int split = split_in < 0 ? 0 : (split_in > B ? B : split_in);
+  const int npc = ((split + 1) >> 1) + ((B - split + 1) >> 1);
+  return pairs ? npc : 2 * npc;
+}
+// The work of workgroup `block` of such a launch.
+__device__ __forceinline__ void seq2_block(const rg_seq_args& a, const int block, unsigned char* const smem) {
   const int B = a.B, split = min(max(a.split, 0), B);
   const int npc = ((split + 1) >> 1) + ((B - split + 1) >> 1);     // pairs per kind
   // pairs == 0: one workgroup per pair (2 npc workgroups); dealt round-robin over the 8 XCDs, the conditional pairs to four of
   // them and the classifier-free pairs (which skip a third of the weight stream) to the other four, so that the workgroups
   // sharing an L2 walk the stream together (speed only).  pairs == 1: npc workgroups, each runs a conditional pair and then
   // the classifier-free pair of the same clips.
-  int p = blockIdx.x, kind0 = 0;
+  int p = block, kind0 = 0;
   if (!a.pairs) {
     if ((npc & 3) == 0) {
-      const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+      const int x = block & 7, q = block >> 3;
       kind0 = x >= 4;
       p = 4 * q + (x & 3);
     } else {
-      kind0 = blockIdx.x >= npc;
-      p = blockIdx.x - kind0 * npc;
+      kind0 = block >= npc;
+      p = block - kind0 * npc;
     }
   }
   int c0, c1;
@@ -1132,6 +1144,15 @@ __global__ void __launch_bounds__(NTH) rg_seq2_kernel(const rg_seq_args a) {
     run_pair(a, c0 + kind * B, c1 + kind * B, smem);
     __syncthreads();     // descriptors, panels and statistics of the pass are dead in every wave
   }
+}
+
+#ifndef RG_SEQ_BODY_ONLY      // (rg_seqx.hip includes this file for run_pair / seq2_block only)
+__global__ void __launch_bounds__(NTH) rg_seq2_kernel(const rg_seq_args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifndef RG2_SHARE_SIMD     // (experiment switch)
+  RG_OWN_THE_SIMD();
+#endif
+  seq2_block(a, blockIdx.x, smem);
 }
 
 extern "C" int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void* stream) {
@@ -1148,8 +1169,6 @@ extern "C" int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void*
     h->err = "rg_seq2_forward: cannot reserve LDS";
     return RG_ERR_HIP;
   }
-  const int split = a.split < 0 ? 0 : (a.split > a.B ? a.B : a.split);
-  const int npc = ((split + 1) >> 1) + ((a.B - split + 1) >> 1);
   rg_prof_rec rec;
   if (h->profiling) {   // bench.py roofline: HIP events around the launch (variant 3), algorithmic FLOPs of the T token rows
     auto get_ev = [&]() {
@@ -1164,7 +1183,7 @@ extern "C" int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void*
     rec.flops = a.B * (cond + unc);
     (void)hipEventRecord(rec.start, rg_stream(stream));
   }
-  hipLaunchKernelGGL(rg_seq2_kernel, dim3(a.pairs ? npc : 2 * npc), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
+  hipLaunchKernelGGL(rg_seq2_kernel, dim3(seq2_grid(a.B, a.split, a.pairs)), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
   if (h->profiling) {
     (void)hipEventRecord(rec.stop, rg_stream(stream));
@@ -1172,3 +1191,4 @@ extern "C" int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void*
   }
   return RG_OK;
 }
+#endif  // RG_SEQ_BODY_ONLY

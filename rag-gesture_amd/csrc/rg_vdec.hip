@@ -17,6 +17,7 @@
 // query live in 40 registers of its lane (S^T = K Q^T, one MFMA per 16 keys: the head's 16 dims fill half of the k = 32
 // contraction, the other half is zero on both operands), softmax over them, then O^T = V^T P with V^T fragments loaded
 // feature-major (the producer stores V transposed) in the order the score registers enumerate the keys.
+#define RG_PACK2_ONE      // (the kernel owns its SIMDs, RG_OWN_THE_SIMD: rg_common.h rg_pack2_bf16)
 #include "rg_common.h"
 #include <type_traits>
 
@@ -50,17 +51,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return rg_pack2_bf16(lo, hi); }
-// GELU (erf form), erf by Abramowitz-Stegun 7.1.26 (abs. error 1.5e-7): as the bf16 path of rg_gemm
-__device__ __forceinline__ float gelu_fast(float v) {
-  const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float e = 1.0f - pl * t * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
-  return 0.5f * v + 0.5f * fabsf(v) * e;
-}
+__device__ __forceinline__ float gelu_fast(float v) { return rg_gelu_erf(v); }
 // 8 fp32 values -> bf16 hi fragment and the bf16 residual fragment
 __device__ __forceinline__ void split_hl(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
   u32x4 h, l;
@@ -123,6 +114,7 @@ struct rg_vdec_group { rg_vdec_args a[4]; };   // up to four stacks (the four bo
 #endif
 
 __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
+  RG_OWN_THE_SIMD();
   const rg_vdec_args& a = grp.a[blockIdx.y];
   if ((int)blockIdx.x >= 4 * a.nseq) return;
 #ifdef RG_STAMPS
@@ -360,35 +352,31 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
     LANE_LOCAL();
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
-      float s = 0.f;
+      // (one pass: per-wave sum and sum of squares, variance = E[x^2] - mean^2 in fp32; rg_seq.hip row_stats)
+      float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
+      for (int j = 0; j < 4; ++j) {
+        s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(v[j][tb][r], v[j][tb][r], ss);
+      }
       s = xsum4(s);
-      const float mw = s * (1.0f / 64);
-      float m2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m2 = fmaf(v[j][tb][r] - mw, v[j][tb][r] - mw, m2);
-      m2 = xsum4(m2);
-      if (g4 == 0) *reinterpret_cast<float2*>(sStat + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, m2);
+      ss = xsum4(ss);
+      if (g4 == 0) *reinterpret_cast<float2*>(sStat + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, ss);
     }
     bar();
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) tot += sStat[(w * TP + 16 * tb + l15) * 2];
-      const float mu = tot * (1.0f / DM);
-      float m2 = 0.f;
+      float tot = 0.f, tot2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
         const float2 p = *reinterpret_cast<const float2*>(sStat + (w * TP + 16 * tb + l15) * 2);
-        const float d = p.x * (1.0f / 64) - mu;
-        m2 += p.y + 64.0f * d * d;
+        tot += p.x;
+        tot2 += p.y;
       }
+      const float mu = tot * (1.0f / DM);
       mean[tb] = mu;
-      rstd[tb] = rsqrtf(m2 * (1.0f / DM) + 1e-5f);
+      rstd[tb] = rsqrtf(fmaxf(fmaf(-mu, mu, tot2 * (1.0f / DM)), 0.f) + 1e-5f);
     }
   };
   // rows of the tile, T layout: row 16 tb + l15 (clamped into the tile for loads, skipped for stores)
@@ -458,16 +446,17 @@ __global__ void __launch_bounds__(NTH) rg_vdec_kernel(const rg_vdec_group grp) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kb][r]);
           mx = xmax4(mx);
+          const float nm2 = mx * -1.44269504088896340736f;
           float sum = 0.f;
 #pragma unroll
           for (int kb = 0; kb < 10; ++kb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              sc[kb][r] = __expf(sc[kb][r] - mx);
+              sc[kb][r] = rg_exp_sub(sc[kb][r], nm2);
               sum += sc[kb][r];
             }
           sum = xsum4(sum);
-          const float inv = 1.0f / sum;
+          const float inv = __builtin_amdgcn_rcpf(sum);
           f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int kp = 0; kp < 5; ++kp) {

@@ -24,6 +24,7 @@
 // and K go to the two panels as bf16; head h = the wave pair (2 h, 2 h + 1); each wave computes the head's 48 x 48 score
 // blocks S^T = K Q^T from the panels (contraction over the head's 128 features), masks keys of the other sequence / padding,
 // takes the softmax over keys per query (lane), and forms O^T = V^T P for its own 64 features from V's accumulators.
+#define RG_PACK2_ONE      // (two waves x >= 247 registers per SIMD: nothing shares this kernel's SIMDs; rg_common.h rg_pack2_bf16)
 #include "rg_common.h"
 #include <type_traits>
 
@@ -57,17 +58,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 __device__ __forceinline__ unsigned pack2(float lo, float hi) { return rg_pack2_bf16(lo, hi); }
-// GELU (erf form), erf by Abramowitz-Stegun 7.1.26 (abs. error 1.5e-7): as the bf16 path of rg_gemm
-__device__ __forceinline__ float gelu_fast(float v) {
-  const float x = fabsf(v) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-  float pl = fmaf(1.061405429f, t, -1.453152027f);
-  pl = fmaf(pl, t, 1.421413741f);
-  pl = fmaf(pl, t, -0.284496736f);
-  pl = fmaf(pl, t, 0.254829592f);
-  const float e = 1.0f - pl * t * __builtin_amdgcn_exp2f(x * x * -1.44269504088896340736f);
-  return 0.5f * v + 0.5f * fabsf(v) * e;
-}
+__device__ __forceinline__ float gelu_fast(float v) { return rg_gelu_erf(v); }
 // 8 fp32 values -> bf16 hi fragment and the bf16 residual fragment
 __device__ __forceinline__ void split_hl(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
   u32x4 h, l;
@@ -120,6 +111,7 @@ __device__ __forceinline__ void zero(Acc& a) {
 struct rg_venc_group { rg_venc_args a[4]; };   // up to four stacks (the four body parts) in one launch: blockIdx.y picks
 
 __global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_group grp) {
+  RG_OWN_THE_SIMD();
   const rg_venc_args& a = grp.a[blockIdx.y];
   if ((int)blockIdx.x >= (a.nseq + 1) / 2) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -327,40 +319,36 @@ __global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_group grp) {
     gemm_unit(acc, panel, TL);
   };
 
-  // ---- exact LayerNorm statistics of the three token rows a lane holds (rg_seq.hip: row_stats)
+  // ---- LayerNorm statistics of the three token rows a lane holds (rg_seq.hip: row_stats)
   auto row_stats = [&](const Acc& v, float (&mean)[3], float (&rstd)[3]) {
     LANE_LOCAL();
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
-      float s = 0.f;
+      // (one pass: per-wave sum and sum of squares, variance = E[x^2] - mean^2 in fp32; rg_seq.hip row_stats)
+      float s = 0.f, ss = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
+      for (int j = 0; j < 4; ++j) {
+        s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ss = fmaf(v[j][tb][r], v[j][tb][r], ss);
+      }
       s = xsum4(s);
-      const float mw = s * (1.0f / 64);
-      float m2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m2 = fmaf(v[j][tb][r] - mw, v[j][tb][r] - mw, m2);
-      m2 = xsum4(m2);
-      if (g4 == 0) *reinterpret_cast<float2*>(sStat + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, m2);
+      ss = xsum4(ss);
+      if (g4 == 0) *reinterpret_cast<float2*>(sStat + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, ss);
     }
     bar();
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
-      float tot = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) tot += sStat[(w * TP + 16 * tb + l15) * 2];
-      const float mu = tot * (1.0f / DM);
-      float m2 = 0.f;
+      float tot = 0.f, tot2 = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) {
         const float2 p = *reinterpret_cast<const float2*>(sStat + (w * TP + 16 * tb + l15) * 2);
-        const float d = p.x * (1.0f / 64) - mu;
-        m2 += p.y + 64.0f * d * d;
+        tot += p.x;
+        tot2 += p.y;
       }
+      const float mu = tot * (1.0f / DM);
       mean[tb] = mu;
-      rstd[tb] = rsqrtf(m2 * (1.0f / DM) + 1e-5f);
+      rstd[tb] = rsqrtf(fmaxf(fmaf(-mu, mu, tot2 * (1.0f / DM)), 0.f) + 1e-5f);
     }
   };
   // x = LayerNorm(x) * gamma + beta in place (gamma, beta = vectors gi, gi + 1 of parameter fragment ps), P0 = bf16(x)
@@ -482,17 +470,18 @@ __global__ void __launch_bounds__(NTH) rg_venc_kernel(const rg_venc_group grp) {
           for (int r = 0; r < 4; ++r)
             if ((kbits >> (12 * qb + 4 * kb + r)) & 1ull) mx = fmaxf(mx, sc[kb][qb][r]);
         mx = xmax4(mx);
+        const float nm2 = mx * -1.44269504088896340736f;
         float sum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = ((kbits >> (12 * qb + 4 * kb + r)) & 1ull) ? __expf(sc[kb][qb][r] - mx) : 0.f;
+            const float e = ((kbits >> (12 * qb + 4 * kb + r)) & 1ull) ? rg_exp_sub(sc[kb][qb][r], nm2) : 0.f;
             sc[kb][qb][r] = e;
             sum += e;
           }
         sum = xsum4(sum);
-        const float inv = 1.0f / sum;
+        const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb) sc[kb][qb] *= inv;
       }

@@ -246,7 +246,7 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, xcd_affine=True, engine=None,
-                 kv_grouped=True, seq_pairs=False, seq_duo=None):
+                 kv_grouped=True, seq_pairs=False, seq_duo=None, lane_dyn=None):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
@@ -295,7 +295,8 @@ class DenoiserSession:
             # time per forward with seq_pairs) -- for the wide launches of a pipeline that fills the chip with them; None: with
             # seq_pairs.  Narrow launches are faster (in latency) with one workgroup per sequence.  Same bits either way.
             duo = bool(seq_pairs) if seq_duo is None else bool(seq_duo)
-            self.sq = SQ.SeqForward(self, pairs=seq_pairs, duo=duo)
+            # lane_dyn: the session runs on one lane of a pipeline that arbitrates launch forms on the device (seqfwd.SeqForward)
+            self.sq = SQ.SeqForward(self, pairs=seq_pairs, duo=duo, lane_dyn=lane_dyn)
             return
         self.xa, self.xb, self.xc = f(M, D), f(M, D), f(M, D)
         # partial LayerNorm statistics: one (sum, sumsq) pair per row and producer column tile (128 wide)
@@ -407,6 +408,11 @@ class DenoiserSession:
         if key not in pool:
             pool[key] = torch.empty(*shape, device=self.w.dev, dtype=dtype)
         return pool[key]
+
+    def chain_end(self):
+        """End of a loop of forwards on this session (the samplers call it): a lane-arbitrated session marks its lane idle."""
+        if self.sq is not None:
+            self.sq.chain_end()
 
     # ------------------------------------------------------------------ per step
     def forward(self, x, step, step_b=None, split=None):

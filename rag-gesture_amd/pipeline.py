@@ -30,7 +30,7 @@ import types
 import torch
 import yaml
 
-from . import capi, denoiser, sampler, schedule as sched_mod, vae as vae_mod
+from . import capi, denoiser, sampler, schedule as sched_mod, seqfwd, vae as vae_mod
 
 MODELS = {}
 
@@ -344,7 +344,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=8,
-                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, **kwargs):
+                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, dynamic_forms=True, dynamic_budget=None, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -373,6 +373,11 @@ class MotionDiffusion(torch.nn.Module):
         self.sample_lanes = None if sample_lanes is None else int(sample_lanes)
         # asynchronous submission (see forward): off = the reference's semantics (results valid on the caller's stream)
         self.async_results, self.slots, self.max_inflight = bool(async_results), max(1, int(slots)), max(1, int(max_inflight))
+        # dynamic_forms: the denoiser launches of submit()'s chains choose their form ON THE DEVICE, launch by launch, from the
+        # workgroups the other lanes hold (include/rg_gesture.h: rg_lane_form / rg_seqx_forward): two sequences per workgroup
+        # while the chip is full, one per workgroup (0.6 of the time per launch) while the pipeline fills or drains.  Same bits.
+        self.dynamic_forms, self._lane_state = bool(dynamic_forms), None
+        self.dynamic_budget = None if dynamic_budget is None else int(dynamic_budget)     # workgroups the lanes may hold together (None: the chip's compute units)
         self.rotation_lanes = None     # submit(): lanes in the rotation of whole batches (None: batch_lanes / base_lanes); longform.py pins 1
         self.form_lanes = None         # ... and how many of their chains really run side by side (None: all of them); longform.py: 2
         self._slot, self._inflight, self._graph_owner, self._slot_done = 0, collections.deque(), {}, {}
@@ -462,6 +467,8 @@ class MotionDiffusion(torch.nn.Module):
         self._used_on(cur, *inputs.values())
         if not self.use_graphs:
             return fn(inputs)
+        if owner is not None:      # the graph captures the owner session's launches: one graph per launch form (_session)
+            key = key + self._form_tag(self._session_opts(owner[0], owner[1], owner[2]))
         ent = self._graphs.pop(key, None)
         if ent is not None:
             self._graphs[key] = ent                               # most recently used goes last
@@ -545,28 +552,52 @@ class MotionDiffusion(torch.nn.Module):
     #                                       ten batch lanes x two slots x three roles must fit: an evicted session re-captures its graphs)
 
     def _session(self, B, role="sample", lane=0):
-        key = (B, role, lane, self._slot)
+        # The launch form the CURRENT rotation resolves to is part of the key (and of the keys of the graphs that capture the
+        # session's launches, _graph_run): a long-form run that pins two lanes after a four-lane run, base and guided batches
+        # of one size on one lane, a synchronous forward() between submit()s each get the session of their own form instead
+        # of whichever was built first.  Sessions are never dropped while their launches may be in flight.
+        opts = self._session_opts(B, role, lane)
+        key = (B, role, lane, self._slot) + self._form_tag(opts)
         if key not in self._sessions:
             while len(self._sessions) >= self.MAX_SESSIONS:      # evict the least recently used session and its graphs
                 old = next(iter(self._sessions))
+                torch.cuda.synchronize()                         # (nothing of it is in flight when its buffers go)
                 del self._sessions[old]
-                for gk in [g for g, o in self._graph_owner.items() if o == old]:
+                for gk in [g for g, o in self._graph_owner.items() if o == old[:4]]:
                     self._graphs.pop(gk, None)
                     del self._graph_owner[gk]
-            opts = dict(self.session_options)
-            if opts.get("seq_pairs", "auto") == "auto":
-                opts["seq_pairs"], duo = self._seq_form_auto(B)
-                if opts.get("seq_duo") is None:
-                    opts["seq_duo"] = duo
-                if opts["seq_pairs"] and opts["seq_duo"] and role == "invert":
-                    # an inversion ALONE runs only while the pipeline fills (in the steady state it shares the launches of a
-                    # pending batch's sampling): the chip is emptying or empty then, so the classifier-free pairs get workgroups
-                    # of their own (B workgroups for 1.6 ms instead of B / 2 for 2.6 ms per launch; same bits)
-                    opts["seq_pairs"], opts["seq_duo"] = False, True
             self._sessions[key] = denoiser.DenoiserSession(self.model.weights, B, **opts)
         else:
             self._sessions[key] = self._sessions.pop(key)        # most recently used goes last
         return self._sessions[key]
+
+    LANE_SLOTS = 32          # lanes the shared arbitration state has room for
+
+    @staticmethod
+    def _form_tag(opts):
+        return (bool(opts.get("seq_pairs")), opts.get("seq_duo"), "lane_dyn" in opts)
+
+    def _session_opts(self, B, role, lane):
+        """Constructor options of the session (B, role, lane): the launch form resolved from the CURRENT rotation."""
+        opts = dict(self.session_options)
+        if opts.get("seq_pairs", "auto") == "auto":
+            opts["seq_pairs"], duo = self._seq_form_auto(B)
+            if opts.get("seq_duo") is None:
+                opts["seq_duo"] = duo
+            if opts["seq_pairs"] and opts["seq_duo"] and role == "invert":
+                # an inversion ALONE runs only while the pipeline fills (in the steady state it shares the launches of a
+                # pending batch's sampling): the chip is emptying or empty then, so the classifier-free pairs get workgroups
+                # of their own (B workgroups for 1.6 ms instead of B / 2 for 2.6 ms per launch; same bits)
+                opts["seq_pairs"], opts["seq_duo"] = False, True
+        cob = self._cob
+        seq = opts.get("engine") != "chain" and getattr(self.model.weights, "seq_streams", None) is not None
+        if (self.dynamic_forms and seq and self.async_results and cob is not None and cob.get("lane") is not None
+                and 0 <= lane < self.LANE_SLOTS and "lane_dyn" not in opts):
+            if self._lane_state is None:
+                self._lane_state = torch.zeros(self.LANE_SLOTS, seqfwd.LANE_STRIDE, device=self.device, dtype=torch.int32)
+            cus = self.dynamic_budget or torch.cuda.get_device_properties(self.device).multi_processor_count
+            opts["lane_dyn"] = (self._lane_state, lane, self.LANE_SLOTS, cus)
+        return opts
 
     def _seq_form_auto(self, B, cus=None):
         """(seq_pairs, seq_duo) of a session of B clips: the WIDEST launch form that still fits the chip beside the other lanes'
@@ -981,8 +1012,12 @@ class MotionDiffusion(torch.nn.Module):
     def flush(self):
         """Finish the pending batches of submit() (their sampling loops alone) and return every result not handed out yet,
         in submission order."""
-        for pid in sorted(self._pend, key=lambda p: self._pend[p].seq):
-            self._ready.append(self._finish_alone(self._pend.pop(pid)))
+        cob, self._cob = self._cob, dict(lane=0)     # (the draining chains are chains of the pipeline: their sessions publish
+        try:                                          #  the workgroups they hold to the launch-form arbitration, _session_opts)
+            for pid in sorted(self._pend, key=lambda p: self._pend[p].seq):
+                self._ready.append(self._finish_alone(self._pend.pop(pid)))
+        finally:
+            self._cob = cob
         out = list(self._ready)
         self._ready.clear()
         return out
@@ -1062,12 +1097,15 @@ class MotionDiffusion(torch.nn.Module):
         guided = pend.use_insertion_guidance
         gi, lr = tuple(int(v) for v in pend.guidance_iters), float(pend.guidance_lr)
         work = []
-        for lane, stream, b0, b1, ex in lanes:         # front end (caller's stream): conditions of the shared sessions
+        for lane, stream, b0, b1, ex in lanes:         # front end (caller's stream): inputs of the shared sessions
             Bl = b1 - b0
             Ep, cat = self._exemplar_inputs(st, ex, main)
             okey = (Bl + Ep, "cobatch", lane, self._slot)
             sess = self._session(Bl + Ep, "cobatch", lane)
             eqm = {c: pad_rows(torch.stack([st.qmask[b] for b, _ in ex]), Ep) for c in denoiser.CONDS}
+            # (on the caller's stream.  Round 6 moved these projections in front of the chain on the LANE's stream -- with
+            #  device-arbitrated launch forms the caller's stream paces the pipeline, profiles/r06k_timed_region.txt -- and got
+            #  32.5-33.6 instead of 30.9-31.4 ms per step AND two unverified runs in four: profiles/r06m_ab.txt.  Removed.)
             self._set_conditions_pair(
                 sess, ("cond2", Bl, Ep, lane, self._slot), okey,
                 (pend.word[b0:b1], pend.audio[b0:b1], pend.spk[b0:b1], pend.motion_mask[b0:b1], {c: pend.qmask[b0:b1] for c in denoiser.CONDS}),

@@ -31,6 +31,7 @@ def ddim_sample_loop(sess, x, in_seq=None, inseq_noise=None):
     S = sess.w.schedule.num_timesteps
     for i in range(S - 1, -1, -1):
         _step(sess, x, i, in_seq, None if in_seq is None else inseq_noise[i])
+    sess.chain_end()
     return x
 
 
@@ -41,6 +42,7 @@ def p_sample_loop(sess, x, noise):
     for i in range(S - 1, -1, -1):
         sess.forward(x, i)
         sess.cfg_ddpm(x, x, i, noise[i])
+    sess.chain_end()
     return x
 
 
@@ -53,6 +55,7 @@ def ddim_reverse_sample_loop(sess, x, out):
         sess.forward(cur, i)
         sess.cfg_ddim(cur, out[i], i, sch.c_next_a[i], sch.c_next_b[i])   # the update writes level i in place of a copy
         cur = out[i]
+    sess.chain_end()
     x.copy_(cur)
     return out
 
@@ -70,6 +73,7 @@ def ddim_guided_sample_loop(sess, x, inverted, guidance_iters, guidance_lr, inse
             in_seq = inverted[i]
             h.call("guidance_update", x, in_seq, sess.B * w.T, w.D, int(guidance_iters[i]), float(guidance_lr))
         _step(sess, x, i, in_seq, None if in_seq is None else inseq_noise[i])
+    sess.chain_end()
     return x
 
 
@@ -98,6 +102,7 @@ def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None
         sess.forward(x_all, i, step_b=k, split=n_a)
         sess.cfg_ddim_rows(0, n_a, xa, xa, i, sch.c_prev_a[i], sch.c_prev_b[i])
         sess.cfg_ddim_rows(n_a, n_b, xb, xb, k, sch.c_next_a[k], sch.c_next_b[k], x_out2=out_b[k])
+    sess.chain_end()
     return x_all, out_b
 
 

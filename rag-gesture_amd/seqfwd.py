@@ -21,11 +21,12 @@ UPL = 16
  U_FFO) = range(16)
 CONDS = ("xf_text", "xf_audio", "xf_spk")
 _vp = ctypes.c_void_p
+LANE_STRIDE = 32          # include/rg_gesture.h: RG_LANE_STRIDE (ints per lane record of the launch-form arbitration state)
 
 
 class SeqArgs(ctypes.Structure):
     _fields_ = [("wstream", _vp), ("pstream", _vp), ("ustream", _vp), ("afrag", _vp), ("x", _vp), ("tbias", _vp),
-                ("src_mask", _vp), ("qmask", _vp), ("head", _vp), ("dump", _vp), ("xbuf", _vp), ("gbuf", _vp),
+                ("src_mask", _vp), ("qmask", _vp), ("head", _vp), ("dump", _vp), ("xbuf", _vp), ("gbuf", _vp), ("form", _vp),
                 ("L", ctypes.c_int), ("B", ctypes.c_int), ("T", ctypes.c_int), ("S", ctypes.c_int),
                 ("step", ctypes.c_int), ("step_b", ctypes.c_int), ("split", ctypes.c_int),
                 ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("pairs", ctypes.c_int)]
@@ -151,12 +152,17 @@ class SeqStreams:
 class SeqForward:
     """Buffers of one DenoiserSession for rg_seq_forward."""
 
-    def __init__(self, sess, pairs=False, duo=True):
+    def __init__(self, sess, pairs=False, duo=True, lane_dyn=None):
         """duo: two sequences of the same kind per workgroup (rg_seq2_forward: every streamed weight fragment feeds both; the
         fp32 residual stream and two bf16 panel images take round trips through scratch buffers in L2) instead of one
         (rg_seq_forward) -- same bits;
         pairs: the classifier-free sequences run behind the conditional ones in the SAME workgroups (half as many workgroups,
-        ~1.6x as long) instead of in workgroups of their own."""
+        ~1.6x as long) instead of in workgroups of their own;
+        lane_dyn = (state int32 [n, LANE_STRIDE] on the device, lane, n, budget): the session belongs to lane `lane` of a pipeline whose
+        lanes share `state` (include/rg_gesture.h: rg_lane_form).  Every forward first publishes the workgroups it will hold;
+        a `duo` session then launches rg_seqx_forward, which runs this narrow form or -- when the other lanes leave room for
+        2 B workgroups -- one workgroup per sequence (0.6 of the time per launch: what counts while the pipeline fills or
+        drains), decided on the device when the launch starts.  `chain_end()` marks the lane idle."""
         w = sess.w
         self.sess, self.h, self.st = sess, sess.h, w.seq_streams
         B, dev = sess.B, w.dev
@@ -177,6 +183,15 @@ class SeqForward:
         a.xbuf = p(self.xbuf) if self.xbuf is not None else None
         a.gbuf = p(self.gbuf) if self.gbuf is not None else None
         self._fn = self.h.lib.rg_seq2_forward if self.duo else self.h.lib.rg_seq_forward
+        self.lane_dyn = None
+        if lane_dyn is not None:
+            state, lane, n, budget = lane_dyn
+            if not (state.is_cuda and state.dtype == torch.int32 and state.is_contiguous() and state.numel() >= LANE_STRIDE * n and 0 <= lane < n):
+                raise capi.RgError("lane_dyn: state must be a contiguous device int32 tensor [n, %d], 0 <= lane < n" % LANE_STRIDE)
+            self.lane_dyn = (state, int(lane), int(n), int(budget))
+            a.form = state.data_ptr() + 4 * (LANE_STRIDE * lane + 1)
+            if self.duo:
+                self._fn = self.h.lib.rg_seqx_forward
 
     def set_a(self, a_pre, o0, o1):
         """a_pre fp32 [L, 3, n, H, 32, 32] of the clips [o0, o1) of the session."""
@@ -191,8 +206,28 @@ class SeqForward:
         a.split = int(self.sess.B if split is None else split)
         a.dump = dump.data_ptr() if dump is not None else None
         a.dump_stage, a.dump_layer = int(dump_stage), int(dump_layer)
+        if self.lane_dyn is not None and not dump_stage:
+            state, lane, n, budget = self.lane_dyn
+            B = self.sess.B
+            wide = 2 * B
+            if self.duo:
+                sp = max(0, min(B, a.split))
+                npc = (sp + 1) // 2 + (B - sp + 1) // 2
+                narrow = npc if a.pairs else 2 * npc
+            else:
+                narrow = wide = B if a.pairs else 2 * B
+            self.h.call("lane_form", state, lane, n, narrow, wide, budget)
         s = torch.cuda.current_stream().cuda_stream
-        rc = self._fn(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
+        fn = self._fn
+        if dump_stage and self.lane_dyn is not None and self.duo:      # diagnostics: the fixed two-sequence form
+            fn = self.h.lib.rg_seq2_forward
+        rc = fn(self.h._h, ctypes.byref(a), ctypes.c_void_p(s))
         if rc != 0:
             raise capi.RgError("rg_seq_forward failed (%d): %s" % (rc, self.h.lib.rg_last_error(self.h._h).decode()))
         return self.sess.head
+
+    def chain_end(self):
+        """The lane's chain of forwards is over (sampler loops call this): it holds no workgroups."""
+        if self.lane_dyn is not None:
+            state, lane, n, budget = self.lane_dyn
+            self.h.call("lane_form", state, lane, n, 0, 0, budget)

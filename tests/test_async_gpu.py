@@ -349,3 +349,48 @@ def test_pipelines_are_bit_stable_under_stream_jitter(rg, use_graphs, calibrate,
     assert model.lane_report["streams"] == n_lanes + 2 and len(model._lane_streams) == n_lanes and model._search_stream is not None
     if use_graphs:
         assert any(k[0] == "dec" and k[-1] >= 0 for k in model._graphs), "decode graphs are per tail lane"
+
+
+@pytest.mark.parametrize("dynamic_forms", [False, True])
+def test_full_depth_pipeline_is_bit_stable_under_load(rg, dynamic_forms):
+    """The benchmarked size (8 layers, 16 clips per batch, 48 exemplars, four batch lanes) through submit() / flush(), three
+    passes of twelve batches, every clip of every batch against its synchronous forward -- the fill and drain batches too,
+    which bench.py's own check (the last four batches) never sees.  This is the test that caught round 6's failure: with
+    248 of 256 vector registers per wave rg_seq2_kernel left room on its SIMDs for waves of the pipeline's small kernels,
+    and beside them one workgroup in ~10^5 (two clips of a batch) came out wrong -- only at full depth, only under load
+    (csrc/rg_common.h RG_OWN_THE_SIMD).  Also with the launch forms arbitrated on the device (rg_seqx_forward)."""
+    dev = torch.device("cuda", 0)
+    cfg = rg.synth.default_model_cfg(num_layers=8)
+    vae_cfgs = rg.synth.synth_vae_cfgs(decoder_arch="all_encoder")
+    db = rg.synth.SyntheticDataset(4096, seed=11, device=dev, feat_device=dev)
+    model = rg.build_architecture(rg.synth.reference_style_model_cfg(cfg, vae_cfgs, with_retrieval=True), database=db, device=dev,
+                                  calibrate_lanes=False, dynamic_forms=dynamic_forms)
+    model.load_state_dict(rg.synth.synth_full_state(0, cfg, vae_cfgs))
+    model.eval()
+    batches = _batches(rg, 16, 12, dev)
+    guided = dict(use_inversion=True, insertion_guidance=True, guidance_iters=GI, guidance_lr=0.1)
+
+    def args(i):
+        d = dict(batches[i])
+        d["trans"] = batches[i]["trans"].clone()
+        return dict(d, retrieval_method="discourse", inference_kwargs=dict(guided, noise_tape=rg.synth.NoiseTape(4700 + i)))
+
+    want = []
+    for i in range(len(batches)):
+        out = model(**args(i))
+        torch.cuda.synchronize()
+        want.append({k: out[k].clone() for k in KEYS})
+    model.async_results = True
+    for rep in range(3):
+        outs = []
+        for i in range(len(batches)):
+            out = model.submit(**args(i))
+            if out is not None:
+                outs.append(out)
+        outs += model.flush()
+        got = [{k: o[k].clone() for k in KEYS} for o in outs]
+        torch.cuda.synchronize()
+        _same(got, want, model, "full depth, pass %d, dynamic forms %s" % (rep, dynamic_forms))
+    forms = {k[1]: (s_.sq.duo, s_.sq.lane_dyn is not None) for k, s_ in model._sessions.items() if s_.sq is not None and k[1] == "cobatch"}
+    assert forms == {"cobatch": (True, dynamic_forms)}, forms
+

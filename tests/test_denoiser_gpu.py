@@ -241,6 +241,50 @@ def test_seq_forward_one_workgroup_per_clip_is_bit_identical(rg, setup, B):
     assert not torch.equal(outs[False, 1][0], outs[False, 1][2])
 
 
+@pytest.mark.parametrize("B,pairs", [(5, False), (16, False), (6, True)])
+def test_device_chosen_launch_form_is_bit_identical(rg, setup, B, pairs):
+    """rg_seqx_forward behind rg_lane_form (include/rg_gesture.h): a lane-arbitrated session runs two sequences per workgroup
+    while the other lanes' workgroups leave no room for one per sequence, and one per sequence when they do -- decided on the
+    device, launch by launch; whichever form runs, the bits are rg_seq_forward's.  The state the lanes share says what ran:
+    state[lane][0] = workgroups held, state[lane][1] = the form flag; chain_end() marks the lane idle."""
+    cfg, P, W = setup[8]
+    data = rg.synth.synth_batch(B, seed=81)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(9)).standard_normal((B, 43, 512)).astype(np.float32)).cuda()
+    mm = torch.ones(B, 43)
+    mm[:, [10, 21, 32]] = 0
+    mm[B - 1, 28:] = 0
+    cases = ((49, None, None), (23, 40, max(1, B // 3)), (0, None, None))
+    ref_sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=False, seq_duo=False)
+    ref_sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
+    ref = [ref_sess.forward(x, *c).clone() for c in cases]
+    n, lane, budget = 8, 3, 256
+    state = torch.zeros(n, rg.seqfwd.LANE_STRIDE, device="cuda", dtype=torch.int32)
+    sess = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=pairs, seq_duo=True, lane_dyn=(state, lane, n, budget))
+    sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
+    for others, want_wide in ((0, True), (budget - 2 * B + 1, False), (budget - 2 * B, True), (10 ** 6, False)):
+        state.zero_()
+        state[0, 0] = others                   # what another lane's launches hold
+        for c, r in zip(cases, ref):
+            out = sess.forward(x, *c).clone()
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all() and torch.equal(out, r), (B, pairs, others, c, (out - r).abs().max().item())
+            st = state.cpu()
+            sp = B if c[2] is None else c[2]
+            npc = (sp + 1) // 2 + (B - sp + 1) // 2
+            assert int(st[lane, 1]) == int(want_wide), (others, st[:, :2].tolist())
+            assert int(st[lane, 0]) == (2 * B if want_wide else (npc if pairs else 2 * npc)), (others, st[:, :2].tolist())
+        sess.chain_end()
+        torch.cuda.synchronize()
+        assert int(state[lane, 0]) == 0
+    # a fixed-form session (one workgroup per sequence) only publishes its load
+    state.zero_()
+    one = rg.denoiser.DenoiserSession(W, B, engine="seq", seq_pairs=False, seq_duo=False, lane_dyn=(state, 1, n, budget))
+    one.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, od.make_query_masks(mm))
+    assert torch.equal(one.forward(x, 49), ref[0]) and int(state[1, 0]) == 2 * B
+    one.chain_end()
+    assert int(state[1, 0]) == 0
+
+
 @pytest.mark.parametrize("grouped", [True, False])
 def test_condition_side_attention_matrices_vs_oracle(rg, parity, setup, grouped):
     """DenoiserSession.set_conditions: A[layer][condition][clip][head] = softmax_N(K)^T V (efficient_attention.py:74-90) of the
