@@ -33,8 +33,21 @@ ARCH = "gfx950"
 # the two denoiser kernels WITH packed fp32 (their workgroups own a whole compute unit: nothing shares their SIMDs) was measured
 # too: bit-identical, race_stress 40 / 40, and worth 0.5 % of a launch (2 574 vs 2 585 us) -- not taken.
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-mllvm", "-amdgpu-early-inline-all=true"] + NO_PACKED_FP32 + os.environ.get("RG_EXTRA_FLAGS", "").split()
+# Round 6: the effect above followed SIMD SHARING, not (only) packed arithmetic -- rg_seq2_kernel without a single v_pk_*_f32
+# failed the same way as soon as its register count left room for foreign waves on its SIMDs (csrc/rg_common.h
+# RG_OWN_THE_SIMD, NOTEBOOK 11.3).  The units below hold only kernels that own their SIMDs (256 registers per wave, two waves
+# per SIMD); their epilogues are written two-wide (rg_common.h rg_fma2 ...) and get the packed instructions.  Results do not
+# depend on the switch (every packed operation is the same IEEE operation per element).
+PACKED_FP32_UNITS = set(os.environ.get("RG_PACKED_UNITS", "rg_seq.hip rg_seq2.hip").split())
+BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+              "-mllvm", "-amdgpu-early-inline-all=true"]
+FLAGS = BASE_FLAGS + NO_PACKED_FP32 + os.environ.get("RG_EXTRA_FLAGS", "").split()
+
+
+def flags_for(src):
+    if os.path.basename(src) in PACKED_FP32_UNITS:
+        return BASE_FLAGS + os.environ.get("RG_EXTRA_FLAGS", "").split()
+    return FLAGS
 
 
 def _hipcc():
@@ -59,7 +72,7 @@ def _compile(src, hdr_mtime, force):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= hdr_mtime):
         return obj
-    cmd = [_hipcc()] + FLAGS + (["-DRG_STAMPS"] if DIAG else []) + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + flags_for(src) + (["-DRG_STAMPS"] if DIAG else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

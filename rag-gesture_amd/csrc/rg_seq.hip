@@ -425,13 +425,8 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     float* const sSt = sStat;
 #pragma unroll
     for (int tb = 0; tb < 3; ++tb) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s += (v[j][tb][0] + v[j][tb][1]) + (v[j][tb][2] + v[j][tb][3]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ss = fmaf(v[j][tb][r], v[j][tb][r], ss);
-      }
+      float s, ss;
+      rg_sum_sq16(v[0][tb], v[1][tb], v[2][tb], v[3][tb], s, ss);
       s = xsum4(s);
       ss = xsum4(ss);
       if (g4 == 0) *reinterpret_cast<float2*>(sSt + (wave * TP + 16 * tb + l15) * 2) = make_float2(s, ss);
@@ -513,22 +508,7 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
-        f32x4& q0 = q[2 * h][tb];
-        f32x4& q1 = q[2 * h + 1][tb];
-        float mx = fmaxf(fmaxf(fmaxf(q0[0], q0[1]), fmaxf(q0[2], q0[3])), fmaxf(fmaxf(q1[0], q1[1]), fmaxf(q1[2], q1[3])));
-        mx = xmax4(mx);
-        const float nm2 = mx * -1.44269504088896340736f;
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          q0[r] = rg_exp_sub(q0[r], nm2);
-          q1[r] = rg_exp_sub(q1[r], nm2);
-          sum += q0[r] + q1[r];
-        }
-        sum = xsum4(sum);
-        const float inv = __builtin_amdgcn_rcpf(sum);
-        q0 *= inv;
-        q1 *= inv;
+        rg_softmax32(q[2 * h][tb], q[2 * h + 1][tb]);
       }
   };
   // y = softmax(q) A for one head: T-layout out blocks 2 h, 2 h + 1 <- A fragments (hi, lo) of the head's two column

@@ -567,13 +567,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          s += (v[q][j][tb][0] + v[q][j][tb][1]) + (v[q][j][tb][2] + v[q][j][tb][3]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ss = fmaf(v[q][j][tb][r], v[q][j][tb][r], ss);
-        }
+        float s, ss;
+        rg_sum_sq16(v[q][0][tb], v[q][1][tb], v[q][2][tb], v[q][3][tb], s, ss);
         s = xsum4(s);
         ss = xsum4(ss);
         if (g4 == 0) *reinterpret_cast<float2*>(sSt + ((q * NW + wave) * TP + 16 * tb + l15) * 2) = make_float2(s, ss);
@@ -643,9 +638,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) {
           const float r = rstd[q][tb], nm = -mean[q][tb] * r;      // (v - mean) rstd as ONE fused multiply-add per value
-          const u32x2 p = u32x2{pack2(fmaf(v[q][j][tb][0], r, nm), fmaf(v[q][j][tb][1], r, nm)),
-                                pack2(fmaf(v[q][j][tb][2], r, nm), fmaf(v[q][j][tb][3], r, nm))};
-          *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) = p;
+          *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) = rg_norm4_bf16(v[q][j][tb], r, nm);
         }
     TSTOP(8);
   };
@@ -689,10 +682,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) {
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf(fmaf(v[q][j][tb][r], rstd[q][tb], nmr[q][tb]), gain[r], off[r]));
-          *reinterpret_cast<u32x2*>(Gw + (2 * slot + q) * PANEL + panel_off(l15, g4, j, tb)) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(Gw + (2 * slot + q) * PANEL + panel_off(l15, g4, j, tb)) = rg_styl4_bf16(v[q][j][tb], rstd[q][tb], nmr[q][tb], gain, off);
         }
     }
   };
@@ -708,10 +698,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int tb = 0; tb < 3; ++tb) {
-          float o[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = silu_f(fmaf(fmaf(v[q][j][tb][r], rstd[q][tb], nmr[q][tb]), gain[r], off[r]));
-          *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) = u32x2{pack2(o[0], o[1]), pack2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(smem + q * PANEL + panel_off(l15, g4, j, tb)) = rg_styl4_bf16(v[q][j][tb], rstd[q][tb], nmr[q][tb], gain, off);
         }
     }
   };
@@ -737,22 +724,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int tb = 0; tb < 3; ++tb) {
-        f32x4& q0 = q[2 * h][tb];
-        f32x4& q1 = q[2 * h + 1][tb];
-        float mx = fmaxf(fmaxf(fmaxf(q0[0], q0[1]), fmaxf(q0[2], q0[3])), fmaxf(fmaxf(q1[0], q1[1]), fmaxf(q1[2], q1[3])));
-        mx = xmax4(mx);
-        const float nm2 = mx * -1.44269504088896340736f;
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          q0[r] = rg_exp_sub(q0[r], nm2);
-          q1[r] = rg_exp_sub(q1[r], nm2);
-          sum += q0[r] + q1[r];
-        }
-        sum = xsum4(sum);
-        const float inv = __builtin_amdgcn_rcpf(sum);
-        q0 *= inv;
-        q1 *= inv;
+        rg_softmax32(q[2 * h][tb], q[2 * h + 1][tb]);
       }
   };
   // y = softmax(q) A for one head, IN PLACE: blocks 2 h, 2 h + 1 of q become those of y (the contraction runs over the head's
@@ -1051,8 +1023,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
             for (int j = 0; j < 4; ++j)
 #pragma unroll
               for (int tb = 0; tb < 3; ++tb)
-                gd[q][j][tb] = u32x2{pack2(gelu_fast(gg[q][j][tb][0]), gelu_fast(gg[q][j][tb][1])),
-                                     pack2(gelu_fast(gg[q][j][tb][2]), gelu_fast(gg[q][j][tb][3]))};
+                gd[q][j][tb] = rg_gelu4_bf16(gg[q][j][tb]);
           TSTOP(3);
         };
         ff1(g0, SITE(11));                      // (nothing held yet: the register form of the unit fits)

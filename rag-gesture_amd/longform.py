@@ -20,6 +20,8 @@ runs batch 1 per clip; per clip the results are the same (clips never interact i
 """
 import os
 
+import contextlib
+
 import torch
 
 from . import capi, dist as rg_dist, packing
@@ -80,6 +82,23 @@ def blend_window(prev, cur, overlap):
             torch.cat([pt[:, :-overlap], ct], 1))
 
 
+@contextlib.contextmanager
+def pinned_lanes(model, on, rotation, form=None):
+    """While a pipelined long-form pass runs, the model's submit() rotates over `rotation` lanes and chooses its launch forms
+    for `form` chains side by side; both settings are the caller's again afterwards -- also when retrieval, a capi.require or
+    an allocation fails in between (a shared model must not stay pinned)."""
+    before = (getattr(model, "rotation_lanes", None), getattr(model, "form_lanes", None))
+    if on:
+        model.rotation_lanes = rotation
+        if form is not None:
+            model.form_lanes = form
+    try:
+        yield
+    finally:
+        if on:
+            model.rotation_lanes, model.form_lanes = before
+
+
 class LongformSynthesizer:
     """model: a rag-gesture_amd MotionDiffusion.  `run(data, features, **inference flags)` mirrors the
     per-sample loop of tools/longform_synthesis.py and returns 30-fps numpy arrays cut to the sample length."""
@@ -107,9 +126,6 @@ class LongformSynthesizer:
         prev_latent, latents = None, []
         # the windows of ONE clip are a dependent chain (window k + 1 samples from window k's latent): they stay on one lane,
         # where window k + 1's exemplar inversion shares the denoiser launches of window k's sampling, instead of rotating
-        rot_before = getattr(self.model, "rotation_lanes", None)
-        if pipelined:
-            self.model.rotation_lanes = 1
 
         def take(out):
             cidx = state["n"]
@@ -123,39 +139,39 @@ class LongformSynthesizer:
                 gt = tuple(out[k].to(dev).float() for k in ("motion", "facial", "trans"))
                 state["gt_so_far"] = gt if cidx == 0 else blend_window(state["gt_so_far"], gt, self.overlap)
 
-        for cidx, (c0, c1) in enumerate(zip(starts, ends)):
-            t0, t1 = c0 / self.fps, c1 / self.fps
-            chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
-            capi.require(chunk["motion"].shape[1] == self.seqlen,
-                    "unsupported argument: requires chunk[\"motion\"].shape[1] == self.seqlen")
-            chunk["motion_length"] = [self.seqlen] * chunk["motion"].shape[0]
-            ann = window_annotations(data, t0, t1)
-            chunk.update(ann)
-            chunk.update(features(cidx, t0, t1, ann))
-            if "sample_name" in data:
-                chunk["sample_name"] = [data["sample_name"][0].replace("/0", "/%d" % cidx)]
-            chunk["retrieval_method"] = retrieval_method
-            ikw = dict(use_inversion=use_inversion, outpaint=outpaint, inversion_start_time=inversion_start_time,
-                       insertion_guidance=insertion_guidance, guidance_lr=guidance_lr, use_prev_latent=True,
-                       prev_latent=prev_latent)
-            if guidance_iters is not None:
-                ikw["guidance_iters"] = guidance_iters
-            if noise_tape is not None:
-                ikw["noise_tape"] = noise_tape
-            chunk["inference_kwargs"] = ikw
-            if pipelined:
-                out = self.model.submit(**chunk)
-                prev_latent = self.model.pending_latent()     # bound when the next window's sampling is queued
-                if out is not None:
+        with pinned_lanes(self.model, pipelined, rotation=1):      # (restored whatever happens in between: ADVICE r05)
+            for cidx, (c0, c1) in enumerate(zip(starts, ends)):
+                t0, t1 = c0 / self.fps, c1 / self.fps
+                chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
+                capi.require(chunk["motion"].shape[1] == self.seqlen,
+                        "unsupported argument: requires chunk[\"motion\"].shape[1] == self.seqlen")
+                chunk["motion_length"] = [self.seqlen] * chunk["motion"].shape[0]
+                ann = window_annotations(data, t0, t1)
+                chunk.update(ann)
+                chunk.update(features(cidx, t0, t1, ann))
+                if "sample_name" in data:
+                    chunk["sample_name"] = [data["sample_name"][0].replace("/0", "/%d" % cidx)]
+                chunk["retrieval_method"] = retrieval_method
+                ikw = dict(use_inversion=use_inversion, outpaint=outpaint, inversion_start_time=inversion_start_time,
+                           insertion_guidance=insertion_guidance, guidance_lr=guidance_lr, use_prev_latent=True,
+                           prev_latent=prev_latent)
+                if guidance_iters is not None:
+                    ikw["guidance_iters"] = guidance_iters
+                if noise_tape is not None:
+                    ikw["noise_tape"] = noise_tape
+                chunk["inference_kwargs"] = ikw
+                if pipelined:
+                    out = self.model.submit(**chunk)
+                    prev_latent = self.model.pending_latent()     # bound when the next window's sampling is queued
+                    if out is not None:
+                        take(out)
+                else:
+                    out = self.model(**chunk)
+                    prev_latent = out["prev_latentout"]
                     take(out)
-            else:
-                out = self.model(**chunk)
-                prev_latent = out["prev_latentout"]
-                take(out)
-        if pipelined:
-            for out in self.model.flush():
-                take(out)
-            self.model.rotation_lanes = rot_before
+            if pipelined:
+                for out in self.model.flush():
+                    take(out)
         capi.require(state["n"] == len(starts), "long-form synthesis: windows left in the pipeline")
         so_far, gt_so_far = state["so_far"], state["gt_so_far"]
         motion, facial, trans = so_far
@@ -206,9 +222,6 @@ class LongformSynthesizer:
         # window k + 1 samples from window k's latents: at most two window batches are ever busy (one sampling, the next one
         # inverting its exemplars).  They rotate over up to four lanes (as in round 4), and the launch forms are chosen for the
         # two chains that really run side by side, not for the model's whole rotation (pipeline._seq_form_auto)
-        rot_before, form_before = getattr(self.model, "rotation_lanes", None), getattr(self.model, "form_lanes", None)
-        if pipelined:
-            self.model.rotation_lanes, self.model.form_lanes = min(4, self.model.batch_lanes), 2
 
         def take(out):
             cidx, act = queued.pop(0)
@@ -224,61 +237,61 @@ class LongformSynthesizer:
                     gt = tuple(out[k][j:j + 1].to(dev).float() for k in ("motion", "facial", "trans"))
                     st["gt_so_far"] = gt if cidx == 0 else blend_window(st["gt_so_far"], gt, self.overlap)
 
-        pending, act_prev = None, None
-        for cidx in range(n_win):
-            act = [ci for ci in mine if cidx < len(state[ci]["starts"])]     # clips that still have a window cidx
-            chunks = []
-            for ci in act:
-                st = state[ci]
-                c0, c1 = st["starts"][cidx], st["ends"][cidx]
-                t0, t1 = c0 / self.fps, c1 / self.fps
-                data = st["data"]
-                chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
-                capi.require(chunk["motion"].shape[0] == 1 and chunk["motion"].shape[1] == self.seqlen,
-                        "unsupported argument: requires chunk[\"motion\"].shape[0] == 1 and chunk[\"motion\"].shape[1] == self.seqlen")
-                ann = window_annotations(data, t0, t1)
-                chunk.update(ann)
-                chunk.update(features(ci, cidx, t0, t1, ann))
-                chunk["sample_name"] = [data["sample_name"][0].replace("/0", "/%d" % cidx)] if "sample_name" in data \
-                    else ["clip%d/%d" % (ci, cidx)]
-                chunks.append(chunk)
-            # one batch: tensors concatenated along the clip dimension, per-clip lists chained
-            batch = {}
-            for k in chunks[0]:
-                v0 = chunks[0][k]
-                if torch.is_tensor(v0):
-                    batch[k] = torch.cat([c[k] for c in chunks], dim=0)
-                elif isinstance(v0, (list, tuple)):
-                    batch[k] = [x for c in chunks for x in c[k]]
+        with pinned_lanes(self.model, pipelined, rotation=min(4, self.model.batch_lanes), form=2):
+            pending, act_prev = None, None
+            for cidx in range(n_win):
+                act = [ci for ci in mine if cidx < len(state[ci]["starts"])]     # clips that still have a window cidx
+                chunks = []
+                for ci in act:
+                    st = state[ci]
+                    c0, c1 = st["starts"][cidx], st["ends"][cidx]
+                    t0, t1 = c0 / self.fps, c1 / self.fps
+                    data = st["data"]
+                    chunk = {k: data[k][:, c0:c1] for k in MOTION_KEYS + REPEAT_KEYS if k in data and torch.is_tensor(data[k])}
+                    capi.require(chunk["motion"].shape[0] == 1 and chunk["motion"].shape[1] == self.seqlen,
+                            "unsupported argument: requires chunk[\"motion\"].shape[0] == 1 and chunk[\"motion\"].shape[1] == self.seqlen")
+                    ann = window_annotations(data, t0, t1)
+                    chunk.update(ann)
+                    chunk.update(features(ci, cidx, t0, t1, ann))
+                    chunk["sample_name"] = [data["sample_name"][0].replace("/0", "/%d" % cidx)] if "sample_name" in data \
+                        else ["clip%d/%d" % (ci, cidx)]
+                    chunks.append(chunk)
+                # one batch: tensors concatenated along the clip dimension, per-clip lists chained
+                batch = {}
+                for k in chunks[0]:
+                    v0 = chunks[0][k]
+                    if torch.is_tensor(v0):
+                        batch[k] = torch.cat([c[k] for c in chunks], dim=0)
+                    elif isinstance(v0, (list, tuple)):
+                        batch[k] = [x for c in chunks for x in c[k]]
+                    else:
+                        batch[k] = v0
+                batch["motion_length"] = [self.seqlen] * len(act)
+                batch["retrieval_method"] = retrieval_method
+                if cidx == 0:
+                    prev = None
+                elif pipelined:
+                    prev = pending.select([act_prev.index(ci) for ci in act])    # bound when this window's sampling is queued
                 else:
-                    batch[k] = v0
-            batch["motion_length"] = [self.seqlen] * len(act)
-            batch["retrieval_method"] = retrieval_method
-            if cidx == 0:
-                prev = None
-            elif pipelined:
-                prev = pending.select([act_prev.index(ci) for ci in act])    # bound when this window's sampling is queued
-            else:
-                prev = torch.cat([state[ci]["prev"] for ci in act], dim=0)
-            ikw = dict(use_inversion=use_inversion, outpaint=outpaint, inversion_start_time=inversion_start_time,
-                       insertion_guidance=insertion_guidance, guidance_lr=guidance_lr, use_prev_latent=True, prev_latent=prev)
-            if guidance_iters is not None:
-                ikw["guidance_iters"] = guidance_iters
-            if noise_tape is not None:
-                ikw["noise_tape"] = noise_tape.for_clips(act) if hasattr(noise_tape, "for_clips") else noise_tape
-            batch["inference_kwargs"] = ikw
-            queued.append((cidx, act))
+                    prev = torch.cat([state[ci]["prev"] for ci in act], dim=0)
+                ikw = dict(use_inversion=use_inversion, outpaint=outpaint, inversion_start_time=inversion_start_time,
+                           insertion_guidance=insertion_guidance, guidance_lr=guidance_lr, use_prev_latent=True, prev_latent=prev)
+                if guidance_iters is not None:
+                    ikw["guidance_iters"] = guidance_iters
+                if noise_tape is not None:
+                    ikw["noise_tape"] = noise_tape.for_clips(act) if hasattr(noise_tape, "for_clips") else noise_tape
+                batch["inference_kwargs"] = ikw
+                queued.append((cidx, act))
+                if pipelined:
+                    out = self.model.submit(**batch)
+                    pending, act_prev = self.model.pending_latent(), act
+                    if out is not None:
+                        take(out)
+                else:
+                    take(self.model(**batch))
             if pipelined:
-                out = self.model.submit(**batch)
-                pending, act_prev = self.model.pending_latent(), act
-                if out is not None:
+                for out in self.model.flush():
                     take(out)
-            else:
-                take(self.model(**batch))
-        if pipelined:
-            for out in self.model.flush():
-                take(out)
-            self.model.rotation_lanes, self.model.form_lanes = rot_before, form_before
         capi.require(not queued, "long-form synthesis: windows left in the pipeline")
         results = {ci: self._finish(state[ci], with_gt) for ci in mine}
         if gather and td.is_available() and td.is_initialized() and td.get_world_size() > 1:

@@ -344,7 +344,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=8,
-                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, dynamic_forms=True, dynamic_budget=None, **kwargs):
+                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, dynamic_forms=False, dynamic_budget=None, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -376,6 +376,10 @@ class MotionDiffusion(torch.nn.Module):
         # dynamic_forms: the denoiser launches of submit()'s chains choose their form ON THE DEVICE, launch by launch, from the
         # workgroups the other lanes hold (include/rg_gesture.h: rg_lane_form / rg_seqx_forward): two sequences per workgroup
         # while the chip is full, one per workgroup (0.6 of the time per launch) while the pipeline fills or drains.  Same bits.
+        # OFF by default: measured on the headline run (profiles/r06s_ab.txt, r06m_ab.txt, r06n_ab.txt: 31.3-31.7 against
+        # 30.8-31.1 ms per step, median batch latency 266-270 against 279-286 ms) it buys latency, not throughput -- with the
+        # chains running wide the caller's stream (clip encode -> retrieval -> exemplar encode -> condition projections, in
+        # series, beside the lanes' launches) paces the pipeline instead of the chains (profiles/r06k_timed_region.txt).
         self.dynamic_forms, self._lane_state = bool(dynamic_forms), None
         self.dynamic_budget = None if dynamic_budget is None else int(dynamic_budget)     # workgroups the lanes may hold together (None: the chip's compute units)
         self.rotation_lanes = None     # submit(): lanes in the rotation of whole batches (None: batch_lanes / base_lanes); longform.py pins 1
