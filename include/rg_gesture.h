@@ -295,6 +295,18 @@ int rg_ln_guard(rg_handle* h, const float* stats, int rows, int nparts, int K, f
 int rg_linear_f32(rg_handle* h, const float* a, const float* w, const float* bias, float* out, int M,
                   int N, int K, int silu_in, int silu_out, void* stream);
 
+/* Condition side of the efficient cross attention, one launch per condition (csrc/rg_condkv.hip): for every clip b, layer l and
+ * head h,  A[l][b][h] = softmax_tokens(K_h)^T V_h  with  [K | V] = xhat_b W_l^T + bias_l
+ * (mogen/models/attentions/efficient_attention.py:74-90; xhat = the condition rows after the LayerNorm WITHOUT its affine,
+ * which is folded into W / bias: LN_l(x) W_l^T + b_l = xhat (W_l diag(gamma_l))^T + (b_l + W_l beta_l)).
+ * xhat bf16 [B][n_tok][512], w bf16 [L][1024 = key 512 | value 512][512], bias fp32 [L][1024]; out fp32: the A matrices of
+ * (layer 0, clip 0), [16 heads][32][32] per clip, layer l at out + l * layer_stride.  n_tok <= 512, 16 heads of 32.
+ * afrag_bf16 (or NULL): the same matrices once more as rg_seq_args.afrag of (layer 0, this condition, clip 0) -- bf16 MFMA
+ * A-operand fragments [8][2 heads][2 column blocks][64 lanes][8] per clip, layer l at + l * afrag_layer_stride elements.
+ * Replaces rg_gemm (K | V of two layers as fp32 [rows][2048]) + rg_kv_reduce per layer: nothing but A is written. */
+int rg_cond_kv(rg_handle* h, const void* xhat_bf16, const void* w_bf16, const float* bias, float* out, long long layer_stride,
+               void* afrag_bf16, long long afrag_layer_stride, int B, int n_tok, int L, void* stream);
+
 /* ---------------------------------------------------------------- one denoiser forward, sequence-stationary
  * ReGestureTransformer.forward at inference (raggesture.py:1041-1085 `forward_test` up to the CFG mix,
  * diffusion_transformer.py:620-668, :105-127 `DecoderLayer`, :74-87 `FFN`, efficient_attention.py:23-45, 62-102,

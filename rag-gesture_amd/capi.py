@@ -52,6 +52,7 @@ def header_version():
 
 
 _SCALARS = {"int": ctypes.c_int, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint, "int64_t": ctypes.c_int64,
+            "long long": ctypes.c_longlong,
             "float": ctypes.c_float, "double": ctypes.c_double}
 
 

@@ -161,6 +161,21 @@ class DenoiserWeights:
                     bs.append(f32(torch.cat(bl, 0)))
                 self.w_kv_grp.append(ws)
                 self.b_kv_grp.append(bs)
+            # ... and all L layers of a condition as ONE plain bf16 matrix [L x 1024, 512] for the fused projection + reduction
+            # (rg_cond_kv: one launch per condition, K | V never leave the registers)
+            self.w_kv_all, self.b_kv_all = [], []
+            if D == 512 and self.H == 16:
+                for ci in range(3):
+                    wl, bl = [], []
+                    for l in range(L):
+                        q = "temporal_decoder_blocks.%d.ca_blocks.%s." % (l, CONDS[ci])
+                        wkv = torch.cat([g(q + "key.weight"), g(q + "value.weight")], 0).double()
+                        bkv = torch.cat([g(q + "key.bias"), g(q + "value.bias")], 0).double()
+                        ga, be = g(q + "text_norm.weight").double(), g(q + "text_norm.bias").double()
+                        wl.append((wkv * ga[None, :]).float())
+                        bl.append((bkv + wkv @ be).float())
+                    self.w_kv_all.append(torch.cat(wl, 0).to(self.dev).to(torch.bfloat16).contiguous())
+                    self.b_kv_all.append(f32(torch.cat(bl, 0)))
             self.ln_ones, self.ln_zeros = torch.ones(D, device=self.dev), torch.zeros(D, device=self.dev)
 
         # --- timestep tables: ss[step][layer][block] = emb_layers(SiLU(time_embed(t_step)))  (fp32, exact)
@@ -246,7 +261,7 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, xcd_affine=True, engine=None,
-                 kv_grouped=True, seq_pairs=False, seq_duo=None, lane_dyn=None):
+                 kv_grouped=True, kv_fused=True, seq_pairs=False, seq_duo=None, lane_dyn=None):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
@@ -266,6 +281,9 @@ class DenoiserSession:
         # kv_grouped (bf16): the conditions' K / V projections of DenoiserWeights.KV_GROUP layers per GEMM on a bf16 normalised
         # operand (set_conditions); False = one fp32-A GEMM with a LayerNorm prologue per layer and condition (round 1-3)
         self.kv_grouped = bool(kv_grouped)
+        # kv_fused (with kv_grouped, bf16, D = 512, 16 heads, <= 512 tokens per clip and condition): projection AND reduction of a
+        # condition in one launch (rg_cond_kv) instead of L / 2 GEMMs + L reductions through fp32 K | V in memory
+        self.kv_fused = bool(kv_fused)
         if ln_mode not in ("auto", "folded", "prologue"):
             raise capi.RgError("ln_mode must be 'auto', 'folded' or 'prologue'")
         if engine not in (None, "seq", "chain"):
@@ -378,11 +396,19 @@ class DenoiserSession:
             kv = self._scratch("kv", (B * kv_max, ldk), torch.float32)
             scratch = self._scratch("ln", (B * kv_max, D), torch.float32)
             xhat_all = self._scratch("xhat", (B * kv_max, D), torch.bfloat16)
+            fused_all = True
             for ci in range(3):
                 xf, _, n_tok = srcs[ci]
                 M = B * n_tok
                 xhat = xhat_all[:M]
                 h.call("layernorm", xf, w.ln_ones, w.ln_zeros, scratch, M, D, xhat)      # exact two-pass statistics, no affine
+                if self.kv_fused and w.w_kv_all and n_tok <= 512:
+                    af = self.sq.afrag if self.sq is not None else None      # (the fragments of the sequence-stationary forward at once)
+                    h.call("cond_kv", xhat, w.w_kv_all[ci], w.b_kv_all[ci], self.a_pre[0, ci, o0:o1], self.a_pre.stride(0),
+                           None if af is None else af[0, ci, o0:o1], 0 if af is None else af.stride(0), B, n_tok, w.L)
+                    fused_all = fused_all and af is not None
+                    continue
+                fused_all = False
                 for gi in range(w.L // KVG):
                     G.gemm(h, M=M, N=ldk, K=D, W=w.w_kv_grp[gi][ci], out=kv, A=xhat, bias=w.b_kv_grp[gi][ci], ldo=ldk)
                     for j in range(KVG):
@@ -396,7 +422,7 @@ class DenoiserSession:
                            segs=[G.Seg(xf, mode=G.A_LN, stats=st, gamma=lw["tn_g"][ci], beta=lw["tn_b"][ci])],
                            seg_len=D, bias=lw["b_kv"][ci], ldo=2 * D)
                     h.call("kv_reduce", kv, 2 * D, self.a_pre[l, ci, o0:o1], B, n_tok, D)
-        if self.sq is not None:
+        if self.sq is not None and not (w.kv_group is not None and self.kv_grouped and fused_all):
             self.sq.set_a(self.a_pre[:, :, o0:o1], o0, o1)
         elif self.abf is not None and finalize:
             h.call("split_transpose_bf16", self.a_pre, self.a_pre_t, w.L * 3 * Bs * w.H)

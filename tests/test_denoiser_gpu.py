@@ -285,19 +285,25 @@ def test_device_chosen_launch_form_is_bit_identical(rg, setup, B, pairs):
     assert int(state[1, 0]) == 0
 
 
-@pytest.mark.parametrize("grouped", [True, False])
-def test_condition_side_attention_matrices_vs_oracle(rg, parity, setup, grouped):
+@pytest.mark.parametrize("mode", ["fused", "grouped", "per-layer"])
+def test_condition_side_attention_matrices_vs_oracle(rg, parity, setup, mode):
     """DenoiserSession.set_conditions: A[layer][condition][clip][head] = softmax_N(K)^T V (efficient_attention.py:74-90) of the
-    text / audio / speaker conditions at full depth against the fp32 oracle -- for the grouped projections (bf16 normalised rows,
-    the layers' LayerNorm affines folded into stacked [key | value] weights, DenoiserWeights.KV_GROUP layers per GEMM) and for
-    the per-layer fp32-A GEMMs with a LayerNorm prologue they replace."""
+    text / audio / speaker conditions at full depth against the fp32 oracle -- for the fused projection + reduction (rg_cond_kv:
+    one launch per condition, K | V never leave the registers; the default), for the grouped projections it replaces (bf16
+    normalised rows, the layers' LayerNorm affines folded into stacked [key | value] weights, DenoiserWeights.KV_GROUP layers per
+    GEMM, then rg_kv_reduce per layer) and for the per-layer fp32-A GEMMs with a LayerNorm prologue of rounds 1-3."""
+    grouped = mode != "per-layer"
     import torch.nn.functional as F
     cfg, P, W = setup[8]
     data, x, mm = _inputs(rg, B=3)
-    sess = rg.denoiser.DenoiserSession(W, 3, kv_grouped=grouped)
+    sess = rg.denoiser.DenoiserSession(W, 3, kv_grouped=grouped, kv_fused=mode == "fused")
+    sess.a_pre.fill_(float("nan"))
     sess.set_conditions(data["word"], data["audio"], data["speaker_ids"], mm, None)
     torch.cuda.synchronize()
     got = sess.a_pre.cpu()                                                  # [L, 3, B, H, 32, 32]
+    assert torch.isfinite(got).all()
+    # the sequence-stationary forward's bf16 fragments: written by rg_cond_kv itself in the fused mode, packed from a_pre otherwise
+    assert sess.sq is not None and torch.equal(sess.sq.afrag, rg.seqfwd.a_fragments(sess.a_pre))
     H, D = cfg["num_heads"], cfg["latent_dim"]
     xf = {"xf_text": od.linear(P, "text_pre_proj", data["word"].float()), "xf_audio": od.linear(P, "audio_pre_proj", data["audio"].float()),
           "xf_spk": P["speaker_embedding.weight"][data["speaker_ids"].long()].float()}
@@ -312,4 +318,4 @@ def test_condition_side_attention_matrices_vs_oracle(rg, parity, setup, grouped)
             ref = torch.einsum("bnhd,bnhl->bhdl", key, val)
             worst = max(worst, relerr(got[l, ci], ref))
     parity.check("condition-side A = softmax_N(K)^T V, L8, %s projections (bf16 operands): worst (layer, condition) vs oracle"
-                 % ("grouped" if grouped else "per-layer"), worst, 6e-3)
+                 % mode, worst, 6e-3)
