@@ -25,11 +25,14 @@ names = ["unit GEMMs", "row statistics", "barriers", "params+panel", "attention 
 # workgroup -> kind (rg_seq2_kernel: XCD-interleaved when the pair count per kind is a multiple of 4)
 npc = B // 2
 kinds = [((b & 7) >= 4) if npc % 4 == 0 else (b >= npc) for b in range(nwg)] if not pairs else [True] * nwg
+summary = {}
 for tag, k in (("conditional pairs", False), ("classifier-free pairs", True)):
     idx = [b for b in range(nwg) if kinds[b] == k]
     if not idx:
         continue
     m = t[idx].mean(dim=(0, 1))
+    summary["classifier_free_pass_us" if k else "conditional_pass_us"] = round(float(m[5]), 1)
+    summary[("classifier_free" if k else "conditional") + "_categories_us"] = {names[i]: round(float(m[i]), 1) for i in range(11)}
     rest = m[5] - m[0] - m[1] - m[2] - m[3] - m[4] - m[6] - m[8] - m[9] - m[10]
     print("%s (mean over workgroups and waves, us): " % tag + "  ".join("%s %.1f" % (names[i], m[i]) for i in (0, 1, 2, 3, 4, 6, 8, 9, 10, 7, 5))
           + "  rest %.1f" % rest + "   pass min / max over workgroups %.1f / %.1f" % (t[idx][:, :, 5].min(), t[idx][:, :, 5].max()))
@@ -48,3 +51,11 @@ for tag, k in (("conditional", False), ("classifier-free", True)):
     for c in range(1 + 3 * per_layer, 1 + 4 * per_layer):
         print("   call %2d: %6.2f | %6.2f | %6.2f | %6.2f" % (c - 1 - 3 * per_layer, log[b, 0, c], log[b, 4, c], log[idx][:, :4, c].mean(), log[idx][:, 4:, c].mean()))
     print("   embed %.2f  head %.2f" % (log[b, 0, 0], log[b, 0, n - 1]))
+
+if os.environ.get("STAMPS_JSON"):
+    import hashlib, json
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "rag-gesture_amd", "csrc", "rg_seq2.hip")
+    summary["kernel_source_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    summary["what"] = "in-kernel wall-clock stamps of rg_seq2_kernel (diagnostic build, RG_DIAG=1), mean over workgroups and waves, B = %d, pairs %s" % (B, pairs)
+    with open(os.environ["STAMPS_JSON"], "w") as f:
+        json.dump(summary, f, indent=1)

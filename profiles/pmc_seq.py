@@ -40,9 +40,12 @@ alg = (st.wstream.numel() * 2 + 2 * (st.pstream[0].numel() * 4 + st.ustream[0].n
 per_cond = (16 * L + 2) * 520 * 1024 + L * 3 * 32 * 1024
 per_unc = (10 * L + 2) * 520 * 1024 + L * 16 * 1024
 if DUO:   # + the fp32 tile round trips (3 per layer) and bf16 panel images (4 per layer for conditional pairs) through xbuf / gbuf: L2-resident scratch
-    scratch = (B // 2) * L * ((3 + 3) * 2 * 96 * 1024 + (2 + 2) * 2 * 96 * 1024 + 4 * 2 * 2 * 48 * 1024)
+    # (round 6: two xbuf round trips per layer and sequence pair of either kind, three gbuf panel images per conditional pair)
+    scratch = (B // 2) * L * (2 * (2 * 2 * 192 * 1024) + 3 * 2 * 96 * 1024)
 else:
     scratch = 0
 wgs = (B // 2 if PAIRS else B) if DUO else (B if PAIRS else 2 * B)
-print(json.dumps(dict(kernel="rg_seq2_kernel" if DUO else "rg_seq_kernel", sequences=2 * B, workgroups=wgs, launches=REPS, flops_per_launch=flops, algorithmic_hbm_bytes=alg,
+import hashlib
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rag-gesture_amd", "csrc", "rg_seq2.hip" if DUO else "rg_seq.hip")
+print(json.dumps(dict(kernel_source_sha256=hashlib.sha256(open(_src, "rb").read()).hexdigest(), kernel="rg_seq2_kernel" if DUO else "rg_seq_kernel", sequences=2 * B, workgroups=wgs, launches=REPS, flops_per_launch=flops, algorithmic_hbm_bytes=alg,
                       lds_ring_bytes=B * (per_cond + per_unc) // (2 if DUO else 1), scratch_round_trip_bytes=scratch)))

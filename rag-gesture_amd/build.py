@@ -38,7 +38,7 @@ NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # RG_OWN_THE_SIMD, NOTEBOOK 11.3).  The units below hold only kernels that own their SIMDs (256 registers per wave, two waves
 # per SIMD); their epilogues are written two-wide (rg_common.h rg_fma2 ...) and get the packed instructions.  Results do not
 # depend on the switch (every packed operation is the same IEEE operation per element).
-PACKED_FP32_UNITS = set(os.environ.get("RG_PACKED_UNITS", "rg_seq.hip rg_seq2.hip").split())
+PACKED_FP32_UNITS = set(os.environ.get("RG_PACKED_UNITS", "rg_seq.hip rg_seq2.hip rg_seqx.hip rg_venc.hip rg_vdec.hip rg_condkv.hip").split())
 BASE_FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
               "-mllvm", "-amdgpu-early-inline-all=true"]
 FLAGS = BASE_FLAGS + NO_PACKED_FP32 + os.environ.get("RG_EXTRA_FLAGS", "").split()
@@ -69,13 +69,17 @@ def _deps_mtime():
 
 def _compile(src, hdr_mtime, force):
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
+    cmd = [_hipcc()] + flags_for(src) + (["-DRG_STAMPS"] if DIAG else []) + ["-c", src, "-o", obj]
+    stamp, want = obj + ".cmd", " ".join(cmd)
+    same_cmd = os.path.exists(stamp) and open(stamp).read() == want      # (a changed flag set rebuilds, not only a changed source)
+    if (not force and same_cmd and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(src)
             and os.path.getmtime(obj) >= hdr_mtime):
         return obj
-    cmd = [_hipcc()] + flags_for(src) + (["-DRG_STAMPS"] if DIAG else []) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    with open(stamp, "w") as f:
+        f.write(want)
     # (the host pass of hipcc sees the device-only feature switch too and says so: not a problem of this build)
     err = "\n".join(l for l in r.stderr.splitlines() if "packed-fp32-ops" not in l)
     if err.strip():
