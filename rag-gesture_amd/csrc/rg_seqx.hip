@@ -43,27 +43,7 @@ __global__ void __launch_bounds__(NTH_X) rg_seqx_kernel(const rg_seq_args a) {
   }
 }
 
-// state: one 128-byte record (RG_LANE_STRIDE ints) per lane, written by that lane's arbitration kernel only: [0] = workgroups
-// its current launch form holds (read by the other lanes' arbitration), [1] = its form flag (read by its own rg_seqx launches)
-__global__ void rg_lane_form_kernel(int* state, int lane, int nlanes, int narrow_wgs, int wide_wgs, int budget) {
-  if (threadIdx.x != 0) return;
-  int others = 0;
-  for (int l = 0; l < nlanes; ++l)
-    if (l != lane) others += __hip_atomic_load(state + l * RG_LANE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int wide = wide_wgs > narrow_wgs && others + wide_wgs <= budget;
-  __hip_atomic_store(state + lane * RG_LANE_STRIDE, wide ? wide_wgs : narrow_wgs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(state + lane * RG_LANE_STRIDE + 1, wide, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 }  // namespace
-
-extern "C" int rg_lane_form(rg_handle* h, int* state, int lane, int nlanes, int narrow_wgs, int wide_wgs, int budget, void* stream) {
-  RG_REQUIRE(h, state, "null state");
-  RG_REQUIRE(h, nlanes >= 1 && nlanes <= 64 && lane >= 0 && lane < nlanes, "lane out of range");
-  RG_REQUIRE(h, narrow_wgs >= 0 && wide_wgs >= 0 && budget >= 0, "negative workgroup count");
-  hipLaunchKernelGGL(rg_lane_form_kernel, dim3(1), dim3(64), 0, rg_stream(stream), state, lane, nlanes, narrow_wgs, wide_wgs, budget);
-  RG_CHECK_LAUNCH(h);
-  return RG_OK;
-}
 
 extern "C" int rg_seqx_forward(rg_handle* h, const rg_seq_args* args_host, void* stream) {
   RG_REQUIRE(h, args_host, "null args");

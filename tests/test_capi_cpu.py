@@ -78,6 +78,16 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
         asm = f.read()
     assert "v_fma_f32" in asm or "v_mul_f32" in asm
     assert not re.search(r"\bv_pk_(?:add|mul|fma)_f32\b", asm)
+    # Round 6: the units that DO get packed fp32 (build.PACKED_FP32_UNITS) hold only kernels that own their SIMDs -- every
+    # __global__ function in them says RG_OWN_THE_SIMD() (all 256 vector registers allocated: no foreign wave beside its own),
+    # and nothing else is built that way
+    assert b.flags_for(src) == b.FLAGS and os.path.basename(src) not in b.PACKED_FP32_UNITS
+    for unit in sorted(b.PACKED_FP32_UNITS):
+        with open(os.path.join(b.CSRC, unit)) as f:
+            text = f.read()
+        assert not any(x in b.flags_for(os.path.join(b.CSRC, unit)) for x in b.NO_PACKED_FP32[-1:]), unit
+        n_kernels = len(re.findall(r"^__global__\b", text, flags=re.M))
+        assert n_kernels >= 1 and n_kernels == len(re.findall(r"^\s*RG_OWN_THE_SIMD\(\);", text, flags=re.M)), (unit, n_kernels)
 
 
 def test_lds_reservation_guard_is_per_device(tmp_path):
