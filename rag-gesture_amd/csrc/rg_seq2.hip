@@ -493,7 +493,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
   };
   // call sites of the unit GEMM (SITE<n>): bit n of RG2_REG_SITES = the site's weights go straight into registers (gemm_frags_reg)
 #ifndef RG2_REG_SITES
-#define RG2_REG_SITES 0xE7B
+#define RG2_REG_SITES 0xE7F      // (round 6: site 2 -- the Q unit beside the held A operands -- fits too since the epilogues shrank; sites 7 and 8 -- a GELU half held -- still spill 71 / 47 registers)
 #endif
 #define SITE(n) std::integral_constant<int, n>()
   // (Round 6 tried the same loop k-step-major with the panel fragment outermost -- four weight quads per k-step, every panel

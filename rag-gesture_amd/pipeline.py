@@ -344,7 +344,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=8,
-                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, dynamic_forms=False, dynamic_budget=None, **kwargs):
+                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, dynamic_forms=False, dynamic_budget=None, invert_alone_wide=True, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -381,6 +381,7 @@ class MotionDiffusion(torch.nn.Module):
         # chains running wide the caller's stream (clip encode -> retrieval -> exemplar encode -> condition projections, in
         # series, beside the lanes' launches) paces the pipeline instead of the chains (profiles/r06k_timed_region.txt).
         self.dynamic_forms, self._lane_state = bool(dynamic_forms), None
+        self.invert_alone_wide = bool(invert_alone_wide)      # an inversion ALONE (a filling pipeline) as one workgroup per sequence
         self.dynamic_budget = None if dynamic_budget is None else int(dynamic_budget)     # workgroups the lanes may hold together (None: the chip's compute units)
         self.rotation_lanes = None     # submit(): lanes in the rotation of whole batches (None: batch_lanes / base_lanes); longform.py pins 1
         self.form_lanes = None         # ... and how many of their chains really run side by side (None: all of them); longform.py: 2
@@ -593,6 +594,8 @@ class MotionDiffusion(torch.nn.Module):
                 # pending batch's sampling): the chip is emptying or empty then, so the classifier-free pairs get workgroups
                 # of their own (B workgroups for 1.6 ms instead of B / 2 for 2.6 ms per launch; same bits)
                 opts["seq_pairs"], opts["seq_duo"] = False, True
+            if role == "invert" and self.invert_alone_wide and self._cob is not None:
+                opts["seq_pairs"], opts["seq_duo"] = False, False
         cob = self._cob
         seq = opts.get("engine") != "chain" and getattr(self.model.weights, "seq_streams", None) is not None
         if (self.dynamic_forms and seq and self.async_results and cob is not None and cob.get("lane") is not None
