@@ -88,6 +88,16 @@ def test_device_code_has_no_packed_fp32_instructions(tmp_path):
         assert not any(x in b.flags_for(os.path.join(b.CSRC, unit)) for x in b.NO_PACKED_FP32[-1:]), unit
         n_kernels = len(re.findall(r"^__global__\b", text, flags=re.M))
         assert n_kernels >= 1 and n_kernels == len(re.findall(r"^\s*RG_OWN_THE_SIMD\(\);", text, flags=re.M)), (unit, n_kernels)
+    # ... and the reservation really yields 256 allocated registers (the compiler's own report), for the two kernels the
+    # round-6 failure was bisected on
+    for unit in ("rg_seq2.hip", "rg_venc.hip"):
+        usrc = os.path.join(b.CSRC, unit)
+        r = subprocess.run([b._hipcc()] + b.flags_for(usrc) + ["--cuda-device-only", "-S", usrc, "-o", str(tmp_path / "u.s"),
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        vg = [int(v) for v in re.findall(r"remark:\s+VGPRs: (\d+)", r.stderr)]
+        assert vg and all(v == 256 for v in vg), (unit, vg)
+        assert "ScratchSize [bytes/lane]: 0" in r.stderr, unit
 
 
 def test_lds_reservation_guard_is_per_device(tmp_path):

@@ -123,8 +123,9 @@ def test_end_to_end_vs_reference_golden(rg, parity, models, golden_dir, rtag, ik
 @pytest.mark.parametrize("start,precision", [(10, "fp32"), (25, "fp32"), (10, "bf16"), (25, "bf16")])
 def test_inversion_start_time_vs_oracle(rg, parity, models, start, precision):
     """`inversion_start_time` != -1 (diffusion_architecture.py:218, 386: the sampling starts from inversion level `start`
-    of the exemplar rows instead of the last one) on the device: guided and plain inversion runs against the oracle with
-    the same option, the synchronous forward and -- bit for bit -- the asynchronous submit() path."""
+    of the exemplar rows instead of the last one) on the device: guided and plain inversion runs of the synchronous forward
+    against the oracle with the same option.  (The submit() path is held to the synchronous forward bit for bit by
+    tests/test_async_gpu.py, not here: ADVICE r05.)"""
     from oracle import diffusion as odf
     model = models[("L2", precision)]
     cfg = rg.synth.default_model_cfg(num_layers=2)
