@@ -80,6 +80,31 @@ int rg_cfg_ddpm_update(rg_handle* h, const float* out, const float* x, const flo
                        const float* js, int B, int T, int D, float w_c, float w_u, float c1, float c2, float sigma,
                        void* stream);
 
+/* Everything between two denoiser forwards of a chain that advances a sampling loop (group a: n_a clips) and an inversion
+ * loop (group b: n_b clips) in the same launches, in ONE launch: group a: rg_cfg_ddim_update_rows of this step, then -- for the
+ * NEXT step, on the rows in_seq_next marks -- rg_guidance_update (g_iter_next iterations, numel = n_a * T * D) and
+ * rg_inseq_replace; group b: rg_cfg_ddim_update_rows with its own coefficients and a second copy of the result.  The same
+ * arithmetic as those entry points, operation for operation (gaussian_diffusion.py:910-1001 `ddim_sample`, :1003-1040
+ * `ddim_reverse_sample`, :1263-1273, :1351-1378 guidance). */
+typedef struct rg_glue_args {
+  const float* out_c_a;    /* denoiser output, conditional rows of group a [n_a][T][D] */
+  const float* out_u_a;    /* ... classifier-free rows of group a */
+  float* x_a;              /* latent of group a, updated in place */
+  const float* out_c_b;
+  const float* out_u_b;
+  float* x_b;              /* latent of group b, updated in place */
+  float* x_b_copy;         /* or NULL: second copy of group b's result (the inversion level kept) */
+  const float* in_seq_next;   /* or NULL: the next step's in_seq of group a [n_a][T][D] */
+  const float* noise_next;    /* its randn_like(in_seq) draw */
+  const float* js;         /* per_joint_scale [T] */
+  int n_a, n_b, T, D;
+  int g_iter_next;         /* insertion-guidance iterations of the next step (0: none) */
+  float wc_a, wu_a, c_recip_a, c_recipm1_a, ca_a, cb_a;   /* CFG weights and DDIM coefficients of group a's step */
+  float wc_b, wu_b, c_recip_b, c_recipm1_b, ca_b, cb_b;   /* ... of group b's */
+  float lr, s_ab_next, s_1mab_next;
+} rg_glue_args;
+int rg_cobatch_glue(rg_handle* h, const rg_glue_args* args_host, void* stream);
+
 /* In-sequence replacement (outpainting / exemplar insertion / prev-latent chaining):
  *   m[r] = any(in_seq[r,:] != 0);  x[r,:] = m ? s_ab*in_seq[r,:] + s_1mab*noise[r,:] : x[r,:]
  *   (gaussian_diffusion.py:934-947 in `ddim_sample`, :459-477 `q_sample`).  rows = B*T. */

@@ -5,7 +5,8 @@
 // layers as fp32 [rows, 2048] (1.7 GB per batch of 64 clips x (150 + 499 + 1) tokens) and L reductions that read it back
 // (kv_reduce_kernel): ~110 launches per set_conditions, 3 ms of kernel time alone and 9-15 ms on the caller's stream of the
 // pipeline, where every small launch waits for compute units behind the denoiser's workgroups.  Here a workgroup owns one clip
-// and the 128 columns [K | V] of TWO heads of one layer: its eight waves take 64 token rows each (N <= 512 tokens), the K | V
+// (two or more where a clip's tokens need only some of the waves) and the 128 columns [K | V] of TWO heads of one layer: its
+// eight waves take 64 token rows each (N <= 512 tokens), the K | V
 // tile stays in the accumulators (128 registers), the softmax over the tokens is two exchanges through LDS (column max, column
 // sum), P^T V runs on the matrix cores from the accumulators themselves (the C layout of two 16-token blocks IS the operand
 // layout of a 32-deep step, for P as A and V as B alike) as bf16 hi + lo products, and the eight partial 32 x 32 matrices are
@@ -68,12 +69,18 @@ __global__ void __launch_bounds__(NTH) cond_kv_kernel(const CondKvArgs a) {
   f32x4* const sPart = reinterpret_cast<f32x4*>(smem + OFF_PART);
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = blockIdx.x >> 3, hp = blockIdx.x & 7, b = blockIdx.y;
+  const int l = blockIdx.x >> 3, hp = blockIdx.x & 7;
   const int N = a.n_tok;
-  const unsigned char* X = reinterpret_cast<const unsigned char*>(a.xhat) + (size_t)b * N * (DM * 2);
+  // A clip takes wpc = ceil(N / 64) waves; a workgroup holds cpw = 8 / wpc clips side by side (499 audio tokens: one clip; the
+  // 150-token text and speaker conditions: two, six of eight waves busy and the weight tile fetched once for both).  Wave ->
+  // (clip slot, 64-row group); a wave without a clip only takes part in the barriers.
+  const int wpc = (N + 63) >> 6, cpw = NWV / wpc;
+  const int slot = wave / wpc, rgi = wave - slot * wpc;
+  const int b = blockIdx.y * cpw + slot;
+  const bool active = slot < cpw && b < a.B;
+  const unsigned char* X = reinterpret_cast<const unsigned char*>(a.xhat) + (size_t)(active ? b : 0) * N * (DM * 2);
   const unsigned char* W = reinterpret_cast<const unsigned char*>(a.w) + (size_t)l * 1024 * (DM * 2);
-  const int r0 = 64 * wave;
-  const bool active = r0 < N;             // (a wave without token rows only takes part in the exchanges)
+  const int r0 = 64 * rgi;
 
   // accumulators: acc[rb][cb][r] = (K | V)[token r0 + 16 rb + 4 g4 + r][column 16 cb + l15]; columns 0-63 = key columns of heads
   // 2 hp, 2 hp + 1, columns 64-127 = their value columns
@@ -145,9 +152,10 @@ __global__ void __launch_bounds__(NTH) cond_kv_kernel(const CondKvArgs a) {
   for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (r0 + 16 * rb + 4 * g4 + r < N) vbits |= 1u << (4 * rb + r);
+      if (active && r0 + 16 * rb + 4 * g4 + r < N) vbits |= 1u << (4 * rb + r);
 
-  // ---- softmax over the tokens, per key column (lane = column 16 cb + l15, cb = 0..3): max, then sum, across the eight waves
+  // ---- softmax over the tokens, per key column (lane = column 16 cb + l15, cb = 0..3): max, then sum, across the clip's waves
+  const int w0 = slot * wpc;      // first wave of this wave's clip
   float cmax[4], cinv[4];
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
@@ -163,9 +171,9 @@ __global__ void __launch_bounds__(NTH) cond_kv_kernel(const CondKvArgs a) {
   __syncthreads();
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
-    float m = sRed[16 * cb + l15];
-#pragma unroll
-    for (int w = 1; w < NWV; ++w) m = fmaxf(m, sRed[w * 64 + 16 * cb + l15]);
+    float m = -INFINITY;
+    if (active)
+      for (int w = 0; w < wpc; ++w) m = fmaxf(m, sRed[(w0 + w) * 64 + 16 * cb + l15]);
     cmax[cb] = m;
     const float nm2 = m * -1.44269504088896340736f;
     float s = 0.f;
@@ -185,8 +193,8 @@ __global__ void __launch_bounds__(NTH) cond_kv_kernel(const CondKvArgs a) {
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb) {
     float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) s += sRed[NWV * 64 + w * 64 + 16 * cb + l15];      // fixed order
+    if (active)
+      for (int w = 0; w < wpc; ++w) s += sRed[NWV * 64 + (w0 + w) * 64 + 16 * cb + l15];      // fixed order
     cinv[cb] = 1.0f / s;
   }
   (void)cinv;
@@ -239,23 +247,24 @@ __global__ void __launch_bounds__(NTH) cond_kv_kernel(const CondKvArgs a) {
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) sPart[(wave * 8 + 4 * hh + 2 * ib + jb) * 64 + lane] = part[hh][ib][jb];
   // column sums for the final scaling: A's row i is key column i
-  if (wave == 0 && g4 == 0) {
+  if (active && rgi == 0 && g4 == 0) {
 #pragma unroll
-    for (int cb = 0; cb < 4; ++cb) sRed[16 * cb + l15] = cinv[cb];
+    for (int cb = 0; cb < 4; ++cb) sRed[slot * 64 + 16 * cb + l15] = cinv[cb];
   }
   __syncthreads();
-  {
-    // wave w adds block w = (hh, ib, jb) of the eight partial matrices, in wave order, scales its rows and stores
+  for (int sl = 0; sl < cpw; ++sl) {
+    // wave w adds block w = (hh, ib, jb) of the partial matrices of clip slot sl, in wave order, scales its rows and stores
+    const int b = blockIdx.y * cpw + sl;
+    if (b >= a.B) break;
     const int hh = wave >> 2, ib = (wave >> 1) & 1, jb = wave & 1;
-    f32x4 s = sPart[(0 * 8 + wave) * 64 + lane];
-#pragma unroll
-    for (int w = 1; w < NWV; ++w) s += sPart[(w * 8 + wave) * 64 + lane];
+    f32x4 s = sPart[((sl * wpc) * 8 + wave) * 64 + lane];
+    for (int w = 1; w < wpc; ++w) s += sPart[((sl * wpc + w) * 8 + wave) * 64 + lane];
     const int h = 2 * hp + hh;
     float* op = a.out + (size_t)l * a.layer_stride + ((size_t)b * 16 + h) * (HD * HD);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 16 * ib + 4 * g4 + r;
-      s[r] *= sRed[32 * hh + i];
+      s[r] *= sRed[sl * 64 + 32 * hh + i];
       op[i * HD + 16 * jb + l15] = s[r];
     }
     if (a.afrag) {
@@ -285,7 +294,8 @@ extern "C" int rg_cond_kv(rg_handle* h, const void* xhat_bf16, const void* w_bf1
   a.bias = bias; a.out = out; a.layer_stride = layer_stride;
   a.afrag = reinterpret_cast<unsigned short*>(afrag_bf16); a.afrag_layer_stride = afrag_layer_stride;
   a.B = B; a.n_tok = n_tok; a.L = L;
-  hipLaunchKernelGGL(cond_kv_kernel, dim3(8 * L, B), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
+  const int wpc = (n_tok + 63) / 64, cpw = NWV / wpc;      // waves per clip, clips per workgroup
+  hipLaunchKernelGGL(cond_kv_kernel, dim3(8 * L, (B + cpw - 1) / cpw), dim3(NTH), LDS_BYTES, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

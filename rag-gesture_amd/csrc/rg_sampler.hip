@@ -143,6 +143,72 @@ __global__ void __launch_bounds__(kBlock) guidance_kernel(float* __restrict__ x,
   }
 }
 
+// Everything between two denoiser forwards of a co-batched chain (sampler.cobatched_loop) in ONE launch, one wave per token row:
+//   sampling rows:  x <- cfg_ddim(out_c, out_u, x) of this step; then, for the NEXT step, the insertion-guidance update and the
+//                   in-sequence replacement on the rows its in_seq marks (cfg_ddim_kernel, guidance_kernel, inseq_replace_kernel,
+//                   in that order, the same arithmetic operation for operation);
+//   inverting rows: x <- cfg_ddim(...) of this step with the inversion's coefficients, and a second copy (the level kept).
+// Four launches of ~15 us each beside a full chip become one (3-4 % of a chain's time).
+__global__ void __launch_bounds__(kBlock) cobatch_glue_kernel(const rg_glue_args a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * kBlock) >> 6;
+  const int d4 = a.D >> 2;
+  const int rows_a = a.n_a * a.T, rows = (a.n_a + a.n_b) * a.T;
+  const float two_over_numel = 2.0f / ((float)rows_a * (float)a.D);
+  for (int r = wave; r < rows; r += nwaves) {
+    const bool ga = r < rows_a;
+    const int rl = ga ? r : r - rows_a;                       // row within its group
+    const float jc = a.js[rl % a.T], ju = 1.0f / jc;
+    const float4* oc = reinterpret_cast<const float4*>((ga ? a.out_c_a : a.out_c_b) + (int64_t)rl * a.D);
+    const float4* ou = reinterpret_cast<const float4*>((ga ? a.out_u_a : a.out_u_b) + (int64_t)rl * a.D);
+    float4* xr = reinterpret_cast<float4*>((ga ? a.x_a : a.x_b) + (int64_t)rl * a.D);
+    const float w_c = ga ? a.wc_a : a.wc_b, w_u = ga ? a.wu_a : a.wu_b;
+    const float c_recip = ga ? a.c_recip_a : a.c_recip_b, c_recipm1 = ga ? a.c_recipm1_a : a.c_recipm1_b;
+    const float c_a = ga ? a.ca_a : a.ca_b, c_b = ga ? a.cb_a : a.cb_b;
+    bool ins = false;                                         // the next step inserts on this row
+    const float4* s = nullptr;
+    if (ga && a.in_seq_next) {
+      s = reinterpret_cast<const float4*>(a.in_seq_next + (int64_t)rl * a.D);
+      bool nz = false;
+      for (int j = lane; j < d4; j += 64) {
+        float4 v = s[j];
+        nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+      }
+      ins = __ballot(nz) != 0ull;
+    }
+    const float4* nn = ins ? reinterpret_cast<const float4*>(a.noise_next + (int64_t)rl * a.D) : nullptr;
+    float4* x2 = (!ga && a.x_b_copy) ? reinterpret_cast<float4*>(a.x_b_copy + (int64_t)rl * a.D) : nullptr;
+    for (int j = lane; j < d4; j += 64) {
+      const float4 c = oc[j], u = ou[j], x = xr[j];
+      float4 p, v;
+      p.x = cfg_one(c.x, u.x, jc, ju, w_c, w_u);
+      p.y = cfg_one(c.y, u.y, jc, ju, w_c, w_u);
+      p.z = cfg_one(c.z, u.z, jc, ju, w_c, w_u);
+      p.w = cfg_one(c.w, u.w, jc, ju, w_c, w_u);
+      v.x = ddim_one(x.x, p.x, c_recip, c_recipm1, c_a, c_b);
+      v.y = ddim_one(x.y, p.y, c_recip, c_recipm1, c_a, c_b);
+      v.z = ddim_one(x.z, p.z, c_recip, c_recipm1, c_a, c_b);
+      v.w = ddim_one(x.w, p.w, c_recip, c_recipm1, c_a, c_b);
+      if (ins) {
+        const float4 y = s[j], e = nn[j];
+        for (int it = 0; it < a.g_iter_next; ++it) {          // (rg_guidance_update; what follows overwrites it, as in the reference)
+          v.x = v.x - a.lr * (two_over_numel * (v.x - y.x));
+          v.y = v.y - a.lr * (two_over_numel * (v.y - y.y));
+          v.z = v.z - a.lr * (two_over_numel * (v.z - y.z));
+          v.w = v.w - a.lr * (two_over_numel * (v.w - y.w));
+        }
+        v.x = a.s_ab_next * y.x + a.s_1mab_next * e.x;
+        v.y = a.s_ab_next * y.y + a.s_1mab_next * e.y;
+        v.z = a.s_ab_next * y.z + a.s_1mab_next * e.z;
+        v.w = a.s_ab_next * y.w + a.s_1mab_next * e.w;
+      }
+      xr[j] = v;
+      if (x2) x2[j] = v;
+    }
+  }
+}
+
 __global__ void __launch_bounds__(kBlock) splice_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
                                                        int d4, int nrows, int src_row0, int dst_row0,
                                                        int hands_off, int nrep, int64_t src_rep_rows,
@@ -227,6 +293,18 @@ extern "C" int rg_cfg_ddpm_update(rg_handle* h, const float* out, const float* x
   int64_t n4 = (int64_t)B * T * D / 4;
   hipLaunchKernelGGL(cfg_ddpm_kernel, dim3(rg_grid_1d(n4, kBlock)), dim3(kBlock), 0, rg_stream(stream), (const float4*)out,
                      (const float4*)x, (const float4*)noise, (float4*)x_out, js, n4, T * D / 4, D / 4, w_c, w_u, c1, c2, sigma);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_cobatch_glue(rg_handle* h, const rg_glue_args* args_host, void* stream) {
+  RG_REQUIRE(h, args_host, "null args");
+  const rg_glue_args& a = *args_host;
+  RG_REQUIRE(h, a.out_c_a && a.out_u_a && a.x_a && a.out_c_b && a.out_u_b && a.x_b && a.js, "null pointer");
+  RG_REQUIRE(h, a.n_a > 0 && a.n_b > 0 && a.T > 0 && a.D > 0 && a.D % 4 == 0 && a.g_iter_next >= 0, "bad shape");
+  RG_REQUIRE(h, !a.in_seq_next || a.noise_next, "in_seq_next needs noise_next");
+  const int rows = (a.n_a + a.n_b) * a.T;
+  hipLaunchKernelGGL(cobatch_glue_kernel, dim3(rg_grid_1d((int64_t)rows * 64, kBlock)), dim3(kBlock), 0, rg_stream(stream), a);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

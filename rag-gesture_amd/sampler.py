@@ -11,9 +11,23 @@ DDIM coefficients come from 50-entry host tables), so a whole loop can be captur
 graph (`GraphedLoop`).  Noise is explicit: the caller supplies the tensors the reference would
 have drawn from torch's global generator.
 """
+import ctypes
+
 import torch
 
 from . import capi
+
+_vp, _f, _i = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
+
+
+class GlueArgs(ctypes.Structure):
+    """include/rg_gesture.h: rg_glue_args (rg_cobatch_glue)."""
+    _fields_ = [("out_c_a", _vp), ("out_u_a", _vp), ("x_a", _vp), ("out_c_b", _vp), ("out_u_b", _vp), ("x_b", _vp), ("x_b_copy", _vp),
+                ("in_seq_next", _vp), ("noise_next", _vp), ("js", _vp),
+                ("n_a", _i), ("n_b", _i), ("T", _i), ("D", _i), ("g_iter_next", _i),
+                ("wc_a", _f), ("wu_a", _f), ("c_recip_a", _f), ("c_recipm1_a", _f), ("ca_a", _f), ("cb_a", _f),
+                ("wc_b", _f), ("wu_b", _f), ("c_recip_b", _f), ("c_recipm1_b", _f), ("ca_b", _f), ("cb_b", _f),
+                ("lr", _f), ("s_ab_next", _f), ("s_1mab_next", _f)]
 
 
 def _step(sess, x, i, in_seq=None, noise=None):
@@ -78,7 +92,7 @@ def ddim_guided_sample_loop(sess, x, inverted, guidance_iters, guidance_lr, inse
 
 
 def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None, guidance_lr=0.1, inseq_noise_a=None,
-                   in_seq_a=None):
+                   in_seq_a=None, fused_glue=True):
     """Two loops advancing in the same launches, one denoiser forward per step for both:
       clips [0, n_a) of the session: the (insertion-guided) DDIM sampling loop of one batch, exactly
         ddim_guided_sample_loop / ddim_sample_loop (inverted_a None) on x_all[:n_a], in place;
@@ -92,6 +106,45 @@ def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None
     n_b = B - n_a
     xa, xb = x_all[:n_a], x_all[n_a:]
     in_seq = in_seq_a
+    if fused_glue and h.recorder is None:
+        # what lies between two forwards as ONE launch (rg_cobatch_glue: this step's two updates + the next step's guidance and
+        # insertion on the sampling rows) instead of four; the first step's insertion in front of the loop as before
+        if in_seq is not None:
+            h.call("inseq_replace", xa, in_seq, inseq_noise_a[S - 1], n_a * T, D, float(sch.s_ab[S - 1]), float(sch.s_1mab[S - 1]))
+        head = sess.head
+
+        def p(t):
+            if t is None:
+                return None
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise capi.RgError("rg_cobatch_glue: contiguous fp32 device tensors expected")
+            return t.data_ptr()
+        cfgw = lambda step: sch.cfg_weights(w.cfg["scale_func_cfg"], step)
+        for k in range(S):
+            i = S - 1 - k
+            sess.forward(x_all, i, step_b=k, split=n_a)
+            a = GlueArgs()
+            a.out_c_a, a.out_u_a, a.x_a = p(head), p(head[B * T:]), p(xa)
+            a.out_c_b, a.out_u_b, a.x_b, a.x_b_copy = p(head[n_a * T:]), p(head[(B + n_a) * T:]), p(xb), p(out_b[k])
+            nxt = None
+            if i > 0:
+                nxt = inverted_a[i - 1] if inverted_a is not None else in_seq_a
+            a.in_seq_next, a.noise_next = p(nxt), (None if nxt is None else p(inseq_noise_a[i - 1]))
+            a.js = p(w.js)
+            a.n_a, a.n_b, a.T, a.D = n_a, n_b, T, D
+            a.g_iter_next = int(guidance_iters[i - 1]) if (nxt is not None and inverted_a is not None) else 0
+            a.wc_a, a.wu_a = cfgw(i)
+            a.c_recip_a, a.c_recipm1_a, a.ca_a, a.cb_a = float(sch.c_recip[i]), float(sch.c_recipm1[i]), float(sch.c_prev_a[i]), float(sch.c_prev_b[i])
+            a.wc_b, a.wu_b = cfgw(k)
+            a.c_recip_b, a.c_recipm1_b, a.ca_b, a.cb_b = float(sch.c_recip[k]), float(sch.c_recipm1[k]), float(sch.c_next_a[k]), float(sch.c_next_b[k])
+            a.lr = float(guidance_lr)
+            if i > 0:
+                a.s_ab_next, a.s_1mab_next = float(sch.s_ab[i - 1]), float(sch.s_1mab[i - 1])
+            rc = h.lib.rg_cobatch_glue(h._h, ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            if rc != 0:
+                raise capi.RgError("rg_cobatch_glue failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
+        sess.chain_end()
+        return x_all, out_b
     for k in range(S):
         i = S - 1 - k
         if inverted_a is not None and i != S - 1:
