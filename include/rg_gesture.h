@@ -117,6 +117,18 @@ int rg_inseq_replace(rg_handle* h, float* x, const float* in_seq, const float* n
 int rg_guidance_update(rg_handle* h, float* x, const float* in_seq, int rows, int dim,
                        int g_iter, float lr, void* stream);
 
+/* All exemplar splices of a batch in one launch: for entry i, rows [r0, r0 + nrows) of exemplar e (upper block and hands
+ * block, row offset n_lat + 1) of inv [S][Ep][T][D] go into rows [q0, q0 + nrows) of clip b -- level `lvl` into start_noise
+ * [B][T][D] (rg_splice_rows) and, when invl [S][B][T][D] is given, every level into it (rg_splice_rows_rep)
+ * (diffusion_architecture.py:386-407).  The entries' destinations do not overlap (raggesture.py:703-731 de-overlaps them). */
+#define RG_SPLICE_MAX 64
+typedef struct rg_splice_table {
+  int n;
+  int e[RG_SPLICE_MAX], b[RG_SPLICE_MAX], r0[RG_SPLICE_MAX], q0[RG_SPLICE_MAX], nrows[RG_SPLICE_MAX];
+} rg_splice_table;
+int rg_splice_many(rg_handle* h, const rg_splice_table* tab_host, const float* inv, float* start_noise, float* invl,
+                   int T, int D, int n_lat, int lvl, int S, int Ep, int B, void* stream);
+
 /* Exemplar splice: copy token rows [r0,r1) of src[b_src] into rows [q0,q1) of dst[b_dst]
  * for the upper block and the hands block (row offset n_lat+1)
  *   (diffusion_architecture.py:386-407).  src/dst are [*,T,D]. */

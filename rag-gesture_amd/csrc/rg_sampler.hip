@@ -226,6 +226,31 @@ __global__ void __launch_bounds__(kBlock) splice_kernel(const float4* __restrict
   }
 }
 
+// Every exemplar splice of a lane's batch in ONE launch (rg_splice_many): entry i = blockIdx.y copies the rows of exemplar
+// e[i] (upper block and hands block) into clip b[i] -- from inversion level `lvl` into the start noise, and, when the guidance
+// target is given, from every level into it.  One launch instead of two per exemplar (96 behind a chain of 48 exemplars).
+__global__ void __launch_bounds__(kBlock) splice_many_kernel(const rg_splice_table tab, const float4* __restrict__ inv,
+                                                            float4* __restrict__ start_noise, float4* __restrict__ invl, int d4,
+                                                            int T, int hands_off, int lvl, int S, int Ep, int B) {
+  const int i = blockIdx.y;
+  const int nrows = tab.nrows[i], e = tab.e[i], b = tab.b[i], r0 = tab.r0[i], q0 = tab.q0[i];
+  const int64_t per = (int64_t)2 * nrows * d4;
+  const int nslab = invl ? S + 1 : 1;                       // slab S (or 0): level lvl -> start noise
+  const int64_t total = per * nslab;
+  for (int64_t k = blockIdx.x * (int64_t)kBlock + threadIdx.x; k < total; k += (int64_t)gridDim.x * kBlock) {
+    const int sl = (int)(k / per);
+    const int64_t w = k % per;
+    const int r = (int)(w / d4), c = (int)(w % d4);
+    const int off = (r >= nrows) ? hands_off : 0;
+    const int rr = (r >= nrows) ? r - nrows : r;
+    const bool to_noise = sl == nslab - 1;
+    const int level = to_noise ? lvl : sl;
+    const float4 v = inv[(((int64_t)level * Ep + e) * T + r0 + off + rr) * d4 + c];
+    if (to_noise) start_noise[(((int64_t)b) * T + q0 + off + rr) * d4 + c] = v;
+    else invl[(((int64_t)sl * B + b) * T + q0 + off + rr) * d4 + c] = v;
+  }
+}
+
 __global__ void __launch_bounds__(kBlock) gather_rows_kernel(const float4* __restrict__ table,
                                                             const int64_t* __restrict__ idx, float4* __restrict__ out,
                                                             int n, int d4) {
@@ -345,6 +370,26 @@ extern "C" int rg_splice_rows_rep(rg_handle* h, const float* src, float* dst, in
   hipLaunchKernelGGL(splice_kernel, dim3(rg_grid_1d((int64_t)2 * nrows * d4 * nrep, kBlock)), dim3(kBlock), 0,
                      rg_stream(stream), (const float4*)src, (float4*)dst, d4, nrows, b_src * T + r0,
                      b_dst * T + q0, n_lat + 1, nrep, (int64_t)src_rep_stride * T, (int64_t)dst_rep_stride * T);
+  RG_CHECK_LAUNCH(h);
+  return RG_OK;
+}
+
+extern "C" int rg_splice_many(rg_handle* h, const rg_splice_table* tab_host, const float* inv, float* start_noise, float* invl,
+                              int T, int D, int n_lat, int lvl, int S, int Ep, int B, void* stream) {
+  RG_REQUIRE(h, tab_host && inv && start_noise, "null pointer");
+  const rg_splice_table& tab = *tab_host;
+  RG_REQUIRE(h, tab.n >= 0 && tab.n <= RG_SPLICE_MAX && D % 4 == 0 && S >= 1 && lvl >= 0 && lvl < S && Ep >= 1 && B >= 1, "bad shape");
+  int most = 0;
+  for (int i = 0; i < tab.n; ++i) {
+    RG_REQUIRE(h, tab.e[i] >= 0 && tab.e[i] < Ep && tab.b[i] >= 0 && tab.b[i] < B && tab.nrows[i] >= 0 && tab.r0[i] >= 0 && tab.q0[i] >= 0
+                   && tab.r0[i] + tab.nrows[i] <= n_lat && tab.q0[i] + tab.nrows[i] <= n_lat, "bad row ranges");
+    most = tab.nrows[i] > most ? tab.nrows[i] : most;
+  }
+  if (tab.n == 0 || most == 0) return RG_OK;
+  const int d4 = D / 4;
+  const int64_t work = (int64_t)2 * most * d4 * (invl ? S + 1 : 1);
+  hipLaunchKernelGGL(splice_many_kernel, dim3(rg_grid_1d(work, kBlock) > 64 ? 64 : rg_grid_1d(work, kBlock), tab.n), dim3(kBlock), 0,
+                     rg_stream(stream), tab, (const float4*)inv, (float4*)start_noise, (float4*)invl, d4, T, n_lat + 1, lvl, S, Ep, B);
   RG_CHECK_LAUNCH(h);
   return RG_OK;
 }

@@ -21,6 +21,7 @@ Differences that are deliberate and documented in DESIGN.md:
      for parity tests.
 """
 import collections
+import ctypes
 import contextlib
 import copy
 import os
@@ -1164,14 +1165,28 @@ class MotionDiffusion(torch.nn.Module):
     def _splice(self, st, ex, inv, Ep):
         """The inverted exemplar rows into the start noise (and, level by level, into the guidance target)."""
         h, rd = self.model.weights.h, st.retrieval_dict
+        lvl = st.inversion_start_time % st.S
+        rows = []
         for e, (b, q_idx) in enumerate(ex):
             r0, r1 = rd["retr_startends"][b][q_idx]
             q0, q1 = rd["query_startends"][b][q_idx]
             capi.require(r1 - r0 == q1 - q0, "unsupported argument: requires r1 - r0 == q1 - q0")
-            lvl = st.inversion_start_time % st.S
-            h.call("splice_rows", inv[lvl], st.start_noise, st.T, st.D, st.n_lat, e, b, r0, r1, q0, q1)
-            if st.use_insertion_guidance:
-                h.call("splice_rows_rep", inv, st.invl, st.T, st.D, st.n_lat, e, b, r0, r1, q0, q1, st.S, Ep, st.B)
+            rows.append((e, b, int(r0), int(q0), int(r1 - r0)))
+        # one launch per 64 exemplars (rg_splice_many) instead of two per exemplar: 96 small launches behind a lane's chain
+        invl = st.invl if st.use_insertion_guidance else None
+        capi.require(inv.is_contiguous() and st.start_noise.is_contiguous() and (invl is None or invl.is_contiguous()),
+                     "splice: contiguous tensors expected")
+        s_ = torch.cuda.current_stream().cuda_stream
+        for c0 in range(0, len(rows), sampler.SPLICE_MAX):
+            tab = sampler.SpliceTable()
+            chunk = rows[c0:c0 + sampler.SPLICE_MAX]
+            tab.n = len(chunk)
+            for i, (e, b, r0, q0, n) in enumerate(chunk):
+                tab.e[i], tab.b[i], tab.r0[i], tab.q0[i], tab.nrows[i] = e, b, r0, q0, n
+            rc = h.lib.rg_splice_many(h._h, ctypes.byref(tab), inv.data_ptr(), st.start_noise.data_ptr(),
+                                      None if invl is None else invl.data_ptr(), st.T, st.D, st.n_lat, lvl, st.S, Ep, st.B, ctypes.c_void_p(s_))
+            if rc != 0:
+                raise capi.RgError("rg_splice_many failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))
 
     def _inversion_pass(self, st):
         """lanes: exemplar inversion -> splice, per clip group, concurrently."""

@@ -20,6 +20,14 @@ from . import capi
 _vp, _f, _i = ctypes.c_void_p, ctypes.c_float, ctypes.c_int
 
 
+SPLICE_MAX = 64
+
+
+class SpliceTable(ctypes.Structure):
+    """include/rg_gesture.h: rg_splice_table (rg_splice_many)."""
+    _fields_ = [("n", _i)] + [(k, _i * SPLICE_MAX) for k in ("e", "b", "r0", "q0", "nrows")]
+
+
 class GlueArgs(ctypes.Structure):
     """include/rg_gesture.h: rg_glue_args (rg_cobatch_glue)."""
     _fields_ = [("out_c_a", _vp), ("out_u_a", _vp), ("x_a", _vp), ("out_c_b", _vp), ("out_u_b", _vp), ("x_b", _vp), ("x_b_copy", _vp),

@@ -38,7 +38,7 @@ def test_header_is_plain_c_and_struct_layouts_match_ctypes(rg, tmp_path):
     if cc is None:
         pytest.skip("no C compiler")
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
-    structs = [("rg_gemm_desc", rg.gemm.GemmDesc), ("rg_seq_args", rg.seqfwd.SeqArgs), ("rg_glue_args", rg.sampler.GlueArgs), ("rg_venc_args", rg.vencfwd.VencArgs),
+    structs = [("rg_gemm_desc", rg.gemm.GemmDesc), ("rg_seq_args", rg.seqfwd.SeqArgs), ("rg_glue_args", rg.sampler.GlueArgs), ("rg_splice_table", rg.sampler.SpliceTable), ("rg_venc_args", rg.vencfwd.VencArgs),
                ("rg_vdec_args", rg.vencfwd.VdecArgs)]
     src = tmp_path / "abi.c"
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rg_gesture.h"', 'int main(void) {']

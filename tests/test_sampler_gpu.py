@@ -95,3 +95,35 @@ def test_cfg_ddim_and_splice(env):
     dd = dst.cuda()
     h.call("splice_rows", src.cuda(), dd, T, D, 10, 1, 2, 2, 5, 1, 4)
     assert torch.equal(dd.cpu(), exp)
+
+
+@pytest.mark.parametrize("guided", [True, False])
+def test_splice_many_equals_the_splices_one_by_one(env, guided):
+    """rg_splice_many (every exemplar of a batch in one launch: level `lvl` into the start noise, all levels into the guidance
+    target) against rg_splice_rows / rg_splice_rows_rep per exemplar (diffusion_architecture.py:386-407), bit for bit, with
+    entries of different lengths, two exemplars in one clip and an empty entry."""
+    import ctypes
+    import importlib
+    rg = importlib.import_module("rag-gesture_amd")
+    h = env[0]
+    S, Ep, B, T, D, n_lat, lvl = 6, 5, 4, 43, 512, 10, 4
+    inv = _rand((S, Ep, T, D), 21).cuda()
+    entries = [(0, 2, 1, 0, 3), (1, 2, 5, 6, 2), (3, 0, 0, 7, 3), (4, 3, 2, 2, 0), (2, 1, 9, 9, 1)]      # (e, b, r0, q0, nrows)
+    sn_ref, sn = _rand((B, T, D), 22).cuda(), None
+    invl_ref = _rand((S, B, T, D), 23).cuda() if guided else None
+    sn, invl = sn_ref.clone(), (invl_ref.clone() if guided else None)
+    for e, b, r0, q0, n in entries:
+        h.call("splice_rows", inv[lvl], sn_ref, T, D, n_lat, e, b, r0, r0 + n, q0, q0 + n)
+        if guided:
+            h.call("splice_rows_rep", inv, invl_ref, T, D, n_lat, e, b, r0, r0 + n, q0, q0 + n, S, Ep, B)
+    tab = rg.sampler.SpliceTable()
+    tab.n = len(entries)
+    for i, (e, b, r0, q0, n) in enumerate(entries):
+        tab.e[i], tab.b[i], tab.r0[i], tab.q0[i], tab.nrows[i] = e, b, r0, q0, n
+    rc = h.lib.rg_splice_many(h._h, ctypes.byref(tab), inv.data_ptr(), sn.data_ptr(), None if invl is None else invl.data_ptr(),
+                              T, D, n_lat, lvl, S, Ep, B, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(sn, sn_ref) and (not guided or torch.equal(invl, invl_ref))
+    assert not torch.equal(sn, _rand((B, T, D), 22).cuda())
+
