@@ -237,7 +237,7 @@ class LongformSynthesizer:
                     gt = tuple(out[k][j:j + 1].to(dev).float() for k in ("motion", "facial", "trans"))
                     st["gt_so_far"] = gt if cidx == 0 else blend_window(st["gt_so_far"], gt, self.overlap)
 
-        with pinned_lanes(self.model, pipelined, rotation=min(4, self.model.batch_lanes), form=2):
+        with pinned_lanes(self.model, pipelined, rotation=min(4, getattr(self.model, "batch_lanes", 4)), form=2):
             pending, act_prev = None, None
             for cidx in range(n_win):
                 act = [ci for ci in mine if cidx < len(state[ci]["starts"])]     # clips that still have a window cidx
