@@ -202,11 +202,7 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         adr = reinterpret_cast<const unsigned char*>(a.pstream) + ((size_t)(st * NU + uid) * 8 << 10);
         cnt = 1; stride = 1;
       } else if (kind == 1) {     // weights: wstream [NU][8][64][1 KiB] (U_KV: [8][128] over two slots)
-#ifdef RG2_HOT_STREAM      // diagnostic (wrong results): every unit streams the SAME 512 KiB, so the stream always hits in L2
-        adr = reinterpret_cast<const unsigned char*>(a.wstream) + ((size_t)1 * 512 << 10);
-#else
         adr = reinterpret_cast<const unsigned char*>(a.wstream) + ((size_t)uid * 512 << 10);
-#endif
         cnt = (uid > 0 && uid < NU - 1 && idx == U_KV) ? 128 : 64;
         stride = cnt;
       } else if (cond) {          // A fragments of (layer, condition, clip): afrag [L][3][B][8][4 KiB]
@@ -428,12 +424,9 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
     constexpr bool STD = decltype(std_tag)::value;
     constexpr bool INIT = decltype(init_tag)::value;
     constexpr int NF = 16 * NJ;                    // fragments of the unit (64 or 32)
-    static_assert(NF % 8 == 0 && 8 % NJ == 0 && RD == 6, "groups of eight fragments, six in flight across the unit's ends");
-#ifndef RG2_LA
-#define RG2_LA 6
-#endif
-    constexpr int LA = RG2_LA;                     // fragments in flight inside the unit (6, or 7: the quad of fragment f - 1 refilled at once)
-    static_assert(LA == 6 || LA == 7, "look-ahead");
+    static_assert(NF % 8 == 0 && 8 % NJ == 0 && RD == 6, "groups of eight fragments, six in flight");
+    // (round 6 measured seven in flight -- the quad of fragment f - 1 refilled at once -- and every unit streaming the same
+    //  512 KiB, i.e. always from L2: 1 446 / 1 439 against 1 443 us per launch.  The stream's latency is not what the loop waits for.)
     LANE_LOCAL();
     TSTART();
     const unsigned char* pl = smem + lane * 16;
@@ -451,8 +444,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         const int j = f % NJ, s = s0 + f / NJ;
-        if (FIRST && f + 1 < 6) {      // the next fragment sits in the ring: landed when at most LA - 2 younger loads are outstanding
-          if (LA == 6 || f == 0) wait_vmcnt<4>(); else wait_vmcnt<5>();
+        if (FIRST && f + 1 < 6) {      // the next fragment sits in the ring: landed when at most 4 younger loads are outstanding
+          wait_vmcnt<4>();
           wr[f + 1] = *reinterpret_cast<const u32x4*>(rl + hs * 1024);
           hs = hs + 1 == RD ? 0 : hs + 1;
         }
@@ -472,11 +465,8 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
         if (LAST && f >= 2) {          // the stream's next six items go to the ring (slots in the order they were read from)
           issue(hs);
           hs = hs + 1 == RD ? 0 : hs + 1;
-        } else if (LA == 6) {
+        } else {
           issue_reg(wr[(f + 6) & 7]);
-        } else {                       // LA == 7: one more in flight from the unit's first fragment to its last group
-          if (FIRST && f == 0) issue_reg(wr[6]);
-          if (!(LAST && f >= 1)) issue_reg(wr[(f + 7) & 7]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
