@@ -37,7 +37,7 @@ enum rg_status {
  * compares it with rg_version() of the library it loaded (rag-gesture_amd/capi.py load_library does and refuses a mismatch).
  * 110 (round 6): rg_seq_args gains `form`; rg_seqx_forward, rg_lane_form.  100 -> 105 were the unversioned states of rounds
  * 1-5 (round 5 changed rg_seq_args -- gbuf in, l0 / l1 out -- and the afrag layout without a bump: ADVICE r05). */
-#define RG_VERSION 110
+#define RG_VERSION 111
 int rg_version(void);
 int rg_create(rg_handle** out, int device);
 void rg_destroy(rg_handle* h);
@@ -390,6 +390,12 @@ typedef struct rg_seq_args {
   int pairs;               /* 0: one workgroup per sequence (2 B workgroups); 1: one workgroup per clip runs the conditional
                               sequence, then its classifier-free twin (B workgroups, 1.7x as long: less CU time per forward,
                               for callers that run several narrow launches side by side) -- same results bit for bit */
+  int* glue_ctr;           /* or NULL.  DEVICE int [B], zero-initialised once by the caller and then left to the launches: with
+                              it, the forward ends with what rg_cobatch_glue does between two forwards of a loop (`glue` below;
+                              n_a + n_b == B, n_b may be 0; its out_* pointers are rows of `head`, its x_* rows of `x`) -- the
+                              workgroup that finishes the second of a clip's two sequences updates that clip's rows, so a loop
+                              step is ONE launch (csrc/rg_tail.h).  Same arithmetic, operation for operation. */
+  rg_glue_args glue;
 } rg_seq_args;
 
 int rg_seq_forward(rg_handle* h, const rg_seq_args* args_host, void* stream);

@@ -3,6 +3,7 @@
 // 16 B per lane coalesced accesses, grid-stride, no LDS.  (include/rg_gesture.h cites the
 // reference lines each one replaces.)
 #include "rg_common.h"
+#include "rg_tail.h"
 
 namespace {
 
@@ -11,11 +12,8 @@ constexpr int kBlock = 256;
 // The reference evaluates eps and the update as separate fp32 torch ops; keep the same
 // operation order and forbid FMA contraction so results match the fp32 oracle bit for bit.
 #pragma clang fp contract(off)
-__device__ __forceinline__ float ddim_one(float x, float x0, float c_recip, float c_recipm1,
-                                          float c_a, float c_b) {
-  float eps = (c_recip * x - x0) / c_recipm1;
-  return x0 * c_a + c_b * eps;
-}
+using rg_tail::ddim_one;     // (rg_tail.h: the denoiser kernels' tails do the same arithmetic)
+using rg_tail::cfg_one;
 
 __global__ void __launch_bounds__(kBlock) ddim_update_kernel(const float4* __restrict__ x,
                                                             const float4* __restrict__ x0,
@@ -30,12 +28,6 @@ __global__ void __launch_bounds__(kBlock) ddim_update_kernel(const float4* __res
     r.w = ddim_one(a.w, b.w, c_recip, c_recipm1, c_a, c_b);
     xo[i] = r;
   }
-}
-
-__device__ __forceinline__ float cfg_one(float oc, float ou, float jc, float ju, float w_c, float w_u) {
-  // reference order: out_text*both*js + out_text*text*js + out_none*retr/js + out_none*none/js;
-  // with (both,text) and (retr,none) pre-summed on the host (one of each pair is 0 for t>100).
-  return oc * w_c * jc + ou * w_u * ju;
 }
 
 // out / out_u: conditional and classifier-free rows of the denoiser output for the same clips; xo2: optional second copy of
@@ -153,59 +145,11 @@ __global__ void __launch_bounds__(kBlock) cobatch_glue_kernel(const rg_glue_args
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * kBlock) >> 6;
-  const int d4 = a.D >> 2;
   const int rows_a = a.n_a * a.T, rows = (a.n_a + a.n_b) * a.T;
-  const float two_over_numel = 2.0f / ((float)rows_a * (float)a.D);
+  const float two_over_numel = rg_tail::two_over_numel(a);
   for (int r = wave; r < rows; r += nwaves) {
     const bool ga = r < rows_a;
-    const int rl = ga ? r : r - rows_a;                       // row within its group
-    const float jc = a.js[rl % a.T], ju = 1.0f / jc;
-    const float4* oc = reinterpret_cast<const float4*>((ga ? a.out_c_a : a.out_c_b) + (int64_t)rl * a.D);
-    const float4* ou = reinterpret_cast<const float4*>((ga ? a.out_u_a : a.out_u_b) + (int64_t)rl * a.D);
-    float4* xr = reinterpret_cast<float4*>((ga ? a.x_a : a.x_b) + (int64_t)rl * a.D);
-    const float w_c = ga ? a.wc_a : a.wc_b, w_u = ga ? a.wu_a : a.wu_b;
-    const float c_recip = ga ? a.c_recip_a : a.c_recip_b, c_recipm1 = ga ? a.c_recipm1_a : a.c_recipm1_b;
-    const float c_a = ga ? a.ca_a : a.ca_b, c_b = ga ? a.cb_a : a.cb_b;
-    bool ins = false;                                         // the next step inserts on this row
-    const float4* s = nullptr;
-    if (ga && a.in_seq_next) {
-      s = reinterpret_cast<const float4*>(a.in_seq_next + (int64_t)rl * a.D);
-      bool nz = false;
-      for (int j = lane; j < d4; j += 64) {
-        float4 v = s[j];
-        nz |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
-      }
-      ins = __ballot(nz) != 0ull;
-    }
-    const float4* nn = ins ? reinterpret_cast<const float4*>(a.noise_next + (int64_t)rl * a.D) : nullptr;
-    float4* x2 = (!ga && a.x_b_copy) ? reinterpret_cast<float4*>(a.x_b_copy + (int64_t)rl * a.D) : nullptr;
-    for (int j = lane; j < d4; j += 64) {
-      const float4 c = oc[j], u = ou[j], x = xr[j];
-      float4 p, v;
-      p.x = cfg_one(c.x, u.x, jc, ju, w_c, w_u);
-      p.y = cfg_one(c.y, u.y, jc, ju, w_c, w_u);
-      p.z = cfg_one(c.z, u.z, jc, ju, w_c, w_u);
-      p.w = cfg_one(c.w, u.w, jc, ju, w_c, w_u);
-      v.x = ddim_one(x.x, p.x, c_recip, c_recipm1, c_a, c_b);
-      v.y = ddim_one(x.y, p.y, c_recip, c_recipm1, c_a, c_b);
-      v.z = ddim_one(x.z, p.z, c_recip, c_recipm1, c_a, c_b);
-      v.w = ddim_one(x.w, p.w, c_recip, c_recipm1, c_a, c_b);
-      if (ins) {
-        const float4 y = s[j], e = nn[j];
-        for (int it = 0; it < a.g_iter_next; ++it) {          // (rg_guidance_update; what follows overwrites it, as in the reference)
-          v.x = v.x - a.lr * (two_over_numel * (v.x - y.x));
-          v.y = v.y - a.lr * (two_over_numel * (v.y - y.y));
-          v.z = v.z - a.lr * (two_over_numel * (v.z - y.z));
-          v.w = v.w - a.lr * (two_over_numel * (v.w - y.w));
-        }
-        v.x = a.s_ab_next * y.x + a.s_1mab_next * e.x;
-        v.y = a.s_ab_next * y.y + a.s_1mab_next * e.y;
-        v.z = a.s_ab_next * y.z + a.s_1mab_next * e.z;
-        v.w = a.s_ab_next * y.w + a.s_1mab_next * e.w;
-      }
-      xr[j] = v;
-      if (x2) x2[j] = v;
-    }
+    rg_tail::glue_row<false>(a, ga, ga ? r : r - rows_a, lane, two_over_numel);      // (row within its group)
   }
 }
 

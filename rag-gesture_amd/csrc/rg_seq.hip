@@ -29,6 +29,7 @@
 // mogen/models/transformers/raggesture.py:1041-1085 (classifier-free row doubling).
 #define RG_PACK2_ONE      // (the kernel owns its SIMDs, RG_OWN_THE_SIMD: rg_common.h rg_pack2_bf16)
 #include "rg_common.h"
+#include "rg_tail.h"
 #include <type_traits>
 
 namespace {
@@ -779,8 +780,10 @@ __device__ __forceinline__ void run_sequence(const rg_seq_args& a, const int seq
     const int t = 16 * tb + l15;
     if (t < T) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4*>(a.head + ((size_t)seq * T + t) * DM + 64 * wave + 16 * j + 4 * g4) = out[j][tb];
+      for (int j = 0; j < 4; ++j) {
+        const size_t o = ((size_t)seq * T + t) * DM + 64 * wave + 16 * j + 4 * g4;
+        rg_tail::store_head(a.head, (unsigned)(o * 4), out[j][tb]);     // (written through: with the tail on, another workgroup of this launch reads it)
+      }
     }
   }
   wait_vmcnt<0>();
@@ -816,6 +819,11 @@ __device__ __forceinline__ void seq_block(const rg_seq_args& a, const int block,
   for (int pass = 0; pass < npass; ++pass) {
     run_sequence(a, seq0 + pass * B, smem);
     __syncthreads();     // descriptors, panels and statistics of the pass are dead in every wave
+    int* const ctr = rg_tail::late_ctr();
+    if (ctr && !a.dump_stage) {            // the loop step's update of this clip, if its other sequence is done (rg_tail.h)
+      const int c = seq0 + pass * B - (seq0 + pass * B >= B ? B : 0);
+      rg_tail::arrive_and_glue<NTH>(ctr, c, c, reinterpret_cast<int*>(smem), __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    }
   }
 }
 

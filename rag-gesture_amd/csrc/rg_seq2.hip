@@ -29,6 +29,7 @@
 #define RG_PACK2_ONE      // the one-instruction bf16 pair (rg_common.h rg_pack2_bf16): ONLY because rg_seq2_kernel owns its SIMDs (RG_OWN_THE_SIMD below)
 #endif
 #include "rg_common.h"
+#include "rg_tail.h"
 #include <type_traits>
 
 namespace {
@@ -1047,8 +1048,10 @@ __device__ __forceinline__ void run_pair(const rg_seq_args& a, const int sA, con
       const int t = 16 * tb + l15;
       if (t < T) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<f32x4*>(a.head + ((size_t)seqs[q] * T + t) * DM + 64 * wave + 16 * j + 4 * g4) = out[q][j][tb];
+        for (int j = 0; j < 4; ++j) {
+          const size_t o = ((size_t)seqs[q] * T + t) * DM + 64 * wave + 16 * j + 4 * g4;
+          rg_tail::store_head(a.head, (unsigned)(o * 4), out[q][j][tb]);     // (written through: with the tail on, another workgroup of this launch reads it)
+        }
       }
     }
   }
@@ -1104,6 +1107,9 @@ __device__ __forceinline__ void seq2_block(const rg_seq_args& a, const int block
     const int kind = a.pairs ? pass : kind0;
     run_pair(a, c0 + kind * B, c1 + kind * B, smem);
     __syncthreads();     // descriptors, panels and statistics of the pass are dead in every wave
+    int* const ctr = rg_tail::late_ctr();
+    if (ctr && !a.dump_stage)              // the loop step's update of these clips, where their other sequence is done (rg_tail.h)
+      rg_tail::arrive_and_glue<NTH>(ctr, c0, c1, reinterpret_cast<int*>(smem), __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
   }
 }
 

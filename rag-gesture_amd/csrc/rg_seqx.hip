@@ -14,6 +14,7 @@
 // Bodies: csrc/rg_seq.hip (run_sequence, seq_block), csrc/rg_seq2.hip (run_pair, seq2_block), compiled here once more.
 #define RG_SEQ_BODY_ONLY
 #include "rg_common.h"
+#include "rg_tail.h"      // (before the bodies: they include it inside their namespaces)
 #include <type_traits>
 
 namespace rgx_two {

@@ -441,7 +441,7 @@ class DenoiserSession:
             self.sq.chain_end()
 
     # ------------------------------------------------------------------ per step
-    def forward(self, x, step, step_b=None, split=None):
+    def forward(self, x, step, step_b=None, split=None, glue=None):
         """x [B,T,D] fp32 (device) at respaced step index `step`; returns the head output
         [2B,T,D] (rows [0,B) conditional, [B,2B) classifier-free) in self.head.
         step_b / split: the clips [split, B) are at step index step_b instead (two diffusion loops advancing in the same
@@ -451,7 +451,11 @@ class DenoiserSession:
         if split is not None and not (0 < split < B):
             step, step_b, split = (step if split >= B else step_b), None, None
         if self.sq is not None:
-            return self.sq.run(x.contiguous(), step, step_b, split)
+            if glue is not None and not x.is_contiguous():
+                raise capi.RgError("DenoiserSession.forward(glue=...): x is updated in place and must be contiguous")
+            return self.sq.run(x.contiguous(), step, step_b, split, glue=glue)
+        if glue is not None:
+            raise capi.RgError("DenoiserSession.forward(glue=...): the sequence-stationary engine only")
         if self.ln_mode == "auto":
             out = self._forward_guarded(x, step)     # settles the mode (one read-back; never inside a capture)
             if split is None:

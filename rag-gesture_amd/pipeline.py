@@ -345,7 +345,7 @@ class MotionDiffusion(torch.nn.Module):
                  genloss_acceleration_weight=True, genloss_hands_weight=2, genloss_smooth=True,
                  body_part_lossweights=None, device="cuda", precision="bf16", lanes=2, sample_lanes=None, session_options=None,
                  vae_options=None, async_results=False, slots=2, max_inflight=2, cobatch_lanes="batch", base_lanes=8,
-                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, dynamic_forms=False, dynamic_budget=None, invert_alone_wide=True, **kwargs):
+                 batch_lanes=4, lane_streams=None, calibrate_lanes=True, decode_stream=False, dynamic_forms=False, dynamic_budget=None, invert_alone_wide=True, tail_glue=True, **kwargs):
         super().__init__()
         # loss_* / diffusion_train / body_part_lossweights are training-only keys: accepted, unused
         self.model = build_submodule(model, device=device, **kwargs)
@@ -383,6 +383,7 @@ class MotionDiffusion(torch.nn.Module):
         # series, beside the lanes' launches) paces the pipeline instead of the chains (profiles/r06k_timed_region.txt).
         self.dynamic_forms, self._lane_state = bool(dynamic_forms), None
         self.invert_alone_wide = bool(invert_alone_wide)      # an inversion ALONE (a filling pipeline) as one workgroup per sequence
+        self.tail_glue = bool(tail_glue)      # co-batched chains: a loop step's update at the end of its forward (sampler.cobatched_loop)
         self.dynamic_budget = None if dynamic_budget is None else int(dynamic_budget)     # workgroups the lanes may hold together (None: the chip's compute units)
         self.rotation_lanes = None     # submit(): lanes in the rotation of whole batches (None: batch_lanes / base_lanes); longform.py pins 1
         self.form_lanes = None         # ... and how many of their chains really run side by side (None: all of them); longform.py: 2
@@ -1132,9 +1133,9 @@ class MotionDiffusion(torch.nn.Module):
                     x_all = torch.cat([s["xa"], s["xb"]], dim=0).contiguous()
                     out_b = torch.empty(S, Ep, T, D, device=dev)
                     sampler.cobatched_loop(sess, x_all, Bl, out_b, inverted_a=s["invl"], guidance_iters=gi, guidance_lr=lr,
-                                           inseq_noise_a=s["noise"], in_seq_a=s["in_seq"])
+                                           inseq_noise_a=s["noise"], in_seq_a=s["in_seq"], tail_glue=self.tail_glue)
                     return x_all[:Bl], out_b
-                key = ("cobatch", Bl, Ep, lane, T, self._slot, guided, pend.in_seq is not None, gi, lr)
+                key = ("cobatch", Bl, Ep, lane, T, self._slot, guided, pend.in_seq is not None, gi, lr, self.tail_glue)
                 xl, inv = self._graph_run(key, ins, loop, owner=okey)
                 pend.x_out[b0:b1].copy_(xl)
                 self._splice(st, ex, inv, Ep)

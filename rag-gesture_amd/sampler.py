@@ -28,14 +28,40 @@ class SpliceTable(ctypes.Structure):
     _fields_ = [("n", _i)] + [(k, _i * SPLICE_MAX) for k in ("e", "b", "r0", "q0", "nrows")]
 
 
-class GlueArgs(ctypes.Structure):
-    """include/rg_gesture.h: rg_glue_args (rg_cobatch_glue)."""
-    _fields_ = [("out_c_a", _vp), ("out_u_a", _vp), ("x_a", _vp), ("out_c_b", _vp), ("out_u_b", _vp), ("x_b", _vp), ("x_b_copy", _vp),
-                ("in_seq_next", _vp), ("noise_next", _vp), ("js", _vp),
-                ("n_a", _i), ("n_b", _i), ("T", _i), ("D", _i), ("g_iter_next", _i),
-                ("wc_a", _f), ("wu_a", _f), ("c_recip_a", _f), ("c_recipm1_a", _f), ("ca_a", _f), ("cb_a", _f),
-                ("wc_b", _f), ("wu_b", _f), ("c_recip_b", _f), ("c_recipm1_b", _f), ("ca_b", _f), ("cb_b", _f),
-                ("lr", _f), ("s_ab_next", _f), ("s_1mab_next", _f)]
+from .seqfwd import GlueArgs      # (rg_glue_args: also the tail of rg_seq_args)
+
+
+TAIL_GLUE = True     # the loops below end every forward with the step's update (rg_seq_args.glue_ctr, csrc/rg_tail.h) where they can
+
+
+def _tail_ok(sess, x):
+    """The loop step's update can ride at the end of the forward: sequence-stationary engine, x updated in place."""
+    return (TAIL_GLUE and getattr(sess, "sq", None) is not None and sess.h.recorder is None and x.is_cuda and x.is_contiguous()
+            and x.dtype == torch.float32 and x.shape[0] == sess.B)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+        raise capi.RgError("rg_cobatch_glue: contiguous fp32 device tensors expected")
+    return t.data_ptr()
+
+
+def _glue_sampling(sess, x, i, nxt, noise_nxt, g_next, lr):
+    """rg_glue_args of a sampling step at respaced index i over ALL clips of the session (its group a): this step's CFG + DDIM
+    update of x, then the NEXT step's guidance update (g_next iterations) and in-sequence replacement on the rows nxt marks."""
+    sch, w, B, T = sess.w.schedule, sess.w, sess.B, sess.w.T
+    a = GlueArgs()
+    a.out_c_a, a.out_u_a, a.x_a, a.js = _p(sess.head), _p(sess.head[B * T:]), _p(x), _p(w.js)
+    a.n_a, a.n_b, a.T, a.D = B, 0, T, w.D
+    a.wc_a, a.wu_a = sch.cfg_weights(w.cfg["scale_func_cfg"], i)
+    a.c_recip_a, a.c_recipm1_a, a.ca_a, a.cb_a = float(sch.c_recip[i]), float(sch.c_recipm1[i]), float(sch.c_prev_a[i]), float(sch.c_prev_b[i])
+    a.in_seq_next, a.noise_next = _p(nxt), (None if nxt is None else _p(noise_nxt))
+    a.g_iter_next, a.lr = (int(g_next) if nxt is not None else 0), float(lr)
+    if i > 0:
+        a.s_ab_next, a.s_1mab_next = float(sch.s_ab[i - 1]), float(sch.s_1mab[i - 1])
+    return a
 
 
 def _step(sess, x, i, in_seq=None, noise=None):
@@ -50,7 +76,16 @@ def _step(sess, x, i, in_seq=None, noise=None):
 def ddim_sample_loop(sess, x, in_seq=None, inseq_noise=None):
     """x: start noise [B,T,D] (updated in place and returned).  in_seq [B,T,D] or None;
     inseq_noise [S,B,T,D] = the randn_like(in_seq) draws, indexed by step."""
-    S = sess.w.schedule.num_timesteps
+    sch, w = sess.w.schedule, sess.w
+    S = sch.num_timesteps
+    if _tail_ok(sess, x):        # one launch per step: the first step's insertion in front, every later one in the tail before it
+        if in_seq is not None:
+            sess.h.call("inseq_replace", x, in_seq, inseq_noise[S - 1], sess.B * w.T, w.D, float(sch.s_ab[S - 1]), float(sch.s_1mab[S - 1]))
+        for i in range(S - 1, -1, -1):
+            nxt = in_seq if i > 0 else None
+            sess.forward(x, i, glue=_glue_sampling(sess, x, i, nxt, None if nxt is None else inseq_noise[i - 1], 0, 0.0))
+        sess.chain_end()
+        return x
     for i in range(S - 1, -1, -1):
         _step(sess, x, i, in_seq, None if in_seq is None else inseq_noise[i])
     sess.chain_end()
@@ -71,7 +106,18 @@ def p_sample_loop(sess, x, noise):
 def ddim_reverse_sample_loop(sess, x, out):
     """DDIM inversion of x [B,T,D] (clean -> noise); out [S,B,T,D] receives every level
     (out[k] = latent at alphas_cumprod_next[k]), x is updated in place to out[S-1]."""
-    sch = sess.w.schedule
+    sch, w = sess.w.schedule, sess.w
+    if _tail_ok(sess, x) and out.is_contiguous() and out.dtype == torch.float32:
+        B, T = sess.B, w.T           # one launch per step: x advances in place, the forward's tail also writes the level kept
+        for i in range(sch.num_timesteps):
+            a = GlueArgs()
+            a.out_c_b, a.out_u_b, a.x_b, a.x_b_copy, a.js = _p(sess.head), _p(sess.head[B * T:]), _p(x), _p(out[i]), _p(w.js)
+            a.n_a, a.n_b, a.T, a.D = 0, B, T, w.D
+            a.wc_b, a.wu_b = sch.cfg_weights(w.cfg["scale_func_cfg"], i)
+            a.c_recip_b, a.c_recipm1_b, a.ca_b, a.cb_b = float(sch.c_recip[i]), float(sch.c_recipm1[i]), float(sch.c_next_a[i]), float(sch.c_next_b[i])
+            sess.forward(x, i, glue=a)
+        sess.chain_end()
+        return out
     cur = x
     for i in range(sch.num_timesteps):
         sess.forward(cur, i)
@@ -90,6 +136,15 @@ def ddim_guided_sample_loop(sess, x, inverted, guidance_iters, guidance_lr, inse
     S = sch.num_timesteps
     capi.require(len(guidance_iters) == S == inverted.shape[0],
             "unsupported argument: requires len(guidance_iters) == S == inverted.shape[0]")
+    if _tail_ok(sess, x):        # one launch per step (as ddim_sample_loop; the next step's guidance update rides along)
+        if in_seq is not None:
+            h.call("inseq_replace", x, in_seq, inseq_noise[S - 1], sess.B * w.T, w.D, float(sch.s_ab[S - 1]), float(sch.s_1mab[S - 1]))
+        for i in range(S - 1, -1, -1):
+            nxt = inverted[i - 1] if i > 0 else None
+            sess.forward(x, i, glue=_glue_sampling(sess, x, i, nxt, None if nxt is None else inseq_noise[i - 1],
+                                                   guidance_iters[i - 1] if i > 0 else 0, guidance_lr))
+        sess.chain_end()
+        return x
     for i in range(S - 1, -1, -1):
         if i != S - 1:
             in_seq = inverted[i]
@@ -100,7 +155,7 @@ def ddim_guided_sample_loop(sess, x, inverted, guidance_iters, guidance_lr, inse
 
 
 def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None, guidance_lr=0.1, inseq_noise_a=None,
-                   in_seq_a=None, fused_glue=True):
+                   in_seq_a=None, fused_glue=True, tail_glue=True):
     """Two loops advancing in the same launches, one denoiser forward per step for both:
       clips [0, n_a) of the session: the (insertion-guided) DDIM sampling loop of one batch, exactly
         ddim_guided_sample_loop / ddim_sample_loop (inverted_a None) on x_all[:n_a], in place;
@@ -128,9 +183,13 @@ def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None
                 raise capi.RgError("rg_cobatch_glue: contiguous fp32 device tensors expected")
             return t.data_ptr()
         cfgw = lambda step: sch.cfg_weights(w.cfg["scale_func_cfg"], step)
+        # tail_glue: the forward's own workgroups do that launch's work as they finish (the one that ends a clip's second
+        # sequence updates the clip: rg_seq_args.glue_ctr, csrc/rg_tail.h) -- a loop step is ONE launch
+        tail = bool(tail_glue) and getattr(sess, "sq", None) is not None and x_all.is_contiguous() and 0 < n_a < B
         for k in range(S):
             i = S - 1 - k
-            sess.forward(x_all, i, step_b=k, split=n_a)
+            if not tail:
+                sess.forward(x_all, i, step_b=k, split=n_a)
             a = GlueArgs()
             a.out_c_a, a.out_u_a, a.x_a = p(head), p(head[B * T:]), p(xa)
             a.out_c_b, a.out_u_b, a.x_b, a.x_b_copy = p(head[n_a * T:]), p(head[(B + n_a) * T:]), p(xb), p(out_b[k])
@@ -148,6 +207,9 @@ def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None
             a.lr = float(guidance_lr)
             if i > 0:
                 a.s_ab_next, a.s_1mab_next = float(sch.s_ab[i - 1]), float(sch.s_1mab[i - 1])
+            if tail:
+                sess.forward(x_all, i, step_b=k, split=n_a, glue=a)
+                continue
             rc = h.lib.rg_cobatch_glue(h._h, ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
             if rc != 0:
                 raise capi.RgError("rg_cobatch_glue failed (%d): %s" % (rc, h.lib.rg_last_error(h._h).decode()))

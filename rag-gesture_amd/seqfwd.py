@@ -24,12 +24,23 @@ _vp = ctypes.c_void_p
 LANE_STRIDE = 32          # include/rg_gesture.h: RG_LANE_STRIDE (ints per lane record of the launch-form arbitration state)
 
 
+class GlueArgs(ctypes.Structure):
+    """include/rg_gesture.h: rg_glue_args (rg_cobatch_glue)."""
+    _fields_ = [("out_c_a", _vp), ("out_u_a", _vp), ("x_a", _vp), ("out_c_b", _vp), ("out_u_b", _vp), ("x_b", _vp), ("x_b_copy", _vp),
+                ("in_seq_next", _vp), ("noise_next", _vp), ("js", _vp),
+                ("n_a", ctypes.c_int), ("n_b", ctypes.c_int), ("T", ctypes.c_int), ("D", ctypes.c_int), ("g_iter_next", ctypes.c_int),
+                ("wc_a", ctypes.c_float), ("wu_a", ctypes.c_float), ("c_recip_a", ctypes.c_float), ("c_recipm1_a", ctypes.c_float), ("ca_a", ctypes.c_float), ("cb_a", ctypes.c_float),
+                ("wc_b", ctypes.c_float), ("wu_b", ctypes.c_float), ("c_recip_b", ctypes.c_float), ("c_recipm1_b", ctypes.c_float), ("ca_b", ctypes.c_float), ("cb_b", ctypes.c_float),
+                ("lr", ctypes.c_float), ("s_ab_next", ctypes.c_float), ("s_1mab_next", ctypes.c_float)]
+
+
 class SeqArgs(ctypes.Structure):
     _fields_ = [("wstream", _vp), ("pstream", _vp), ("ustream", _vp), ("afrag", _vp), ("x", _vp), ("tbias", _vp),
                 ("src_mask", _vp), ("qmask", _vp), ("head", _vp), ("dump", _vp), ("xbuf", _vp), ("gbuf", _vp), ("form", _vp),
                 ("L", ctypes.c_int), ("B", ctypes.c_int), ("T", ctypes.c_int), ("S", ctypes.c_int),
                 ("step", ctypes.c_int), ("step_b", ctypes.c_int), ("split", ctypes.c_int),
-                ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("pairs", ctypes.c_int)]
+                ("dump_stage", ctypes.c_int), ("dump_layer", ctypes.c_int), ("pairs", ctypes.c_int),
+                ("glue_ctr", _vp), ("glue", GlueArgs)]
 
 
 def supported(cfg, T, precision):
@@ -173,6 +184,7 @@ class SeqForward:
             self.xbuf = torch.empty(nwg * 2 * 8 * 12 * 64 * 4, device=dev, dtype=torch.float32)
             self.gbuf = torch.empty(nwg * 8 * 48 * 1024, device=dev, dtype=torch.uint8)
         self.afrag = torch.zeros(w.L, 3, B, 8, 2, 2, 64, 8, device=dev, dtype=torch.bfloat16)
+        self.glue_ctr = torch.zeros(B, device=dev, dtype=torch.int32)       # arrival counters of the forwards' tails (run(glue=...))
         a = self.args = SeqArgs()
         p = lambda t: t.data_ptr()
         a.wstream, a.pstream, a.ustream, a.afrag = p(self.st.wstream), p(self.st.pstream), p(self.st.ustream), p(self.afrag)
@@ -197,8 +209,16 @@ class SeqForward:
         """a_pre fp32 [L, 3, n, H, 32, 32] of the clips [o0, o1) of the session."""
         self.afrag[:, :, o0:o1] = a_fragments(a_pre)
 
-    def run(self, x, step, step_b=None, split=None, dump=None, dump_stage=0, dump_layer=0):
+    def run(self, x, step, step_b=None, split=None, dump=None, dump_stage=0, dump_layer=0, glue=None):
+        """glue: a GlueArgs (n_a + n_b == B clips; n_b may be 0) -- the forward ends with the loop step's update of x that
+        rg_cobatch_glue would do in a launch of its own (include/rg_gesture.h: rg_seq_args.glue_ctr; csrc/rg_tail.h)."""
         a = self.args
+        if glue is not None:
+            if glue.n_a + glue.n_b != self.sess.B or glue.T != self.sess.w.T or glue.D != self.sess.w.D or dump_stage:
+                raise capi.RgError("rg_seq_forward: the tail's groups must cover the session's clips (n_a + n_b == B)")
+            a.glue, a.glue_ctr = glue, self.glue_ctr.data_ptr()
+        else:
+            a.glue_ctr = None
         if not (x.is_contiguous() and x.dtype == torch.float32 and x.numel() == self.sess.B * self.sess.w.T * self.sess.w.D):
             raise capi.RgError("rg_seq_forward: x must be a contiguous fp32 [B, T, D] tensor")
         a.x, a.step = x.data_ptr(), int(step)
