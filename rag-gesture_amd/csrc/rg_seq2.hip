@@ -1131,6 +1131,7 @@ extern "C" int rg_seq2_forward(rg_handle* h, const rg_seq_args* args_host, void*
   RG_REQUIRE(h, a.step >= 0 && a.step < a.S && a.step_b >= 0 && a.step_b < a.S, "step out of range");
   RG_REQUIRE(h, a.dump_stage == 0 || a.dump, "dump_stage needs a dump buffer");
   RG_REQUIRE(h, a.pairs == 0 || a.pairs == 1, "pairs must be 0 or 1");
+  RG_REQUIRE(h, rg_tail::args_ok(a), "glue_ctr: glue must cover the B clips (n_a + n_b == B, T, D = 512), its pointers set, no dump");
   static rg_attr_once lds_once;
   if (!rg_reserve_lds(lds_once, rg_seq2_kernel, LDS_BYTES)) {
     h->err = "rg_seq2_forward: cannot reserve LDS";

@@ -56,6 +56,7 @@ extern "C" int rg_seqx_forward(rg_handle* h, const rg_seq_args* args_host, void*
   RG_REQUIRE(h, a.step >= 0 && a.step < a.S && a.step_b >= 0 && a.step_b < a.S, "step out of range");
   RG_REQUIRE(h, a.dump_stage == 0, "diagnostic dumps: use rg_seq_forward / rg_seq2_forward");
   RG_REQUIRE(h, a.pairs == 0 || a.pairs == 1, "pairs must be 0 or 1");
+  RG_REQUIRE(h, rg_tail::args_ok(a), "glue_ctr: glue must cover the B clips (n_a + n_b == B, T, D = 512), its pointers set, no dump");
   static rg_attr_once lds_once;
   if (!rg_reserve_lds(lds_once, rg_seqx_kernel, LDS_X)) {
     h->err = "rg_seqx_forward: cannot reserve LDS";

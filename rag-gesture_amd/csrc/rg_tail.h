@@ -161,4 +161,14 @@ __device__ __forceinline__ void arrive_and_glue(int* const ctr, const int c0, co
   }
 }
 
+// Host side: what the entry points require of args->glue when args->glue_ctr is set.
+inline bool args_ok(const rg_seq_args& a) {
+  if (!a.glue_ctr) return true;
+  const rg_glue_args& g = a.glue;
+  if (a.dump_stage || g.n_a < 0 || g.n_b < 0 || g.n_a + g.n_b != a.B || g.T != a.T || g.D != 512 || !g.js || g.g_iter_next < 0) return false;
+  if (g.n_a && !(g.out_c_a && g.out_u_a && g.x_a)) return false;
+  if (g.n_b && !(g.out_c_b && g.out_u_b && g.x_b)) return false;
+  return !g.in_seq_next || g.noise_next;
+}
+
 }  // namespace rg_tail

@@ -179,3 +179,27 @@ def test_single_loops_with_tail_equal_the_launch_pairs(rg, form):
     for run in res[True]:
         for name, a, b in zip(("sample", "guided+in_seq", "guided", "inverted x", "levels"), ref, run):
             assert torch.equal(a, b), name
+
+
+def test_tail_arguments_are_checked(rg):
+    """glue_ctr with a glue that does not cover the session's clips is refused by the entry points (and by the host wrapper)."""
+    import ctypes
+    cfg = rg.synth.default_model_cfg(num_layers=1)
+    W = rg.denoiser.DenoiserWeights(rg.synth.synth_denoiser_state(0, cfg), cfg, rg.schedule.Schedule(), "cuda", precision="bf16")
+    B, T, D = 2, 43, 512
+    d = rg.synth.synth_batch(B, seed=3)
+    x = torch.zeros(B, T, D, device="cuda")
+    for form in (dict(seq_duo=False), dict(seq_duo=True)):
+        sc = rg.denoiser.DenoiserSession(W, B, engine="seq", **form)
+        sc.set_conditions(d["word"], d["audio"], d["speaker_ids"], torch.ones(B, T), {c: torch.ones(B, T) for c in rg.denoiser.CONDS})
+        g = rg.sampler._glue_sampling(sc, x, 5, None, None, 0, 0.0)
+        g.n_a = 1                                                  # one clip without an update
+        with pytest.raises(rg.capi.RgError):
+            sc.forward(x, 5, glue=g)
+        a = sc.sq.args
+        a.x, a.step, a.step_b, a.split = x.data_ptr(), 5, 5, B
+        a.glue, a.glue_ctr = g, sc.sq.glue_ctr.data_ptr()
+        rc = sc.sq._fn(sc.h._h, ctypes.byref(a), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc != 0 and b"glue" in sc.h.lib.rg_last_error(sc.h._h)
+        a.glue_ctr = None
+    torch.cuda.synchronize()
