@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(kBlock) cobatch_glue_kernel(const rg_glue_args
   const float two_over_numel = rg_tail::two_over_numel(a);
   for (int r = wave; r < rows; r += nwaves) {
     const bool ga = r < rows_a;
-    rg_tail::glue_row<false>(a, ga, ga ? r : r - rows_a, lane, two_over_numel);      // (row within its group)
+    rg_tail::glue_row(a, ga, ga ? r : r - rows_a, lane, two_over_numel);      // (row within its group)
   }
 }
 

@@ -35,33 +35,67 @@ __device__ __forceinline__ float cfg_one(float oc, float ou, float jc, float ju,
   return oc * w_c * jc + ou * w_u * ju;
 }
 
-template <bool COH>
-__device__ __forceinline__ float4 load_out(const float* row, const int j) {
-  if (COH) {
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, 0x7fffffff, 0x00020000);
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, j * 16, 0, COHERENT);
-    return float4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
-  }
-  return reinterpret_cast<const float4*>(row)[j];
+template <typename P>
+__device__ __forceinline__ P* uniform_ptr(P* p) {       // a wave-uniform pointer the compiler does not know to be one
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  return reinterpret_cast<P*>((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) << 32 |
+                              (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v));
+}
+// 16 bytes of a head row past every cache: base (wave-uniform) + row_bytes (wave-uniform, a scalar operand) + 16 j
+__device__ __forceinline__ float4 load_out(const float* base, const unsigned row_bytes, const int j) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, j * 16, row_bytes, COHERENT);
+  return float4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
 }
 
-// One token row (group a: ga, row rl of the group = clip * T + token) by one wave:
-//   sampling rows (a):  x <- cfg_ddim(out_c, out_u, x) of this step; then, for the NEXT step, the insertion-guidance update and
-//                       the in-sequence replacement where its in_seq marks the row (rg_cfg_ddim_update_rows, rg_guidance_update,
-//                       rg_inseq_replace, in that order, operation for operation);
-//   inverting rows (b): x <- cfg_ddim(...) of this step with the inversion's coefficients, and a second copy (the level kept).
-template <bool COH>
-__device__ __forceinline__ void glue_row(const rg_glue_args& a, const bool ga, const int rl, const int lane,
-                                         const float two_over_numel) {
+// The group's coefficients of a step.
+struct step_coef { float w_c, w_u, c_recip, c_recipm1, c_a, c_b; };
+__device__ __forceinline__ step_coef coef_of(const rg_glue_args& a, const bool ga) {
+  return ga ? step_coef{a.wc_a, a.wu_a, a.c_recip_a, a.c_recipm1_a, a.ca_a, a.cb_a}
+            : step_coef{a.wc_b, a.wu_b, a.c_recip_b, a.c_recipm1_b, a.ca_b, a.cb_b};
+}
+
+// Four consecutive features of one token row: x <- cfg_ddim(out_c, out_u, x) of this step; then, where the NEXT step inserts on
+// the row (ins; y = its in_seq, e = its noise draw), the insertion-guidance update and the in-sequence replacement
+// (rg_cfg_ddim_update_rows, rg_guidance_update, rg_inseq_replace, in that order, operation for operation).
+__device__ __forceinline__ float4 glue_elem(const rg_glue_args& a, const step_coef& k, const float4 c, const float4 u, const float4 x,
+                                            const float jc, const float ju, const bool ins, const float4 y, const float4 e,
+                                            const float two_over_numel) {
 #pragma clang fp contract(off)
+  float4 p, v;
+  p.x = cfg_one(c.x, u.x, jc, ju, k.w_c, k.w_u);
+  p.y = cfg_one(c.y, u.y, jc, ju, k.w_c, k.w_u);
+  p.z = cfg_one(c.z, u.z, jc, ju, k.w_c, k.w_u);
+  p.w = cfg_one(c.w, u.w, jc, ju, k.w_c, k.w_u);
+  v.x = ddim_one(x.x, p.x, k.c_recip, k.c_recipm1, k.c_a, k.c_b);
+  v.y = ddim_one(x.y, p.y, k.c_recip, k.c_recipm1, k.c_a, k.c_b);
+  v.z = ddim_one(x.z, p.z, k.c_recip, k.c_recipm1, k.c_a, k.c_b);
+  v.w = ddim_one(x.w, p.w, k.c_recip, k.c_recipm1, k.c_a, k.c_b);
+  if (ins) {
+    for (int it = 0; it < a.g_iter_next; ++it) {          // (rg_guidance_update; what follows overwrites it, as in the reference)
+      v.x = v.x - a.lr * (two_over_numel * (v.x - y.x));
+      v.y = v.y - a.lr * (two_over_numel * (v.y - y.y));
+      v.z = v.z - a.lr * (two_over_numel * (v.z - y.z));
+      v.w = v.w - a.lr * (two_over_numel * (v.w - y.w));
+    }
+    v.x = a.s_ab_next * y.x + a.s_1mab_next * e.x;
+    v.y = a.s_ab_next * y.y + a.s_1mab_next * e.y;
+    v.z = a.s_ab_next * y.z + a.s_1mab_next * e.z;
+    v.w = a.s_ab_next * y.w + a.s_1mab_next * e.w;
+  }
+  return v;
+}
+
+// One token row (group a: ga, row rl of the group = clip * T + token) by one wave (rg_cobatch_glue's launch):
+//   sampling rows (a):  this step's update, then the next step's guidance update and in-sequence replacement on marked rows;
+//   inverting rows (b): this step's update with the inversion's coefficients, and a second copy (the level kept).
+__device__ __forceinline__ void glue_row(const rg_glue_args& a, const bool ga, const int rl, const int lane, const float two_over_numel) {
   const int d4 = a.D >> 2;
   const float jc = a.js[rl % a.T], ju = 1.0f / jc;
-  const float* oc = (ga ? a.out_c_a : a.out_c_b) + (int64_t)rl * a.D;
-  const float* ou = (ga ? a.out_u_a : a.out_u_b) + (int64_t)rl * a.D;
+  const float4* oc = reinterpret_cast<const float4*>((ga ? a.out_c_a : a.out_c_b) + (int64_t)rl * a.D);
+  const float4* ou = reinterpret_cast<const float4*>((ga ? a.out_u_a : a.out_u_b) + (int64_t)rl * a.D);
   float4* xr = reinterpret_cast<float4*>((ga ? a.x_a : a.x_b) + (int64_t)rl * a.D);
-  const float w_c = ga ? a.wc_a : a.wc_b, w_u = ga ? a.wu_a : a.wu_b;
-  const float c_recip = ga ? a.c_recip_a : a.c_recip_b, c_recipm1 = ga ? a.c_recipm1_a : a.c_recipm1_b;
-  const float c_a = ga ? a.ca_a : a.ca_b, c_b = ga ? a.cb_a : a.cb_b;
+  const step_coef k = coef_of(a, ga);
   bool ins = false;                                         // the next step inserts on this row
   const float4* s = nullptr;
   if (ga && a.in_seq_next) {
@@ -75,32 +109,76 @@ __device__ __forceinline__ void glue_row(const rg_glue_args& a, const bool ga, c
   }
   const float4* nn = ins ? reinterpret_cast<const float4*>(a.noise_next + (int64_t)rl * a.D) : nullptr;
   float4* x2 = (!ga && a.x_b_copy) ? reinterpret_cast<float4*>(a.x_b_copy + (int64_t)rl * a.D) : nullptr;
+  const float4 zero{0.f, 0.f, 0.f, 0.f};
   for (int j = lane; j < d4; j += 64) {
-    const float4 c = load_out<COH>(oc, j), u = load_out<COH>(ou, j), x = xr[j];
-    float4 p, v;
-    p.x = cfg_one(c.x, u.x, jc, ju, w_c, w_u);
-    p.y = cfg_one(c.y, u.y, jc, ju, w_c, w_u);
-    p.z = cfg_one(c.z, u.z, jc, ju, w_c, w_u);
-    p.w = cfg_one(c.w, u.w, jc, ju, w_c, w_u);
-    v.x = ddim_one(x.x, p.x, c_recip, c_recipm1, c_a, c_b);
-    v.y = ddim_one(x.y, p.y, c_recip, c_recipm1, c_a, c_b);
-    v.z = ddim_one(x.z, p.z, c_recip, c_recipm1, c_a, c_b);
-    v.w = ddim_one(x.w, p.w, c_recip, c_recipm1, c_a, c_b);
-    if (ins) {
-      const float4 y = s[j], e = nn[j];
-      for (int it = 0; it < a.g_iter_next; ++it) {          // (rg_guidance_update; what follows overwrites it, as in the reference)
-        v.x = v.x - a.lr * (two_over_numel * (v.x - y.x));
-        v.y = v.y - a.lr * (two_over_numel * (v.y - y.y));
-        v.z = v.z - a.lr * (two_over_numel * (v.z - y.z));
-        v.w = v.w - a.lr * (two_over_numel * (v.w - y.w));
-      }
-      v.x = a.s_ab_next * y.x + a.s_1mab_next * e.x;
-      v.y = a.s_ab_next * y.y + a.s_1mab_next * e.y;
-      v.z = a.s_ab_next * y.z + a.s_1mab_next * e.z;
-      v.w = a.s_ab_next * y.w + a.s_1mab_next * e.w;
-    }
+    const float4 v = glue_elem(a, k, oc[j], ou[j], xr[j], jc, ju, ins, ins ? s[j] : zero, ins ? nn[j] : zero, two_over_numel);
     xr[j] = v;
     if (x2) x2[j] = v;
+  }
+}
+
+// A whole clip (group a: ga, clip cl of the group) by the NW waves of a workgroup, at the end of a forward (D = 512: a row is
+// two 16-byte pieces per lane; T <= 48: NB batches of RPW rows per wave).  The same arithmetic; what differs is the order of the
+// memory operations: every load of a batch of rows is issued before the first result is needed -- row after row, each a chain of
+// loads that miss every cache (the head rows) in front of its stores, the clip took ~18 us of a compute unit's time per step.
+// 16 bytes of global memory (the pointers below have lost their provenance: say which address space they point to)
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
+__device__ __forceinline__ float4 gload(const float* p, const int j) {
+  const f32x4 v = ((const gf32x4*)p)[j];
+  return float4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void gstore(float* p, const int j, const float4 v) { ((gf32x4*)p)[j] = f32x4{v.x, v.y, v.z, v.w}; }
+template <int NW>
+__device__ __forceinline__ void glue_clip(const rg_glue_args& a, const bool ga, const int cl, const int wave, const int lane,
+                                          const float two_over_numel) {
+  constexpr int RPW = 3, NB = (48 + NW * RPW - 1) / (NW * RPW);     // rows per wave and batch; batches (120 registers of loads each)
+  const int T = a.T;
+  const step_coef k = coef_of(a, ga);
+  const float* const oc0 = uniform_ptr(ga ? a.out_c_a : a.out_c_b);
+  const float* const ou0 = uniform_ptr(ga ? a.out_u_a : a.out_u_b);
+  float* const x0 = uniform_ptr(ga ? a.x_a : a.x_b);
+  const bool marks = ga && a.in_seq_next;
+  // (without marks the two loads below read x instead: valid memory, values unused -- no branch between the loads of a batch)
+  const float* const y0 = uniform_ptr(marks ? a.in_seq_next : x0);
+  const float* const e0 = uniform_ptr(marks ? a.noise_next : x0);
+  float* const x2_0 = uniform_ptr((!ga && a.x_b_copy) ? a.x_b_copy : nullptr);
+#pragma unroll 1
+  for (int nb = 0; nb < NB; ++nb) {
+    float4 C[RPW][2], U[RPW][2], X[RPW][2], Y[RPW][2], E[RPW][2];
+    float jc[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int t = min(wave + NW * (RPW * nb + i), T - 1);                // (rows beyond T: a valid row again, nothing stored)
+      const int row = __builtin_amdgcn_readfirstlane(cl * T + t);         // (uniform by construction; says so to the compiler)
+      const int64_t o = (int64_t)row * 512;
+      jc[i] = a.js[t];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        C[i][h] = load_out(oc0, (unsigned)row * 2048u, lane + 64 * h);
+        U[i][h] = load_out(ou0, (unsigned)row * 2048u, lane + 64 * h);
+        X[i][h] = gload(x0 + o, lane + 64 * h);
+        Y[i][h] = gload(y0 + o, lane + 64 * h);
+        E[i][h] = gload(e0 + o, lane + 64 * h);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int t = wave + NW * (RPW * nb + i);
+      const int64_t o = (int64_t)__builtin_amdgcn_readfirstlane(cl * T + min(t, T - 1)) * 512;
+      bool nz = false;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) nz |= (Y[i][h].x != 0.f) | (Y[i][h].y != 0.f) | (Y[i][h].z != 0.f) | (Y[i][h].w != 0.f);
+      const bool ins = marks && __ballot(nz) != 0ull;                     // the next step inserts on this row
+      const float ju = 1.0f / jc[i];
+      if (t < T) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 v = glue_elem(a, k, C[i][h], U[i][h], X[i][h], jc[i], ju, ins, Y[i][h], E[i][h], two_over_numel);
+          gstore(x0 + o, lane + 64 * h, v);
+          if (x2_0) gstore(x2_0 + o, lane + 64 * h, v);
+        }
+      }
+    }
   }
 }
 
@@ -156,8 +234,7 @@ __device__ __forceinline__ void arrive_and_glue(int* const ctr, const int c0, co
     const int c = q ? c1 : c0;
     const bool ga = c < g.n_a;
     const int cl = ga ? c : c - g.n_a;
-#pragma unroll 1
-    for (int t = wave; t < g.T; t += NTH / 64) glue_row<true>(g, ga, cl * g.T + t, lane, ton);
+    glue_clip<NTH / 64>(g, ga, cl, wave, lane, ton);
   }
 }
 

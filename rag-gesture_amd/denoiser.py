@@ -261,7 +261,7 @@ class DenoiserSession:
     DEFAULT_ENGINE = "seq"
 
     def __init__(self, weights, B, ln_mode="auto", styl_prepass=True, xcd_affine=True, engine=None,
-                 kv_grouped=True, kv_fused=True, seq_pairs=False, seq_duo=None, lane_dyn=None):
+                 kv_grouped=True, kv_fused=True, seq_pairs=False, seq_duo=None, lane_dyn=None, tail_glue=True):
         """engine: "seq" = the whole forward as ONE launch, one workgroup per sequence, activations resident in registers /
         LDS, weights streamed (rg_seq_forward, csrc/rg_seq.hip; bf16 production path, D = 512, FF = 1024, T <= 48); "chain" =
         one launch per op (~90 per forward: rg_gemm + attention + stylization kernels).  None = "seq" where the shape is
@@ -278,6 +278,9 @@ class DenoiserSession:
         styl_prepass / xcd_affine: measurement knobs of the launch chain (NOTEBOOK section 6).  (Round 5 removed three more
         that no default used and every measurement had gone against: sa_fused, styl_in_gemm, tile64; and seq_launches, the
         forward cut into several launches by layer ranges: no gain on the step, NOTEBOOK 8.4.)"""
+        # tail_glue: the DDIM loops over this session end every forward with the step's update (one launch per step; sampler.py,
+        # csrc/rg_tail.h) -- False keeps the update in launches of its own (same bits)
+        self.tail_glue = bool(tail_glue)
         # kv_grouped (bf16): the conditions' K / V projections of DenoiserWeights.KV_GROUP layers per GEMM on a bf16 normalised
         # operand (set_conditions); False = one fp32-A GEMM with a LayerNorm prologue per layer and condition (round 1-3)
         self.kv_grouped = bool(kv_grouped)

@@ -587,6 +587,7 @@ class MotionDiffusion(torch.nn.Module):
     def _session_opts(self, B, role, lane):
         """Constructor options of the session (B, role, lane): the launch form resolved from the CURRENT rotation."""
         opts = dict(self.session_options)
+        opts.setdefault("tail_glue", self.tail_glue)
         if opts.get("seq_pairs", "auto") == "auto":
             opts["seq_pairs"], duo = self._seq_form_auto(B)
             if opts.get("seq_duo") is None:

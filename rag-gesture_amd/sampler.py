@@ -36,7 +36,7 @@ TAIL_GLUE = True     # the loops below end every forward with the step's update 
 
 def _tail_ok(sess, x):
     """The loop step's update can ride at the end of the forward: sequence-stationary engine, x updated in place."""
-    return (TAIL_GLUE and getattr(sess, "sq", None) is not None and sess.h.recorder is None and x.is_cuda and x.is_contiguous()
+    return (TAIL_GLUE and getattr(sess, "tail_glue", True) and getattr(sess, "sq", None) is not None and sess.h.recorder is None and x.is_cuda and x.is_contiguous()
             and x.dtype == torch.float32 and x.shape[0] == sess.B)
 
 
@@ -185,7 +185,7 @@ def cobatched_loop(sess, x_all, n_a, out_b, inverted_a=None, guidance_iters=None
         cfgw = lambda step: sch.cfg_weights(w.cfg["scale_func_cfg"], step)
         # tail_glue: the forward's own workgroups do that launch's work as they finish (the one that ends a clip's second
         # sequence updates the clip: rg_seq_args.glue_ctr, csrc/rg_tail.h) -- a loop step is ONE launch
-        tail = bool(tail_glue) and getattr(sess, "sq", None) is not None and x_all.is_contiguous() and 0 < n_a < B
+        tail = bool(tail_glue) and _tail_ok(sess, x_all) and 0 < n_a < B
         for k in range(S):
             i = S - 1 - k
             if not tail:
